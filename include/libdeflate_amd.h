@@ -1,0 +1,288 @@
+/*
+ * libdeflate_amd.h - C-ABI of the MI355X-native whole-buffer DEFLATE engine.
+ *
+ * Two groups of entry points, all `extern "C"`, plain pointers and sizes:
+ *
+ *  (1) The 21 `libdeflate_*` symbols of the reference's public header
+ *      (/root/reference/libdeflate.h, v1.25) with identical signatures,
+ *      argument meaning, return conventions and error codes, so that a
+ *      program written against libdeflate links against libdeflate_amd.so
+ *      unchanged.  Each declaration cites the reference line it replaces.
+ *      `in`/`out` are HOST pointers, exactly as in the reference; every call
+ *      is executed as a batch of one on the GPU (H2D, kernels, D2H).  There
+ *      is NO CPU fallback: without a usable gfx950 device the allocators
+ *      return NULL and the checksum calls abort() with a message on stderr.
+ *
+ *  (2) The additive batch extension `libdeflate_amd_*`: the same operations
+ *      over N independent chunks that are ALREADY RESIDENT IN HBM, described
+ *      by offset/size arrays (also in HBM).  This is the hot path bench.py
+ *      measures; one 64-lane wavefront (decode, checksums) or one workgroup
+ *      (LZ77 parse) per chunk.  `stream` is a hipStream_t passed as void*
+ *      (NULL = the default stream); the calls enqueue work and return.
+ *
+ * Result conventions are the reference's: compress -> bytes written, 0 when
+ * the output does not fit (libdeflate.h:73-74); decompress ->
+ * enum libdeflate_result (libdeflate.h:194-209).
+ */
+#ifndef LIBDEFLATE_AMD_H
+#define LIBDEFLATE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIBDEFLATE_VERSION_MAJOR	1	/* libdeflate.h:15 */
+#define LIBDEFLATE_VERSION_MINOR	25	/* libdeflate.h:16 */
+#define LIBDEFLATE_VERSION_STRING	"1.25"	/* libdeflate.h:17 */
+#define LIBDEFLATE_AMD_VERSION_STRING	"0.1-gfx950"
+
+#ifndef LIBDEFLATEAPI
+#  define LIBDEFLATEAPI __attribute__((visibility("default")))
+#endif
+
+struct libdeflate_compressor;	/* opaque; host object + device scratch */
+struct libdeflate_decompressor;	/* opaque */
+
+/* libdeflate.h:379-406 - per-object allocator override */
+struct libdeflate_options {
+	size_t sizeof_options;		/* must equal sizeof(struct) */
+	void *(*malloc_func)(size_t);	/* NULL -> global / malloc */
+	void (*free_func)(void *);
+};
+
+/* libdeflate.h:194-209 */
+enum libdeflate_result {
+	LIBDEFLATE_SUCCESS = 0,
+	LIBDEFLATE_BAD_DATA = 1,
+	LIBDEFLATE_SHORT_OUTPUT = 2,
+	LIBDEFLATE_INSUFFICIENT_SPACE = 3,
+};
+
+/* ------------------------------------------------------------------ */
+/* (1) drop-in single-buffer API (host pointers)                       */
+/* ------------------------------------------------------------------ */
+
+/* libdeflate.h:59-60; level 0..12, -1 = 6; NULL on bad level / OOM / no GPU */
+LIBDEFLATEAPI struct libdeflate_compressor *
+libdeflate_alloc_compressor(int compression_level);
+
+/* libdeflate.h:65-67 */
+LIBDEFLATEAPI struct libdeflate_compressor *
+libdeflate_alloc_compressor_ex(int compression_level,
+			       const struct libdeflate_options *options);
+
+/* libdeflate.h:85-88 */
+LIBDEFLATEAPI size_t
+libdeflate_deflate_compress(struct libdeflate_compressor *compressor,
+			    const void *in, size_t in_nbytes,
+			    void *out, size_t out_nbytes_avail);
+
+/* libdeflate.h:114-116; compressor may be NULL */
+LIBDEFLATEAPI size_t
+libdeflate_deflate_compress_bound(struct libdeflate_compressor *compressor,
+				  size_t in_nbytes);
+
+/* libdeflate.h:122-125 */
+LIBDEFLATEAPI size_t
+libdeflate_zlib_compress(struct libdeflate_compressor *compressor,
+			 const void *in, size_t in_nbytes,
+			 void *out, size_t out_nbytes_avail);
+
+/* libdeflate.h:132-134 */
+LIBDEFLATEAPI size_t
+libdeflate_zlib_compress_bound(struct libdeflate_compressor *compressor,
+			       size_t in_nbytes);
+
+/* libdeflate.h:140-143 */
+LIBDEFLATEAPI size_t
+libdeflate_gzip_compress(struct libdeflate_compressor *compressor,
+			 const void *in, size_t in_nbytes,
+			 void *out, size_t out_nbytes_avail);
+
+/* libdeflate.h:150-152 */
+LIBDEFLATEAPI size_t
+libdeflate_gzip_compress_bound(struct libdeflate_compressor *compressor,
+			       size_t in_nbytes);
+
+/* libdeflate.h:159-160; NULL is a no-op */
+LIBDEFLATEAPI void
+libdeflate_free_compressor(struct libdeflate_compressor *compressor);
+
+/* libdeflate.h:181-182 */
+LIBDEFLATEAPI struct libdeflate_decompressor *
+libdeflate_alloc_decompressor(void);
+
+/* libdeflate.h:187-188 */
+LIBDEFLATEAPI struct libdeflate_decompressor *
+libdeflate_alloc_decompressor_ex(const struct libdeflate_options *options);
+
+/* libdeflate.h:242-246 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_deflate_decompress(struct libdeflate_decompressor *decompressor,
+			      const void *in, size_t in_nbytes,
+			      void *out, size_t out_nbytes_avail,
+			      size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:254-259 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_deflate_decompress_ex(struct libdeflate_decompressor *decompressor,
+				 const void *in, size_t in_nbytes,
+				 void *out, size_t out_nbytes_avail,
+				 size_t *actual_in_nbytes_ret,
+				 size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:269-273 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_zlib_decompress(struct libdeflate_decompressor *decompressor,
+			   const void *in, size_t in_nbytes,
+			   void *out, size_t out_nbytes_avail,
+			   size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:282-287 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_zlib_decompress_ex(struct libdeflate_decompressor *decompressor,
+			      const void *in, size_t in_nbytes,
+			      void *out, size_t out_nbytes_avail,
+			      size_t *actual_in_nbytes_ret,
+			      size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:297-301 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_gzip_decompress(struct libdeflate_decompressor *decompressor,
+			   const void *in, size_t in_nbytes,
+			   void *out, size_t out_nbytes_avail,
+			   size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:310-315 */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_gzip_decompress_ex(struct libdeflate_decompressor *decompressor,
+			      const void *in, size_t in_nbytes,
+			      void *out, size_t out_nbytes_avail,
+			      size_t *actual_in_nbytes_ret,
+			      size_t *actual_out_nbytes_ret);
+
+/* libdeflate.h:322-323; NULL is a no-op */
+LIBDEFLATEAPI void
+libdeflate_free_decompressor(struct libdeflate_decompressor *decompressor);
+
+/* libdeflate.h:335-336; initial value 1; buffer == NULL -> 1 */
+LIBDEFLATEAPI uint32_t
+libdeflate_adler32(uint32_t adler, const void *buffer, size_t len);
+
+/* libdeflate.h:345-346; initial value 0; buffer == NULL -> 0 */
+LIBDEFLATEAPI uint32_t
+libdeflate_crc32(uint32_t crc, const void *buffer, size_t len);
+
+/* libdeflate.h:363-365 */
+LIBDEFLATEAPI void
+libdeflate_set_memory_allocator(void *(*malloc_func)(size_t),
+				void (*free_func)(void *));
+
+/* ------------------------------------------------------------------ */
+/* (2) batch extension: N independent chunks resident in HBM            */
+/* ------------------------------------------------------------------ */
+
+enum libdeflate_amd_format {
+	LIBDEFLATE_AMD_DEFLATE = 0,	/* raw DEFLATE     */
+	LIBDEFLATE_AMD_ZLIB = 1,	/* + 2 B header, Adler-32 footer (BE) */
+	LIBDEFLATE_AMD_GZIP = 2,	/* + 10 B header, CRC-32 + ISIZE (LE) */
+};
+
+/* status of the library itself (not of a stream) */
+enum libdeflate_amd_status {
+	LIBDEFLATE_AMD_OK = 0,
+	LIBDEFLATE_AMD_NO_DEVICE = -1,	/* no gfx950 device / HIP runtime error */
+	LIBDEFLATE_AMD_BAD_ARG = -2,
+	LIBDEFLATE_AMD_OOM = -3,	/* hipMalloc of scratch failed */
+};
+
+/* 0 when a usable device is present; never falls back to the CPU */
+LIBDEFLATEAPI int libdeflate_amd_device_ready(void);
+/* human-readable reason for the last non-OK status (thread-local) */
+LIBDEFLATEAPI const char *libdeflate_amd_last_error(void);
+
+/*
+ * Chunk i of a batch occupies bytes [offsets[i], offsets[i] + nbytes[i]) of a
+ * base buffer.  `d_` pointers are device pointers.  Offsets/sizes are u64 so
+ * the same descriptors serve 4 KiB filesystem blocks and multi-GiB buffers.
+ *
+ * Compress: for each chunk writes a complete stream of `format` into its
+ * output slot and the stream size into d_out_nbytes[i] (0 = did not fit in
+ * d_out_avail[i], same rule as libdeflate.h:73-74).
+ * Batch counterpart of libdeflate_{deflate,zlib,gzip}_compress
+ * (libdeflate.h:85-88,122-125,140-143).
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_compress_batch(struct libdeflate_compressor *compressor,
+			      int format, size_t n_chunks,
+			      const void *d_in, const uint64_t *d_in_offsets,
+			      const uint64_t *d_in_nbytes,
+			      void *d_out, const uint64_t *d_out_offsets,
+			      const uint64_t *d_out_avail,
+			      uint64_t *d_out_nbytes, void *stream);
+
+/*
+ * Decompress: d_results[i] receives the enum libdeflate_result of chunk i.
+ * d_actual_in / d_actual_out may be NULL; a NULL d_actual_out has the
+ * reference's meaning (the stream must fill d_out_avail[i] exactly, else
+ * SHORT_OUTPUT, decompress_template.h:765-770).  A failed chunk never
+ * affects its neighbours.  Batch counterpart of
+ * libdeflate_{deflate,zlib,gzip}_decompress_ex (libdeflate.h:254-259,
+ * 282-287,310-315).
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_decompress_batch(struct libdeflate_decompressor *decompressor,
+				int format, size_t n_chunks,
+				const void *d_in, const uint64_t *d_in_offsets,
+				const uint64_t *d_in_nbytes,
+				void *d_out, const uint64_t *d_out_offsets,
+				const uint64_t *d_out_avail,
+				int32_t *d_results,
+				uint64_t *d_actual_in, uint64_t *d_actual_out,
+				void *stream);
+
+/*
+ * Checksums of N chunks.  d_init may be NULL (CRC: 0, Adler: 1), otherwise
+ * d_init[i] is the running value to continue from (libdeflate.h:326-346).
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_crc32_batch(size_t n_chunks, const void *d_in,
+			   const uint64_t *d_offsets, const uint64_t *d_nbytes,
+			   const uint32_t *d_init, uint32_t *d_out,
+			   void *stream);
+LIBDEFLATEAPI int
+libdeflate_amd_adler32_batch(size_t n_chunks, const void *d_in,
+			     const uint64_t *d_offsets,
+			     const uint64_t *d_nbytes,
+			     const uint32_t *d_init, uint32_t *d_out,
+			     void *stream);
+
+/*
+ * Convenience forms taking HOST arrays of per-chunk host pointers (what a
+ * cgo/JNI/ctypes caller holding ordinary buffers has).  They stage the batch
+ * through HBM, run the device batch above and copy results back; blocking.
+ * results/actual_* have the meaning above.
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_compress_batch_host(struct libdeflate_compressor *compressor,
+				   int format, size_t n_chunks,
+				   const void *const *in,
+				   const size_t *in_nbytes,
+				   void *const *out, const size_t *out_avail,
+				   size_t *out_nbytes);
+LIBDEFLATEAPI int
+libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
+				     int format, size_t n_chunks,
+				     const void *const *in,
+				     const size_t *in_nbytes,
+				     void *const *out, const size_t *out_avail,
+				     int32_t *results, size_t *actual_in,
+				     size_t *actual_out /* NULL allowed */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBDEFLATE_AMD_H */

@@ -1,0 +1,103 @@
+/*
+ * device_common.h - small wave64 helpers shared by the gfx950 kernels.
+ * CDNA4 only: a wavefront is 64 lanes; no warp-size abstraction.
+ */
+#ifndef LDA_DEVICE_COMMON_H
+#define LDA_DEVICE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LDA_WAVE 64
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t s32;
+
+/* result codes: libdeflate.h:194-209 */
+#define LDA_SUCCESS 0
+#define LDA_BAD_DATA 1
+#define LDA_SHORT_OUTPUT 2
+#define LDA_INSUFFICIENT_SPACE 3
+
+#define LDA_FMT_DEFLATE 0
+#define LDA_FMT_ZLIB 1
+#define LDA_FMT_GZIP 2
+
+static __device__ __forceinline__ u32 lane_id(void)
+{
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+
+/* value of 'v' in the first active lane, as a wave-uniform (SGPR) value */
+static __device__ __forceinline__ u32 bcast_first(u32 v)
+{
+	return __builtin_amdgcn_readfirstlane(v);
+}
+
+static __device__ __forceinline__ u32 bcast_lane(u32 v, u32 lane)
+{
+	return __builtin_amdgcn_readlane(v, lane);
+}
+
+static __device__ __forceinline__ u32 wave_xor(u32 v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v ^= __shfl_xor(v, off, 64);
+	return v;
+}
+
+static __device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+static __device__ __forceinline__ u64 wave_sum64(u64 v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		u32 lo = __shfl_xor((u32)v, off, 64);
+		u32 hi = __shfl_xor((u32)(v >> 32), off, 64);
+		v += ((u64)hi << 32) | lo;
+	}
+	return v;
+}
+
+/* inclusive prefix sum across the 64 lanes */
+static __device__ __forceinline__ u32 wave_scan_incl(u32 v)
+{
+	u32 lane = lane_id();
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		u32 t = __shfl_up(v, off, 64);
+		if (lane >= (u32)off)
+			v += t;
+	}
+	return v;
+}
+
+static __device__ __forceinline__ u32 wave_max(u32 v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		u32 t = __shfl_xor(v, off, 64);
+		v = t > v ? t : v;
+	}
+	return v;
+}
+
+/* make earlier LDS/global writes of this wave visible to its other lanes */
+static __device__ __forceinline__ void wave_sync(void)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#endif /* LDA_DEVICE_COMMON_H */
