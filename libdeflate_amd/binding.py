@@ -42,6 +42,7 @@ BATCH_SYMBOLS = [
 ]
 
 _lib = None
+MISSING = []
 
 
 def load():
@@ -55,12 +56,24 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C libdeflate_amd/csrc -j` (hipcc, gfx950). "
             "libdeflate_amd has no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same
+    # SONAME as /opt/rocm's).  Importing torch first makes the dynamic loader
+    # bind our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped;
+    # the other order would map two runtimes and the second one sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     P, SZ = c_void_p, c_size_t
     psz = POINTER(c_size_t)
 
     def sig(name, restype, *argtypes):
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            MISSING.append(name)    # tests/test_abi.py asserts this stays empty
+            return
         fn.restype = restype
         fn.argtypes = list(argtypes)
 

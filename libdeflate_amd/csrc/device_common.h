@@ -15,6 +15,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int32_t s32;
+typedef int64_t s64;
 
 /* result codes: libdeflate.h:194-209 */
 #define LDA_SUCCESS 0
@@ -35,6 +36,13 @@ static __device__ __forceinline__ u32 lane_id(void)
 static __device__ __forceinline__ u32 bcast_first(u32 v)
 {
 	return __builtin_amdgcn_readfirstlane(v);
+}
+
+/* 64-bit value of the first active lane */
+static __device__ __forceinline__ u64 bcast64(u64 v)
+{
+	return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) |
+	       __builtin_amdgcn_readfirstlane((u32)v);
 }
 
 static __device__ __forceinline__ u32 bcast_lane(u32 v, u32 lane)

@@ -1,0 +1,302 @@
+/*
+ * host_decompress.hip - C-ABI of the decompressor: object lifetime, the
+ * device batch entry point, the host-pointer batch, and the nine
+ * single-buffer libdeflate_*_decompress[_ex] calls as batches of one.
+ *
+ * Reference interfaces replaced: libdeflate.h:181-188 (alloc), :242-315
+ * (decompress), :322-323 (free), :363-365 (allocator).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "host_objects.h"
+#include "kernels.h"
+
+namespace lda {
+
+malloc_func_t g_malloc = nullptr;
+free_func_t g_free = nullptr;
+
+void *DevBuf::reserve(size_t n)
+{
+	if (n <= cap)
+		return p;
+	release();
+	size_t want = align_up(n + n / 8 + 4096, 4096);
+	hipError_t e = hipMalloc(&p, want);
+	if (e != hipSuccess) {
+		p = nullptr;
+		set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e));
+		return nullptr;
+	}
+	cap = want;
+	return p;
+}
+
+void DevBuf::release()
+{
+	if (p)
+		(void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
+/* resolve the allocator the way lib/deflate_compress.c:3910-3917 does */
+bool pick_allocator(const struct libdeflate_options *options,
+		    malloc_func_t *m, free_func_t *f)
+{
+	*m = g_malloc ? g_malloc : malloc;
+	*f = g_free ? g_free : free;
+	if (options) {
+		/* lib/deflate_compress.c:3885-3886 */
+		if (options->sizeof_options != sizeof(*options))
+			return false;
+		if (options->malloc_func)
+			*m = options->malloc_func;
+		if (options->free_func)
+			*f = options->free_func;
+	}
+	return true;
+}
+
+} /* namespace lda */
+
+using namespace lda;
+
+/* lib/utils.c:61-67 */
+extern "C" LIBDEFLATEAPI void
+libdeflate_set_memory_allocator(void *(*malloc_func)(size_t),
+				void (*free_func)(void *))
+{
+	g_malloc = malloc_func;
+	g_free = free_func;
+}
+
+extern "C" LIBDEFLATEAPI struct libdeflate_decompressor *
+libdeflate_alloc_decompressor_ex(const struct libdeflate_options *options)
+{
+	malloc_func_t m;
+	free_func_t f;
+
+	if (!pick_allocator(options, &m, &f))
+		return NULL;
+	if (!device_ctx()) {
+		fprintf(stderr, "libdeflate_amd: alloc_decompressor: no usable "
+			"gfx950 device (%s); no CPU fallback\n",
+			libdeflate_amd_last_error());
+		return NULL;
+	}
+	void *mem = m(sizeof(struct libdeflate_decompressor));
+	if (!mem)
+		return NULL;
+	struct libdeflate_decompressor *d =
+		new (mem) libdeflate_decompressor();
+	d->free_func = f;
+	return d;
+}
+
+extern "C" LIBDEFLATEAPI struct libdeflate_decompressor *
+libdeflate_alloc_decompressor(void)
+{
+	return libdeflate_alloc_decompressor_ex(NULL);
+}
+
+extern "C" LIBDEFLATEAPI void
+libdeflate_free_decompressor(struct libdeflate_decompressor *d)
+{
+	if (!d)
+		return;
+	d->scratch.release();
+	d->stage.release();
+	free_func_t f = d->free_func;
+	d->~libdeflate_decompressor();
+	f(d);
+}
+
+/* ------------------------------------------------------------------ */
+
+extern "C" LIBDEFLATEAPI int
+libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
+				size_t n, const void *d_in,
+				const uint64_t *d_in_offsets,
+				const uint64_t *d_in_nbytes, void *d_out,
+				const uint64_t *d_out_offsets,
+				const uint64_t *d_out_avail, int32_t *d_results,
+				uint64_t *d_actual_in, uint64_t *d_actual_out,
+				void *stream)
+{
+	DeviceCtx *c = device_ctx();
+	hipStream_t st = (hipStream_t)stream;
+
+	if (!c)
+		return LIBDEFLATE_AMD_NO_DEVICE;
+	if (n == 0)
+		return LIBDEFLATE_AMD_OK;
+	if (!d || !d_in || !d_in_offsets || !d_in_nbytes || !d_out ||
+	    !d_out_offsets || !d_out_avail || !d_results ||
+	    format < LIBDEFLATE_AMD_DEFLATE || format > LIBDEFLATE_AMD_GZIP) {
+		set_error("decompress_batch: bad argument");
+		return LIBDEFLATE_AMD_BAD_ARG;
+	}
+	/* scratch: [sums u32 x n][actual_in u64 x n][actual_out u64 x n] */
+	size_t sums_bytes = align_up(n * 4, 16);
+	uint8_t *s = (uint8_t *)d->scratch.reserve(sums_bytes + 16 * n);
+	if (!s)
+		return LIBDEFLATE_AMD_OOM;
+	uint32_t *sums = (uint32_t *)s;
+	uint64_t *ain = d_actual_in ? d_actual_in : (uint64_t *)(s + sums_bytes);
+	uint64_t *aout = d_actual_out ? d_actual_out :
+			 (uint64_t *)(s + sums_bytes + 8 * n);
+	int exact_fill = d_actual_out == NULL;
+
+	hipLaunchKernelGGL(lda_inflate_batch_kernel, dim3((unsigned)n), dim3(64),
+			   0, st, (uint64_t)n, format, (const uint8_t *)d_in,
+			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
+			   d_out_offsets, d_out_avail, d_results, ain, aout);
+	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
+	if (format != LIBDEFLATE_AMD_DEFLATE) {
+		int rc = format == LIBDEFLATE_AMD_GZIP ?
+			libdeflate_amd_crc32_batch(n, d_out, d_out_offsets, aout,
+						   NULL, sums, stream) :
+			libdeflate_amd_adler32_batch(n, d_out, d_out_offsets,
+						     aout, NULL, sums, stream);
+		if (rc != LIBDEFLATE_AMD_OK)
+			return rc;
+	}
+	if (format != LIBDEFLATE_AMD_DEFLATE || exact_fill) {
+		hipLaunchKernelGGL(lda_inflate_finalize_kernel,
+				   dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+				   st, (uint64_t)n, format, exact_fill,
+				   (const uint8_t *)d_in, d_in_offsets, d_out_avail,
+				   sums, d_results, ain, aout);
+		LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
+	}
+	return LIBDEFLATE_AMD_OK;
+}
+
+extern "C" LIBDEFLATEAPI int
+libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
+				     int format, size_t n,
+				     const void *const *in,
+				     const size_t *in_nbytes, void *const *out,
+				     const size_t *out_avail, int32_t *results,
+				     size_t *actual_in, size_t *actual_out)
+{
+	if (!device_ctx())
+		return LIBDEFLATE_AMD_NO_DEVICE;
+	if (n == 0)
+		return LIBDEFLATE_AMD_OK;
+	if (!d || !in || !in_nbytes || !out || !out_avail || !results) {
+		set_error("decompress_batch_host: NULL argument");
+		return LIBDEFLATE_AMD_BAD_ARG;
+	}
+	/* staging layout: 6 u64 arrays + results, then inputs, then outputs */
+	std::vector<uint64_t> desc(6 * n);
+	uint64_t *in_off = &desc[0], *in_n = &desc[n], *out_off = &desc[2 * n],
+		 *out_av = &desc[3 * n];
+	size_t desc_bytes = align_up(6 * n * 8 + n * 4, 64);
+	size_t pos = desc_bytes;
+	for (size_t i = 0; i < n; i++) {
+		in_off[i] = pos;
+		in_n[i] = in_nbytes[i];
+		pos = align_up(pos + in_nbytes[i] + 16, 16);
+	}
+	size_t out_begin = pos;
+	for (size_t i = 0; i < n; i++) {
+		out_off[i] = pos;
+		out_av[i] = out_avail[i];
+		pos = align_up(pos + out_avail[i] + 16, 16);
+	}
+	uint8_t *st = (uint8_t *)d->stage.reserve(pos + 64);
+	if (!st)
+		return LIBDEFLATE_AMD_OOM;
+	LDA_HIP_TRY(hipMemcpy(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice),
+		    LIBDEFLATE_AMD_NO_DEVICE);
+	for (size_t i = 0; i < n; i++)
+		if (in_nbytes[i])
+			LDA_HIP_TRY(hipMemcpy(st + in_off[i], in[i], in_nbytes[i],
+					      hipMemcpyHostToDevice),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+	uint64_t *d_desc = (uint64_t *)st;
+	int32_t *d_res = (int32_t *)(st + 6 * n * 8);
+	int rc = libdeflate_amd_decompress_batch(
+		d, format, n, st, d_desc, d_desc + n, st, d_desc + 2 * n,
+		d_desc + 3 * n, d_res, d_desc + 4 * n,
+		actual_out ? d_desc + 5 * n : NULL, NULL);
+	if (rc != LIBDEFLATE_AMD_OK)
+		return rc;
+	LDA_HIP_TRY(hipDeviceSynchronize(), LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipMemcpy(&desc[4 * n], d_desc + 4 * n, 2 * n * 8,
+			      hipMemcpyDeviceToHost), LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipMemcpy(results, d_res, n * 4, hipMemcpyDeviceToHost),
+		    LIBDEFLATE_AMD_NO_DEVICE);
+	(void)out_begin;
+	for (size_t i = 0; i < n; i++) {
+		if (actual_in)
+			actual_in[i] = results[i] == 0 ? desc[4 * n + i] : 0;
+		if (actual_out)
+			actual_out[i] = results[i] == 0 ? desc[5 * n + i] : 0;
+		if (results[i] != LIBDEFLATE_SUCCESS)
+			continue;	/* output undefined on failure */
+		size_t nout = actual_out ? desc[5 * n + i] : out_avail[i];
+		if (nout)
+			LDA_HIP_TRY(hipMemcpy(out[i], st + out_off[i], nout,
+					      hipMemcpyDeviceToHost),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+	}
+	return LIBDEFLATE_AMD_OK;
+}
+
+/* ---- the single-buffer calls: batches of one ---- */
+
+static enum libdeflate_result
+decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
+	       size_t in_nbytes, void *out, size_t out_avail,
+	       size_t *actual_in_ret, size_t *actual_out_ret)
+{
+	const void *ins[1] = { in };
+	void *outs[1] = { out };
+	int32_t res = LIBDEFLATE_BAD_DATA;
+	size_t ain = 0, aout = 0;
+	int rc = libdeflate_amd_decompress_batch_host(
+		d, format, 1, ins, &in_nbytes, outs, &out_avail, &res, &ain,
+		actual_out_ret ? &aout : NULL);
+
+	if (rc != LIBDEFLATE_AMD_OK)
+		die_no_device("libdeflate_*_decompress");
+	if (res == LIBDEFLATE_SUCCESS) {
+		if (actual_in_ret)
+			*actual_in_ret = ain;
+		if (actual_out_ret)
+			*actual_out_ret = aout;
+	}
+	return (enum libdeflate_result)res;
+}
+
+#define DEFINE_DECOMPRESS(name, fmt)                                          \
+	extern "C" LIBDEFLATEAPI enum libdeflate_result                       \
+	libdeflate_##name##_decompress_ex(struct libdeflate_decompressor *d, \
+					  const void *in, size_t in_nbytes,   \
+					  void *out, size_t out_avail,        \
+					  size_t *actual_in_ret,              \
+					  size_t *actual_out_ret)             \
+	{                                                                     \
+		return decompress_one(d, fmt, in, in_nbytes, out, out_avail,  \
+				      actual_in_ret, actual_out_ret);         \
+	}                                                                     \
+	extern "C" LIBDEFLATEAPI enum libdeflate_result                       \
+	libdeflate_##name##_decompress(struct libdeflate_decompressor *d,     \
+				       const void *in, size_t in_nbytes,      \
+				       void *out, size_t out_avail,           \
+				       size_t *actual_out_ret)                \
+	{                                                                     \
+		return decompress_one(d, fmt, in, in_nbytes, out, out_avail,  \
+				      NULL, actual_out_ret);                  \
+	}
+
+DEFINE_DECOMPRESS(deflate, LIBDEFLATE_AMD_DEFLATE)
+DEFINE_DECOMPRESS(zlib, LIBDEFLATE_AMD_ZLIB)
+DEFINE_DECOMPRESS(gzip, LIBDEFLATE_AMD_GZIP)

@@ -1,0 +1,45 @@
+/*
+ * host_objects.h - the two opaque objects of the C-ABI.
+ *
+ * Each is ONE allocation through the selected allocator (per-object options >
+ * libdeflate_set_memory_allocator > malloc), like the reference
+ * (lib/deflate_compress.c:3910-3917, programs/test_custom_malloc.c:53-77).
+ * Device memory hangs off the object and never goes through that allocator.
+ */
+#ifndef LDA_HOST_OBJECTS_H
+#define LDA_HOST_OBJECTS_H
+
+#include "host_common.h"
+
+namespace lda {
+
+typedef void *(*malloc_func_t)(size_t);
+typedef void (*free_func_t)(void *);
+
+extern malloc_func_t g_malloc;	/* libdeflate_set_memory_allocator */
+extern free_func_t g_free;
+
+/* grow-only device buffer owned by an object */
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	void *reserve(size_t n);	/* nullptr + error on failure */
+	void release();
+};
+
+} /* namespace lda */
+
+struct libdeflate_decompressor {
+	lda::free_func_t free_func;
+	lda::DevBuf scratch;	/* per-chunk u32 sums + u64 actual_in/out */
+	lda::DevBuf stage;	/* host-pointer entry points */
+};
+
+struct libdeflate_compressor {
+	lda::free_func_t free_func;
+	int level;
+	lda::DevBuf scratch;	/* parse/encode workspace + per-chunk sums */
+	lda::DevBuf stage;
+};
+
+#endif /* LDA_HOST_OBJECTS_H */

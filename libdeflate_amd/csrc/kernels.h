@@ -19,6 +19,20 @@ lda_adler32_batch_kernel(uint64_t n_chunks, const uint8_t *base,
 			 const uint64_t *offsets, const uint64_t *nbytes,
 			 const uint32_t *init, uint32_t *out);
 
+/* inflate_kernel.hip */
+extern "C" __global__ void
+lda_inflate_batch_kernel(uint64_t n_chunks, int format, const uint8_t *in_base,
+			 const uint64_t *in_offsets, const uint64_t *in_nbytes,
+			 uint8_t *out_base, const uint64_t *out_offsets,
+			 const uint64_t *out_avail, int32_t *results,
+			 uint64_t *actual_in, uint64_t *actual_out);
+extern "C" __global__ void
+lda_inflate_finalize_kernel(uint64_t n_chunks, int format, int exact_fill,
+			    const uint8_t *in_base, const uint64_t *in_offsets,
+			    const uint64_t *out_avail, const uint32_t *sums,
+			    int32_t *results, uint64_t *actual_in,
+			    uint64_t *actual_out);
+
 /* CRC constant tables, generated on the host at first use (host_api.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)
 #define LDA_CRC_XPOW_WORDS 1024

@@ -1,0 +1,271 @@
+"""Hand-assembled DEFLATE streams and randomized stream cases used by both the
+oracle tests (CPU) and the GPU parity tests.
+
+The hand-assembled ones rebuild, with our own bit writer, the vectors that the
+reference's unit tests pin:
+  programs/test_incomplete_codes.c:71-372, test_invalid_streams.c:58-121,
+  test_overread.c:15-91, test_trailing_bytes.c:41-150.
+"""
+import random
+import zlib
+
+from tests import datagen
+
+
+class BitWriter:
+    """LSB-first bit packer (the job of put_bits/flush_bits in
+    programs/test_util.c:210-237)."""
+
+    def __init__(self):
+        self.acc = 0
+        self.n = 0
+        self.out = bytearray()
+
+    def put(self, value, nbits):
+        self.acc |= (value & ((1 << nbits) - 1)) << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 0xFF)
+            self.acc >>= 8
+            self.n -= 8
+
+    def put_code(self, code, nbits):
+        """Huffman codewords go MSB-first."""
+        for i in range(nbits - 1, -1, -1):
+            self.put((code >> i) & 1, 1)
+
+    def finish(self):
+        if self.n:
+            self.out.append(self.acc & 0xFF)
+            self.acc = 0
+            self.n = 0
+        return bytes(self.out)
+
+
+PERM = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+
+
+def _dyn_header(w, final, nlit, noff, pre_lens):
+    """BFINAL, BTYPE=2, HLIT/HDIST/HCLEN and the precode lengths."""
+    w.put(final, 1)
+    w.put(2, 2)
+    w.put(nlit - 257, 5)
+    w.put(noff - 1, 5)
+    nexp = 19
+    while nexp > 4 and pre_lens.get(PERM[nexp - 1], 0) == 0:
+        nexp -= 1
+    w.put(nexp - 4, 4)
+    for i in range(nexp):
+        w.put(pre_lens.get(PERM[i], 0), 3)
+
+
+def incomplete_empty_offset_code():
+    """test_incomplete_codes.c:75-147: litlen code {A:1,B:2,EOB:2 bits}, the
+    offset code has no codewords at all (one length-0 entry); data "ABAA"."""
+    w = BitWriter()
+    # precode: sym0 -> 1 bit '0'?  use lens: 0:1? need lens {0,1,2}: three syms
+    # precode lens: presym 0:2 bits, 1:2 bits, 2:2 bits, 18:2 bits (complete)
+    pre = {0: 2, 1: 2, 2: 2, 18: 2}
+    # canonical precode codewords (by len then symbol): 0->00 1->01 2->10 18->11
+    code = {0: 0, 1: 1, 2: 2, 18: 3}
+    _dyn_header(w, 1, 257, 1, pre)
+
+    def lens_run_zeros(n):
+        while n:
+            r = min(n, 138)
+            assert r >= 11
+            w.put_code(code[18], 2)
+            w.put(r - 11, 7)
+            n -= r
+    # litlen lens: 0..64 zero (65 syms), 'A'(65)=1, 'B'(66)=2, 67..255 zero
+    # (189 syms), 256=2
+    lens_run_zeros(65)
+    w.put_code(code[1], 2)
+    w.put_code(code[2], 2)
+    n = 189
+    w.put_code(code[18], 2); w.put(138 - 11, 7); n -= 138
+    w.put_code(code[18], 2); w.put(n - 11, 7)
+    w.put_code(code[2], 2)
+    # offset lens: single 0
+    w.put_code(code[0], 2)
+    # litlen canonical: A:'0', B:'10', EOB:'11'
+    for sym in "ABAA":
+        if sym == "A":
+            w.put_code(0, 1)
+        else:
+            w.put_code(2, 2)
+    w.put_code(3, 2)
+    return w.finish(), b"ABAA"
+
+
+def incomplete_singleton_litlen():
+    """test_incomplete_codes.c:179-210: the only litlen codeword is EOB with
+    length 1 (incomplete but accepted); output is empty."""
+    w = BitWriter()
+    pre = {0: 1, 1: 2, 18: 2}
+    code = {0: (0, 1), 1: (2, 2), 18: (3, 2)}
+    _dyn_header(w, 1, 257, 1, pre)
+    n = 256
+    w.put_code(*code[18]); w.put(138 - 11, 7); n -= 138
+    w.put_code(*code[18]); w.put(n - 11, 7)
+    w.put_code(*code[1])        # EOB len 1
+    w.put_code(*code[0])        # offset sym0 len 0
+    w.put_code(0, 1)            # EOB
+    return w.finish(), b""
+
+
+def incomplete_singleton_offset(sym_nonzero):
+    """test_incomplete_codes.c:217-368: the offset code has exactly one
+    codeword of length 1 (symbol 0, or a non-zero symbol); the data is a
+    literal followed by a match that uses it."""
+    w = BitWriter()
+    pre = {0: 1, 1: 2, 2: 3, 18: 3}
+    # canonical: 0:'0', 1:'10', 2:'110', 18:'111'
+    code = {0: (0, 1), 1: (2, 2), 2: (6, 3), 18: (7, 3)}
+    noff = 2 if sym_nonzero else 1
+    # litlen: 254 -> len 2? keep simple: lits 0xfe(254):2, 0xff(255):2,
+    # EOB(256):2, len sym 257 (length 3): 2  -> complete (4 x 2 bits)
+    _dyn_header(w, 1, 258, noff, pre)
+    n = 254
+    w.put_code(*code[18]); w.put(138 - 11, 7); n -= 138
+    w.put_code(*code[18]); w.put(n - 11, 7)
+    for _ in range(4):
+        w.put_code(*code[2])
+    if sym_nonzero:
+        w.put_code(*code[0])    # offset sym 0: unused
+        w.put_code(*code[1])    # offset sym 1: len 1
+    else:
+        w.put_code(*code[1])    # offset sym 0: len 1
+    # litlen canonical (all len 2): 254:'00' 255:'01' 256:'10' 257:'11'
+    if sym_nonzero:
+        # "fe ff" then match len 3 offset 2 -> fe ff fe ff fe
+        w.put_code(0, 2); w.put_code(1, 2)
+        w.put_code(3, 2); w.put_code(0, 1)
+        want = bytes([0xFE, 0xFF, 0xFE, 0xFF, 0xFE])
+    else:
+        # "ff" then match len 3 offset 1 -> ff ff ff ff
+        w.put_code(1, 2)
+        w.put_code(3, 2); w.put_code(0, 1)
+        want = bytes([0xFF] * 4)
+    w.put_code(2, 2)
+    return w.finish(), want
+
+
+def too_many_codeword_lengths():
+    """test_invalid_streams.c:65-118: the length runs overshoot
+    HLIT+HDIST -> BAD_DATA."""
+    w = BitWriter()
+    pre = {0: 1, 18: 1}
+    _dyn_header(w, 1, 257, 1, pre)
+    # canonical: 0:'0', 18:'1'; 258 lengths wanted, give 138+138 zeros = 276
+    w.put_code(1, 1); w.put(127, 7)
+    w.put_code(1, 1); w.put(127, 7)
+    w.put(0, 16)
+    return w.finish()
+
+
+def overread_stream():
+    """test_overread.c:15-68: litlen code where the all-zero-bits codeword is
+    a literal, stream truncated right after the header: the implicit zero bits
+    decode as an endless run of literals -> must be BAD_DATA."""
+    w = BitWriter()
+    pre = {1: 1, 18: 1}
+    # canonical: 1:'0', 18:'1'
+    _dyn_header(w, 1, 257, 1, pre)
+    # litlen: sym 0 len 1, syms 1..255 zero, sym 256 len 1 -> '0'=lit 0,'1'=EOB
+    w.put_code(0, 1)
+    n = 255
+    w.put_code(1, 1); w.put(138 - 11, 7); n -= 138
+    w.put_code(1, 1); w.put(n - 11, 7)
+    w.put_code(0, 1)
+    # offset: one symbol with len 1
+    w.put_code(0, 1)
+    return w.finish()
+
+
+def trailing_bytes_input():
+    """test_trailing_bytes.c:74-75"""
+    return bytes(((i % 123) + (i % 1023)) & 0xFF for i in range(32768))
+
+
+def litrunlen_input():
+    """test_litrunlen_overflow.c:35-40 style: 125500 bytes, no matches."""
+    out = bytearray(125500)
+    v = 0
+    for i in range(len(out)):
+        out[i] = (v >> 8) & 0xFF if i & 1 else v & 0xFF
+        if i & 1:
+            v = (v * 31 + 7) & 0xFFFF
+    return bytes(out)
+
+
+def _zcompress(fmt, level, data):
+    wbits = {"deflate": -15, "zlib": 15, "gzip": 31}[fmt]
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits)
+    return c.compress(data) + c.flush()
+
+
+def random_cases(seed, count, compress=None, sizes=None):
+    """Randomized (fmt, stream, out_avail, want_actual_out, tag) cases:
+    valid streams from `compress(fmt, level, data)` (default: Python's zlib),
+    plus truncated / bit-flipped / short-output / oversized-output / trailing
+    garbage variants."""
+    rng = random.Random(seed)
+    compress = compress or _zcompress
+    sizes = sizes or [0, 1, 5, 31, 32, 100, 1000, 5000, 20000, 70000]
+    cases = []
+    for it in range(count):
+        n = rng.choice(sizes)
+        kind = rng.randrange(5)
+        if kind == 0:
+            data = datagen.random_chunk(n, seed * 7919 + it)
+        elif kind == 1:
+            data = datagen.lowentropy_chunk(n, seed * 7919 + it)
+        elif kind == 2:
+            data = (b"hello world, " * (n // 13 + 1))[:n]
+        elif kind == 3:
+            data = datagen.binary_chunk(n, seed * 7919 + it)
+        else:
+            data = datagen.text_chunk(n, seed * 7919 + it)
+        fmt = rng.choice(["deflate", "zlib", "gzip"])
+        level = rng.choice([0, 1, 3, 6, 9])
+        comp = compress(fmt, level, data)
+        mode = rng.randrange(7)
+        avail = n
+        if mode == 1 and comp:
+            comp = comp[:rng.randrange(len(comp))]
+        elif mode == 2 and comp:
+            b = bytearray(comp)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            comp = bytes(b)
+        elif mode == 3:
+            avail = max(0, n - rng.randrange(0, 300))
+        elif mode == 4:
+            avail = n + rng.randrange(0, 300)
+        elif mode == 5:
+            comp = comp + bytes(rng.randrange(256)
+                                for _ in range(rng.randrange(20)))
+        for want in (True, False):
+            cases.append((fmt, comp, avail, want, f"it{it}/m{mode}/l{level}"))
+    return cases
+
+
+def garbage_cases(seed, count):
+    """Streams of random bytes: exercises every header/validity failure."""
+    rng = random.Random(seed)
+    cases = []
+    for it in range(count):
+        n = rng.choice([0, 1, 2, 5, 6, 17, 18, 19, 40, 200, 2000])
+        s = bytes(rng.randrange(256) for _ in range(n))
+        if rng.randrange(3) == 0 and n >= 3:
+            # bias towards a dynamic block header
+            s = bytes([(s[0] & 0xF8) | 0x05]) + s[1:]
+        fmt = rng.choice(["deflate", "deflate", "zlib", "gzip"])
+        if fmt == "zlib" and n >= 2 and rng.randrange(2):
+            s = b"\x78\x9c" + s[2:]
+        if fmt == "gzip" and n >= 10 and rng.randrange(2):
+            s = b"\x1f\x8b\x08" + bytes([rng.choice([0, 4, 8, 16, 2, 28])]) + s[4:]
+        avail = rng.choice([0, 10, 1000, 70000])
+        cases.append((fmt, s, avail, True, f"garbage{it}"))
+    return cases

@@ -1,0 +1,154 @@
+"""GPU inflate (HIP) vs the oracle, through the C-ABI: result codes,
+actual_in/actual_out and every output byte.  Mirrors the reference's
+test_incomplete_codes / test_invalid_streams / test_overread /
+test_trailing_bytes programs plus randomized and corrupted streams."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import datagen, streams
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from libdeflate_amd import api
+    d = api.Decompressor()
+    yield d
+    d.close()
+
+
+def _run_cases(dec, oracle, cases):
+    """Group by (fmt, want_actual_out) and push each group as one batch."""
+    groups = {}
+    for cs in cases:
+        groups.setdefault((cs[0], cs[3]), []).append(cs)
+    for (fmt, want), group in groups.items():
+        got = dec.decompress_batch_host(fmt, [g[1] for g in group],
+                                        [g[2] for g in group], want)
+        for cs, g in zip(group, got):
+            o = oracle.decompress_ex(fmt, cs[1], cs[2], want)
+            assert g[0] == o[0], (cs[4], fmt, "gpu", g[:3], "oracle", o[:3])
+            if o[0] == 0:
+                assert g[1] == o[1], (cs[4], "actual_in")
+                if want:
+                    assert g[2] == o[2], (cs[4], "actual_out")
+                assert g[3] == o[3], (cs[4], "bytes differ")
+
+
+def test_reference_unit_test_vectors(dec, oracle):
+    cases = []
+    for i, (s, want) in enumerate([streams.incomplete_empty_offset_code(),
+                                   streams.incomplete_singleton_litlen(),
+                                   streams.incomplete_singleton_offset(False),
+                                   streams.incomplete_singleton_offset(True)]):
+        cases.append(("deflate", s, len(want), True, f"incomplete{i}"))
+        cases.append(("deflate", s, len(want), False, f"incomplete{i}x"))
+    cases.append(("deflate", streams.too_many_codeword_lengths(), 1000, True, "toomany"))
+    cases.append(("deflate", streams.overread_stream(), 128, True, "overread"))
+    _run_cases(dec, oracle, cases)
+    # and the literal expectations of the reference tests
+    r = dec.decompress_ex("deflate", streams.overread_stream(), 128)
+    assert r[0] == 1
+    s, want = streams.incomplete_singleton_offset(True)
+    assert dec.decompress_ex("deflate", s, len(want))[3] == want
+
+
+def test_trailing_bytes(dec, oracle):
+    data = streams.trailing_bytes_input()
+    for fmt in ("deflate", "zlib", "gzip"):
+        comp = streams._zcompress(fmt, 6, data)
+        for extra in (b"", b"\x01\x02\x03\x04"):
+            assert dec.decompress_ex(fmt, comp + extra, len(data)) == \
+                (0, len(comp), len(data), data)
+            r, aout, out = dec.decompress(fmt, comp + extra, len(data), False)
+            assert (r, out) == (0, data)
+        assert dec.decompress(fmt, comp, len(data) + 1, False)[0] == 2
+        assert dec.decompress(fmt, comp, len(data) - 1)[0] == 3
+
+
+def test_golden_fixtures(dec):
+    """Results of the real reference, committed in tests/golden/."""
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        g = json.load(f)
+    groups = {}
+    for cs in g["cases"]:
+        groups.setdefault((cs["fmt"], cs["want_out"]), []).append(cs)
+    for (fmt, want), group in groups.items():
+        got = dec.decompress_batch_host(
+            fmt, [bytes.fromhex(c["stream"]) for c in group],
+            [c["avail"] for c in group], want)
+        for cs, r in zip(group, got):
+            assert r[0] == cs["result"], cs["tag"]
+            if r[0] == 0:
+                assert r[1] == cs["actual_in"], cs["tag"]
+                if want:
+                    assert r[2] == cs["actual_out"], cs["tag"]
+                assert zlib.crc32(r[3]) == cs["out_crc32"], cs["tag"]
+
+
+def test_randomized_vs_oracle(dec, oracle):
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    comp = (lambda f, l, d: ref.compress(f, l, d)) if ref else None
+    _run_cases(dec, oracle, streams.random_cases(21, 300, compress=comp))
+    _run_cases(dec, oracle, streams.garbage_cases(22, 600))
+
+
+def test_levels_and_sizes(dec, oracle):
+    """Edge-size sweep of SURVEY.md §8(d) x formats x producer levels."""
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    sizes = [0, 1, 18, 19, 20, 31, 32, 51, 52, 511, 512, 4999, 5000, 5001,
+             65535, 65536, 65537, 300000]
+    cases = []
+    for i, n in enumerate(sizes):
+        d = datagen.chunk(i, n, 0x0E110010)
+        for fmt in ("deflate", "zlib", "gzip"):
+            for lvl in (0, 1, 6, 9, 12):
+                s = ref.compress(fmt, lvl, d) if ref else \
+                    streams._zcompress(fmt, min(lvl, 9), d)
+                cases.append((fmt, s, n, True, f"n{n}/l{lvl}"))
+                cases.append((fmt, s, n, False, f"n{n}/l{lvl}/exact"))
+    _run_cases(dec, oracle, cases)
+    lit = streams.litrunlen_input()     # test_litrunlen_overflow.c
+    for lvl in (3, 6, 12):
+        s = ref.compress("deflate", lvl, lit) if ref else \
+            streams._zcompress("deflate", min(lvl, 9), lit)
+        assert dec.decompress_ex("deflate", s, len(lit))[3] == lit
+
+
+def test_device_batch_bit_exact(dec):
+    """Config-4 shape at reduced count: gzip streams of 64 KiB chunks,
+    decoded from HBM to HBM, every byte compared."""
+    import torch
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    n, size = 512, 65536
+    chunks = datagen.batch(n, size, 0x0E110004, distinct=32)
+    comp = [ref.compress("gzip", 6, c) if ref else streams._zcompress("gzip", 6, c)
+            for c in chunks[:32]]
+    comp = [comp[i % 32] for i in range(n)]
+    offs, blob = [], bytearray()
+    for c in comp:
+        offs.append(len(blob))
+        blob += c
+        blob += bytes((-len(blob)) % 16)
+    blob += bytes(64)
+    d_in = torch.frombuffer(blob, dtype=torch.uint8).cuda()
+    in_off = torch.tensor(offs, dtype=torch.int64).cuda()
+    in_n = torch.tensor([len(c) for c in comp], dtype=torch.int64).cuda()
+    d_out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+    out_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+    out_av = torch.full((n,), size, dtype=torch.int64, device="cuda")
+    res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    dec.decompress_batch("gzip", d_in, in_off, in_n, d_out, out_off, out_av, res)
+    torch.cuda.synchronize()
+    assert res.cpu().numpy().tolist() == [0] * n
+    got = d_out.cpu().numpy().tobytes()
+    assert got == b"".join(chunks)

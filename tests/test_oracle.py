@@ -1,0 +1,108 @@
+"""Pins the oracle (CPU restatement) before anything trusts it:
+ (a) the reference's own unit-test vectors, rebuilt in tests/streams.py;
+ (b) the committed golden fixtures produced by the real reference;
+ (c) live against oracle/_ref (the reference compiled from its sources) when
+     it is present - randomized valid / truncated / corrupted streams.
+Runs on CPU (`-m "not gpu"`)."""
+import json
+import os
+import zlib
+
+import pytest
+
+from tests import datagen, streams
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_checksums_vs_zlib(oracle):
+    import random
+    rng = random.Random(3)
+    for n in [0, 1, 2, 3, 15, 16, 17, 255, 256, 4999, 5552, 5553, 70000]:
+        d = bytes(rng.randrange(256) for _ in range(n))
+        for init in (None, rng.getrandbits(32)):
+            c0 = 0 if init is None else init
+            a0 = 1 if init is None else ((init % 65521) << 16) | (init >> 16) % 65521
+            assert oracle.crc32(d, c0) == zlib.crc32(d, c0)
+            assert oracle.adler32(d, a0) == zlib.adler32(d, a0)
+    # Adler overflow vector: programs/test_checksums.c:184-196
+    d = b"\xff" * 5553
+    init = (65520 << 16) | 65520
+    assert oracle.adler32(d, init) == zlib.adler32(d, init)
+    # multipart == one shot: test_checksums.c:73-84
+    d = datagen.text_chunk(10000, 1)
+    assert oracle.crc32(d[5000:], oracle.crc32(d[:5000])) == oracle.crc32(d)
+    assert oracle.adler32(d[777:], oracle.adler32(d[:777])) == oracle.adler32(d)
+    # NULL buffer rules are exercised through ctypes None
+    assert oracle.lib.oracle_crc32(1234, None, 1234) == 0
+    assert oracle.lib.oracle_adler32(1234, None, 1234) == 1
+
+
+def test_reference_unit_test_vectors(oracle):
+    s, want = streams.incomplete_empty_offset_code()
+    assert oracle.decompress_ex("deflate", s, 4)[0::3] == (0, want)
+    assert zlib.decompress(s, -15) == want
+    s, want = streams.incomplete_singleton_litlen()
+    r = oracle.decompress_ex("deflate", s, 0)
+    assert r[0] == 0 and r[2] == 0
+    for nz in (False, True):
+        s, want = streams.incomplete_singleton_offset(nz)
+        r = oracle.decompress_ex("deflate", s, len(want))
+        assert (r[0], r[3]) == (0, want), nz
+        assert zlib.decompress(s, -15) == want
+    assert oracle.decompress_ex("deflate", streams.too_many_codeword_lengths(),
+                                1000)[0] == 1
+    # must be BAD_DATA, not INSUFFICIENT_SPACE (test_overread.c:70-91)
+    assert oracle.decompress_ex("deflate", streams.overread_stream(), 128)[0] == 1
+
+
+def test_trailing_bytes_semantics(oracle):
+    """programs/test_trailing_bytes.c:74-142"""
+    data = streams.trailing_bytes_input()
+    for fmt in ("deflate", "zlib", "gzip"):
+        comp = streams._zcompress(fmt, 6, data)
+        for extra in (b"", b"\x01\x02\x03\x04"):
+            r, ain, aout, out = oracle.decompress_ex(fmt, comp + extra, len(data))
+            assert (r, ain, aout, out) == (0, len(comp), len(data), data)
+            r, ain, aout, out = oracle.decompress_ex(fmt, comp + extra,
+                                                     len(data), False)
+            assert (r, ain, out) == (0, len(comp), data)
+            # exact-fill rule
+            assert oracle.decompress_ex(fmt, comp, len(data) + 1, False)[0] == 2
+            assert oracle.decompress_ex(fmt, comp, len(data) - 1)[0] == 3
+
+
+def test_golden_fixtures(oracle):
+    """Streams produced by the real reference (oracle/make_golden.py)."""
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        g = json.load(f)
+    assert len(g["cases"]) >= 100
+    for cs in g["cases"]:
+        comp = bytes.fromhex(cs["stream"])
+        r, ain, aout, out = oracle.decompress_ex(cs["fmt"], comp, cs["avail"],
+                                                 cs["want_out"])
+        assert r == cs["result"], cs["tag"]
+        if r == 0:
+            assert ain == cs["actual_in"], cs["tag"]
+            if cs["want_out"]:
+                assert aout == cs["actual_out"], cs["tag"]
+            assert oracle.crc32(out) == cs["out_crc32"], cs["tag"]
+    for cs in g["checksums"]:
+        d = datagen.chunk(cs["idx"], cs["n"], cs["seed"])
+        assert oracle.crc32(d, cs["crc_init"]) == cs["crc32"]
+        assert oracle.adler32(d, cs["adler_init"]) == cs["adler32"]
+
+
+def test_live_against_reference(oracle, ref):
+    comp = lambda fmt, lvl, d: ref.compress(fmt, lvl, d)
+    cases = streams.random_cases(11, 250, compress=comp)
+    cases += streams.garbage_cases(12, 400)
+    for fmt, s, avail, want, tag in cases:
+        a = ref.decompress_ex(fmt, s, avail, want)
+        b = oracle.decompress_ex(fmt, s, avail, want)
+        assert a[0] == b[0], (tag, fmt, a[:3], b[:3])
+        if a[0] == 0:
+            assert a == b, tag
+    for n in (0, 1, 4999, 5000, 5001, 65536, 1 << 20):
+        for fmt in ("deflate", "zlib", "gzip"):
+            assert oracle.bound(fmt, n) == ref.bound(fmt, n)
