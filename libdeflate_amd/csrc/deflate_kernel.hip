@@ -1,0 +1,1121 @@
+/*
+ * deflate_kernel.hip - batched DEFLATE / zlib / gzip compression for gfx950.
+ *
+ * Replaces, for a batch of independent buffers resident in HBM:
+ *   libdeflate_deflate_compress      lib/deflate_compress.c:4030-4072
+ *   greedy / lazy / lazy2 parsers    lib/deflate_compress.c:2528-2834
+ *   hash-chain match finder          lib/hc_matchfinder.h:182-399
+ *   Huffman code construction        lib/deflate_compress.c:759-1396
+ *   block flush / bit output         lib/deflate_compress.c:1482-2038
+ *   gzip / zlib framing              lib/gzip_compress.c:31-82, lib/zlib_compress.c:31-74
+ *
+ * This is NOT the reference's algorithm transliterated: the reference walks
+ * the buffer one position at a time.  Here ONE 512-thread workgroup (8 waves)
+ * owns a buffer and keeps the whole 32 KiB LZ77 window state in the CU's
+ * 160 KiB LDS:
+ *
+ *   in[]    32 KiB ring of input bytes           (coalesced 16 B loads)
+ *   prev[]  32 Ki x u16 ring: previous position with the same 4-byte hash
+ *   head[]  16 Ki x u16: most recent position per hash bucket
+ *   seq[]   the current block's matches (position, length, distance)
+ *
+ * and advances in TILES of 2048 positions:
+ *
+ *   S1  every lane hashes one position; each wave bitonic-sorts its 64
+ *       (hash, lane) keys so equal hashes become neighbours: that yields the
+ *       in-order "previous occurrence" links inside the group without any
+ *       serial insertion;
+ *   S2  one wave threads the groups through head[] in position order
+ *       (first/last of each hash run only: no conflicts inside a group);
+ *   S3  ALL positions of the tile search their chain in parallel (depth and
+ *       nice length per level as lib/deflate_compress.c:3927-3979): quick
+ *       4-byte reject, 8-byte-at-a-time extension, best (len, dist) per
+ *       position;
+ *   S4  the greedy / lazy / lazy2 choice is then a pure function of the
+ *       per-position results (rules of deflate_compress.c:2573-2575,
+ *       2712-2755); one lane walks the tile hopping from token to token;
+ *   S5  at block end: symbol histogram -> length-limited canonical Huffman
+ *       codes, exact cost of dynamic / static / stored, header;
+ *   S6  tokens are encoded position-parallel: every lane looks up its
+ *       codeword(s), a workgroup prefix sum of the bit lengths gives the bit
+ *       offset, ds_or packs the bits into an LDS staging buffer that is
+ *       written to HBM with coalesced 16-byte stores.
+ *
+ * HBM traffic is the algorithmic minimum: the input is read once, the output
+ * written once.  The compressed bytes differ from the reference's
+ * (libdeflate.h:76-83 leaves them unpinned); validity, round trip,
+ * compress_bound and ratio-vs-reference are what the tests check.
+ */
+#include "device_common.h"
+#include "kernels.h"
+
+#define NT 512
+#define NWAVES 8
+#define TILE 2048
+#define RING 32768u
+#define RMASK (RING - 1)
+#define LOOKAHEAD 272u
+#define HASH_BITS 14
+#define SEQ_CAP 2048u
+#define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile */
+#define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
+#define EWIN 1024u		/* encode window (positions) */
+#define STG_WORDS 1024u		/* 4 KiB staging */
+
+#define M_FIRST 0x10000u
+#define M_LAST 0x20000u
+#define M_VALID 0x40000u
+
+struct deflate_lds {
+	u8 in[RING + 32];
+	u16 prev[RING];
+	u16 head[1u << HASH_BITS];
+	u32 seq_pl[SEQ_CAP];	/* block-relative position | length << 16 */
+	u16 seq_d[SEQ_CAP];	/* distance */
+	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
+	u8 mark[TILE + 8];	/* 1 = literal chosen at this position */
+	u32 freq[320];		/* litlen 0..287, offset 288..319 */
+	u8 lens[320];
+	u16 codes[320];		/* bit-reversed codewords */
+	u16 sorted[288];
+	u32 hw[288 * 2];	/* Huffman build scratch */
+	u16 pre_items[320 + 8];	/* precode symbol | extra << 5 */
+	u32 pre_freq[19];
+	u8 pre_lens[19];
+	u16 pre_codes[19];
+	u32 scan[NWAVES + 1];
+	u32 carry[6];		/* staging bytes kept between blocks */
+	u32 vars[16];
+};
+
+enum {
+	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
+	V_TMP2, V_TMP3
+};
+
+struct level_params {
+	u32 depth;
+	u32 nice;
+	u32 mode;	/* 0 greedy, 1 lazy, 2 lazy2 */
+};
+
+/* ---------------- small helpers ---------------- */
+
+static __device__ __forceinline__ u32 ld32(const u8 *ring, u32 pos)
+{
+	u32 v;
+	__builtin_memcpy(&v, ring + (pos & RMASK), 4);
+	return v;
+}
+
+static __device__ __forceinline__ u64 ld64(const u8 *ring, u32 pos)
+{
+	u64 v;
+	__builtin_memcpy(&v, ring + (pos & RMASK), 8);
+	return v;
+}
+
+static __device__ __forceinline__ u32 hash4(u32 w)
+{
+	/* multiplicative hash, lib/matchfinder_common.h:168-172 */
+	return (w * 0x1E35A7BDu) >> (32 - HASH_BITS);
+}
+
+/* workgroup exclusive scan of one value per thread; returns the exclusive
+ * prefix and writes the total to *total.  Two barriers. */
+static __device__ u32 block_scan(struct deflate_lds *L, u32 v, u32 *total)
+{
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	u32 incl = wave_scan_incl(v);
+
+	if (lane == 63)
+		L->scan[wave] = incl;
+	__syncthreads();
+	u32 base = 0, tot = 0;
+#pragma unroll
+	for (u32 w = 0; w < NWAVES; w++) {
+		u32 s = L->scan[w];
+		if (w < wave)
+			base += s;
+		tot += s;
+	}
+	__syncthreads();
+	*total = tot;
+	return base + incl - v;
+}
+
+/* length slot / extra bits (lib/deflate_compress.c:237-308 tables, computed) */
+static __device__ __forceinline__ void
+length_code(u32 len, u32 *slot, u32 *xbits, u32 *xval)
+{
+	u32 l = len - 3;
+	if (l < 8) {
+		*slot = l; *xbits = 0; *xval = 0;
+	} else if (len == 258) {
+		*slot = 28; *xbits = 0; *xval = 0;
+	} else {
+		u32 hb = 31 - __builtin_clz(l);
+		*xbits = hb - 2;
+		*slot = 4 * (hb - 1) + ((l >> (hb - 2)) & 3);
+		*xval = l & ((1u << (hb - 2)) - 1);
+	}
+}
+
+static __device__ __forceinline__ void
+dist_code(u32 dist, u32 *slot, u32 *xbits, u32 *xval)
+{
+	u32 d = dist - 1;
+	if (d < 4) {
+		*slot = d; *xbits = 0; *xval = 0;
+	} else {
+		u32 hb = 31 - __builtin_clz(d);
+		*xbits = hb - 1;
+		*slot = 2 * hb + ((d >> (hb - 1)) & 1);
+		*xval = d & ((1u << (hb - 1)) - 1);
+	}
+}
+
+/* ---------------- Huffman code construction (wave 0) ---------------- */
+
+/*
+ * Length-limited canonical code for freq[0..n) -> lens[], codes[] (codewords
+ * bit-reversed, ready for LSB-first output).  Called by ONE wave.
+ *   - rank sort by (freq, sym) with all lanes;
+ *   - optimal tree by the in-place two-queue method on lane 0;
+ *   - depth clamp with Kraft repair (what lib/deflate_compress.c:1022-1091
+ *     achieves with its length-count shuffle);
+ *   - fewer than two used symbols -> two 1-bit codewords
+ *     (lib/deflate_compress.c:1369-1378).
+ */
+static __device__ void
+make_code(struct deflate_lds *L, const u32 *freq, u32 n, u32 maxlen,
+	  u8 *lens, u16 *codes, u32 lane)
+{
+	u16 *sorted = L->sorted;
+	u32 *A = L->hw;
+
+	for (u32 s = lane; s < n; s += 64)
+		lens[s] = 0;
+	/* rank sort of used symbols */
+	u32 used = 0;
+	for (u32 s0 = 0; s0 < n; s0 += 64) {
+		u32 s = s0 + lane;
+		u32 f = s < n ? freq[s] : 0;
+		used += __builtin_popcountll(__ballot(f != 0));
+	}
+	for (u32 s = lane; s < n; s += 64) {
+		u32 f = freq[s];
+		if (!f)
+			continue;
+		u32 key = (f << 9) | s, rank = 0;	/* freq < 2^22 */
+		for (u32 t = 0; t < n; t++) {
+			u32 ft = freq[t];
+			rank += (ft != 0) & (((ft << 9) | t) < key);
+		}
+		sorted[rank] = (u16)s;
+	}
+	wave_sync();
+	if (used < 2) {
+		if (lane == 0) {
+			u32 s = used ? sorted[0] : 0;
+			u32 other = s ? 0 : 1;
+			lens[s] = 1;
+			lens[other] = 1;
+		}
+		wave_sync();
+	} else {
+		if (lane == 0) {
+			/* in-place Huffman (Moffat & Katajainen) on A[0..used) */
+			u32 m = used;
+			for (u32 i = 0; i < m; i++)
+				A[i] = freq[sorted[i]];
+			u32 leaf = 0, root = 0;
+			for (u32 next = 0; next + 1 < m; next++) {
+				u32 w;
+				if (leaf >= m || (root < next && A[root] < A[leaf])) {
+					w = A[root]; A[root++] = next;
+				} else {
+					w = A[leaf++];
+				}
+				if (leaf >= m || (root < next && A[root] < A[leaf])) {
+					w += A[root]; A[root++] = next;
+				} else {
+					w += A[leaf++];
+				}
+				A[next] = w;
+			}
+			/* internal node depths */
+			A[m - 2] = 0;
+			for (s32 j = (s32)m - 3; j >= 0; j--)
+				A[j] = A[A[j]] + 1;
+			/* leaf depths: count per depth, clamp later */
+			u32 cnt[40];
+			for (u32 i = 0; i < 40; i++)
+				cnt[i] = 0;
+			s32 avail = 1, usedn = 0, depth = 0;
+			s32 rootj = (s32)m - 2, nextl = (s32)m - 1;
+			while (avail > 0) {
+				while (rootj >= 0 && (s32)A[rootj] == depth) {
+					usedn++;
+					rootj--;
+				}
+				while (avail > usedn) {
+					cnt[depth < 39 ? depth : 39]++;
+					nextl--;
+					avail--;
+				}
+				avail = 2 * usedn;
+				depth++;
+				usedn = 0;
+			}
+			(void)nextl;
+			/* clamp to maxlen, repair Kraft sum (zlib-style) */
+			u32 over = 0;
+			for (u32 d = maxlen + 1; d < 40; d++) {
+				over += cnt[d];
+				cnt[maxlen] += cnt[d];
+				cnt[d] = 0;
+			}
+			if (over) {
+				/* kraft in units of 2^-maxlen */
+				u32 kraft = 0;
+				for (u32 d = 1; d <= maxlen; d++)
+					kraft += cnt[d] << (maxlen - d);
+				while (kraft > (1u << maxlen)) {
+					/* lengthen one codeword: pick the deepest
+					 * level < maxlen that has a leaf */
+					u32 d = maxlen - 1;
+					while (cnt[d] == 0)
+						d--;
+					cnt[d]--;
+					cnt[d + 1] += 2;
+					cnt[maxlen]--;
+					kraft -= 1;	/* 2^-maxlen freed */
+				}
+			}
+			/* assign: rarest symbols get the longest codewords */
+			u32 i = 0;
+			for (u32 d = maxlen; d >= 1; d--)
+				for (u32 k = 0; k < cnt[d]; k++)
+					lens[sorted[i++]] = (u8)d;
+		}
+		wave_sync();
+	}
+	/* canonical codewords, bit-reversed (lane 0: n <= 288 steps) */
+	if (lane == 0) {
+		u32 bl[16], nc[16];
+		for (u32 d = 0; d < 16; d++)
+			bl[d] = 0;
+		for (u32 s = 0; s < n; s++)
+			bl[lens[s]]++;
+		bl[0] = 0;
+		u32 code = 0;
+		for (u32 d = 1; d < 16; d++) {
+			code = (code + bl[d - 1]) << 1;
+			nc[d] = code;
+		}
+		for (u32 s = 0; s < n; s++) {
+			u32 l = lens[s];
+			if (l)
+				codes[s] = (u16)(__brev(nc[l]++) >> (32 - l));
+			else
+				codes[s] = 0;
+		}
+	}
+	wave_sync();
+}
+
+/* ---------------- bit output through the LDS staging area ---------------- */
+
+struct outstate {
+	u8 *out;		/* output slot of this buffer */
+	u64 avail;
+	u64 sg;			/* global byte offset (relative to out, may be
+				 * negative via wrap) of staging word 0; 16-aligned
+				 * as an absolute address */
+	u64 bits;		/* bits produced so far, relative to out[0] */
+};
+
+static __device__ __forceinline__ u32 *stg_of(struct deflate_lds *L)
+{
+	return &L->M[EWIN];
+}
+
+/* OR 'nbits' (<= 57) bits of 'code' at absolute bit position 'bitpos' */
+static __device__ __forceinline__ void
+stg_put(struct deflate_lds *L, const struct outstate *os, u64 bitpos, u64 code,
+	u32 nbits)
+{
+	if (!nbits)
+		return;
+	u64 rel = bitpos - 8 * os->sg;	/* sg <= bitpos/8 by construction */
+	u32 w = (u32)(rel >> 5), s = (u32)rel & 31;
+	u32 *stg = stg_of(L);
+	u64 lo = code << s;
+	atomicOr(&stg[w], (u32)lo);
+	if (s + nbits > 32)
+		atomicOr(&stg[w + 1], (u32)(lo >> 32));
+	if (s + nbits > 64)
+		atomicOr(&stg[w + 2], (u32)(code >> (64 - s)));
+}
+
+/*
+ * Write the completed bytes of the staging area to HBM and slide the rest to
+ * the front.  Whole workgroup; 'final' also writes the last partial unit.
+ */
+static __device__ void
+stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
+{
+	u32 *stg = stg_of(L);
+	u8 *stgb = (u8 *)stg;
+	const u32 tid = threadIdx.x;
+	u64 done_bytes = final ? (os->bits + 7) / 8 : os->bits / 8;
+	u64 rel_end = done_bytes - os->sg;	/* staging bytes that are final */
+	s64 first = -(s64)os->sg;		/* staging index of out[0] if sg<0 */
+	u32 start = first > 0 ? (u32)first : 0;
+	u32 units = final ? (u32)((rel_end + 15) / 16) : (u32)(rel_end / 16);
+
+	__syncthreads();
+	/* 16-byte units: unit u covers staging bytes [16u, 16u+16) */
+	for (u32 u = tid; u < units; u += NT) {
+		u32 b0 = u * 16, b1 = b0 + 16;
+		u8 *g = os->out + (s64)(os->sg + b0);
+		if (b0 >= start && b1 <= rel_end) {
+			*(uint4 *)g = *(const uint4 *)(stgb + b0);
+		} else {
+			for (u32 b = b0 < start ? start : b0; b < b1 && b < rel_end; b++)
+				g[b - b0] = stgb[b];
+		}
+	}
+	__syncthreads();
+	/* slide the unfinished tail to the front */
+	u32 keep_from = units * 16;
+	u32 total_words = (u32)((os->bits - 8 * os->sg + 31) / 32) + 1;
+	u32 keep_words = final ? 0 : total_words - keep_from / 4;
+	u32 v = 0;
+	if (tid < keep_words && keep_from / 4 + tid < STG_WORDS + 8)
+		v = stg[keep_from / 4 + tid];
+	__syncthreads();
+	for (u32 i = tid; i < STG_WORDS + 8; i += NT)
+		stg[i] = 0;
+	__syncthreads();
+	if (tid < keep_words)
+		stg[tid] = v;
+	os->sg += keep_from;
+	__syncthreads();
+}
+
+/* bring back the few unfinished bytes saved in carry[] (the staging area
+ * shares LDS with the tile scratch and is clobbered between blocks) */
+static __device__ void stg_restore(struct deflate_lds *L)
+{
+	u32 *stg = stg_of(L);
+
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < STG_WORDS + 8; i += NT)
+		stg[i] = i < 6 ? L->carry[i] : 0;
+	__syncthreads();
+}
+
+static __device__ void stg_save(struct deflate_lds *L, struct outstate *os)
+{
+	stg_flush(L, os, false);
+	if (threadIdx.x < 6)
+		L->carry[threadIdx.x] = stg_of(L)[threadIdx.x];
+	__syncthreads();
+}
+
+/* ---------------- the kernel ---------------- */
+
+extern "C" __global__ void __launch_bounds__(NT)
+lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
+			 u32 nice, u32 mode,
+			 const u8 *__restrict__ in_base,
+			 const u64 *__restrict__ in_offsets,
+			 const u64 *__restrict__ in_nbytes,
+			 u8 *__restrict__ out_base,
+			 const u64 *__restrict__ out_offsets,
+			 const u64 *__restrict__ out_avail_arr,
+			 u64 *__restrict__ out_nbytes,
+			 const u32 *__restrict__ sums)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
+	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+	for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+		const u8 *inp = in_base + in_offsets[c];
+		const u64 n64 = in_nbytes[c];
+		struct outstate os;
+		os.out = out_base + out_offsets[c];
+		os.avail = out_avail_arr[c];
+		const u32 hdr_bytes = format == LDA_FMT_GZIP ? 10 :
+				      format == LDA_FMT_ZLIB ? 2 : 0;
+		const u32 ftr_bytes = format == LDA_FMT_GZIP ? 8 :
+				      format == LDA_FMT_ZLIB ? 4 : 0;
+		bool overflow = false;
+
+		/* the reference refuses outright when the container cannot fit
+		 * (gzip_compress.c:41-42, zlib_compress.c:42-43) */
+		if (os.avail <= hdr_bytes + ftr_bytes && (hdr_bytes + ftr_bytes))
+			overflow = true;
+		if (n64 > 0xFFFFFF00u)	/* positions are 32-bit here */
+			overflow = true;
+		const u32 n = (u32)n64;
+
+		/* ---- per-buffer init ---- */
+		__syncthreads();
+		for (u32 i = tid; i < (1u << HASH_BITS) / 2; i += NT)
+			((u32 *)L->head)[i] = 0x80008000u;
+		for (u32 i = tid; i < 320; i += NT)
+			L->freq[i] = 0;
+		for (u32 i = tid; i < STG_WORDS + 8; i += NT)
+			stg_of(L)[i] = 0;
+		if (tid < 8)
+			L->M[tid] = 0;
+		if (tid == 0) {
+			L->vars[V_NSEQ] = 0;
+			L->vars[V_ENTRY] = 0;
+		}
+		os.sg = (u64)(0 - ((uintptr_t)os.out & 15));
+		os.bits = 0;
+		__syncthreads();
+
+		/* container header through the staging area */
+		if (!overflow && hdr_bytes) {
+			if (tid == 0) {
+				if (format == LDA_FMT_GZIP) {
+					/* gzip_compress.c:44-64: XFL 4 fastest, 2 best */
+					u32 xfl = level < 2 ? 4 : level >= 8 ? 2 : 0;
+					stg_put(L, &os, 0, 0x00088B1Full, 32);
+					stg_put(L, &os, 32, 0, 32);	/* MTIME */
+					stg_put(L, &os, 64, xfl | (0xFFu << 8), 16);
+				} else {
+					/* zlib_compress.c:45-60 */
+					u32 fl = level < 2 ? 0 : level < 6 ? 1 :
+						 level < 8 ? 2 : 3;
+					u32 h = (0x78u << 8) | (fl << 6);
+					h |= 31 - (h % 31);
+					stg_put(L, &os, 0, ((h & 0xFF) << 8) | (h >> 8), 16);
+				}
+			}
+			os.bits = 8 * hdr_bytes;
+		}
+		__syncthreads();
+		stg_save(L, &os);
+
+		u32 loaded = 0;		/* input bytes present in the ring */
+		u32 block_start = 0;
+		u32 walkpos = 0;	/* absolute position the parse has reached */
+		const bool aligned_in = ((uintptr_t)inp & 15) == 0;
+
+		/* level 0 and tiny inputs: stored blocks only
+		 * (deflate_compress.c:3925-3931, 2392-2443) */
+		const bool stored_only = level == 0 ||
+			n <= (u32)(55 - 4 * (level > 12 ? 12 : level));
+		u32 num_tiles = (n + TILE - 1) / TILE;
+		if (num_tiles == 0)
+			num_tiles = 1;
+
+		for (u32 tile = 0; tile < num_tiles && !overflow; tile++) {
+			const u32 t = tile * TILE;
+			const u32 tend = t + TILE < n ? t + TILE : n;
+			const bool last_tile = tile + 1 == num_tiles;
+
+			/* ---- S0: stage input up to tend + LOOKAHEAD ---- */
+			u32 want = tend + LOOKAHEAD < n ? tend + LOOKAHEAD : n;
+			if (aligned_in) {
+				u32 from = loaded & ~15u;
+				for (u32 p = from + tid * 16; p < want; p += NT * 16) {
+					uint4 v = *(const uint4 *)(inp + p);
+					*(uint4 *)&L->in[p & RMASK] = v;
+					if ((p & RMASK) < 32)
+						*(uint4 *)&L->in[RING + (p & RMASK)] = v;
+				}
+			} else {
+				for (u32 p = loaded + tid; p < want; p += NT) {
+					u8 b = inp[p];
+					L->in[p & RMASK] = b;
+					if ((p & RMASK) < 32)
+						L->in[RING + (p & RMASK)] = b;
+				}
+			}
+			loaded = want;
+			for (u32 i = tid; i < TILE + 8; i += NT)
+				L->mark[i] = 0;
+			__syncthreads();
+
+			if (!stored_only) {
+				/* ---- S1: hash + in-wave sort -> local links ---- */
+#pragma unroll
+				for (u32 gi = 0; gi < TILE / 64 / NWAVES; gi++) {
+					u32 g = wave + NWAVES * gi;
+					u32 gb = t + g * 64;
+					u32 p = gb + lane;
+					bool valid = p + 4 <= n;
+					u32 h = valid ? hash4(ld32(L->in, p)) :
+							(0x4000u | lane);
+					u32 key = (h << 6) | lane;
+#pragma unroll
+					for (u32 k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+						for (u32 j = k >> 1; j > 0; j >>= 1) {
+							u32 other = __shfl_xor(key, j, 64);
+							bool up = (lane & k) == 0;
+							bool lower = (lane & j) == 0;
+							u32 mn = key < other ? key : other;
+							u32 mx = key < other ? other : key;
+							key = (lower == up) ? mn : mx;
+						}
+					}
+					u32 left = __shfl_up(key, 1, 64);
+					u32 right = __shfl_down(key, 1, 64);
+					bool first = lane == 0 || (left >> 6) != (key >> 6);
+					bool last = lane == 63 || (right >> 6) != (key >> 6);
+					u32 orig = key & 63, hh = key >> 6;
+					bool isv = hh < 0x4000u;
+					if (isv && !first)
+						L->prev[(gb + orig) & RMASK] =
+							(u16)(gb + (left & 63));
+					L->M[4 + g * 64 + orig] = hh |
+						(first ? M_FIRST : 0) |
+						(last ? M_LAST : 0) |
+						(isv ? M_VALID : 0);
+				}
+				__syncthreads();
+
+				/* ---- S2: thread groups through head[] in order ---- */
+				if (wave == 0) {
+					u32 ngroups = (tend - t + 63) / 64;
+					for (u32 g = 0; g < ngroups; g++) {
+						u32 i = g * 64 + lane;
+						u32 m = L->M[4 + i];
+						u32 h = m & 0x3FFF;
+						if (m & M_VALID) {
+							if (m & M_FIRST)
+								L->prev[(t + i) & RMASK] = L->head[h];
+							if (m & M_LAST)
+								L->head[h] = (u16)(t + i);
+						}
+						wave_sync();
+					}
+				}
+				__syncthreads();
+
+				/* ---- S3: all positions search their chain ---- */
+				{
+					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
+					u32 lo_pos = lo > 0 ? (u32)lo : 0;
+					for (u32 i = tid; i < TILE; i += NT) {
+						u32 p = t + i;
+						u32 res = 0;
+						if (p + 4 <= n) {
+							u32 maxlen = n - p < 258 ? n - p : 258;
+							u32 nice_l = nice < maxlen ? nice : maxlen;
+							u32 cur = ld32(L->in, p);
+							u32 best = 3, bestd = 0;
+							u32 dmax = p - lo_pos;
+							u32 dprev = 0;
+							u32 c16 = L->prev[p & RMASK];
+							for (u32 dep = depth; dep; dep--) {
+								u32 d = (p - c16) & 0xFFFF;
+								if (d <= dprev || d > dmax)
+									break;
+								u32 cp = p - d;
+								if (ld32(L->in, cp) == cur &&
+								    (best < 4 || best >= maxlen ||
+								     L->in[(cp + best) & RMASK] ==
+								     L->in[(p + best) & RMASK])) {
+									u32 len = 4;
+									while (len < maxlen) {
+										u64 x = ld64(L->in, p + len) ^
+											ld64(L->in, cp + len);
+										if (x) {
+											len += (u32)__builtin_ctzll(x) >> 3;
+											break;
+										}
+										len += 8;
+									}
+									if (len > maxlen)
+										len = maxlen;
+									if (len > best) {
+										best = len;
+										bestd = d;
+										if (len >= nice_l)
+											break;
+									}
+								}
+								dprev = d;
+								c16 = L->prev[cp & RMASK];
+							}
+							if (best >= 4)
+								res = best | (bestd << 16);
+						}
+						L->M[4 + i] = res;
+					}
+				}
+				__syncthreads();
+
+				/* ---- S4: token choice, one lane hops through the tile ---- */
+				if (tid == 0) {
+					s32 p = (s32)L->vars[V_ENTRY];	/* tile-relative */
+					s32 limit = last_tile ? (s32)(tend - t) :
+							(s32)TILE - 2;
+					u32 nseq = L->vars[V_NSEQ];
+					while (p < limit) {
+						u32 m0 = L->M[4 + p];
+						u32 m1 = L->M[4 + p + 1];
+						u32 m2 = L->M[4 + p + 2];
+						u32 l0 = m0 & 0xFFFF;
+						if (l0 == 0) {
+							L->mark[4 + p] = 1;
+							p++;
+							continue;
+						}
+						u32 d0 = m0 >> 16;
+						if (mode >= 1 && l0 < nice) {
+							u32 l1 = m1 & 0xFFFF, d1 = m1 >> 16;
+							if (l1 >= l0 &&
+							    4 * (s32)(l1 - l0) +
+							    ((s32)(31 - __builtin_clz(d0)) -
+							     (s32)(31 - __builtin_clz(d1))) > 2) {
+								L->mark[4 + p] = 1;
+								p++;
+								continue;
+							}
+							if (mode >= 2) {
+								u32 l2 = m2 & 0xFFFF, d2 = m2 >> 16;
+								if (l2 >= l0 &&
+								    4 * (s32)(l2 - l0) +
+								    ((s32)(31 - __builtin_clz(d0)) -
+								     (s32)(31 - __builtin_clz(d2))) > 6) {
+									L->mark[4 + p] = 1;
+									L->mark[4 + p + 1] = 1;
+									p += 2;
+									continue;
+								}
+							}
+						}
+						L->seq_pl[nseq] = (u32)((s32)t + p - (s32)block_start) |
+								  (l0 << 16);
+						L->seq_d[nseq] = (u16)d0;
+						nseq++;
+						p += (s32)l0;
+					}
+					L->vars[V_TMP0] = L->vars[V_NSEQ];	/* first new seq */
+					L->vars[V_NSEQ] = nseq;
+					L->vars[V_WALKPOS_LO] = (u32)((s32)t + p);
+					L->vars[V_ENTRY] = (u32)(p - (s32)TILE);
+				}
+				__syncthreads();
+				walkpos = L->vars[V_WALKPOS_LO];
+
+				/* histogram of the tokens chosen in this tile */
+				{
+					u32 s0 = L->vars[V_TMP0], s1 = L->vars[V_NSEQ];
+					for (u32 s = s0 + tid; s < s1; s += NT) {
+						u32 sl, xb, xv;
+						length_code(L->seq_pl[s] >> 16, &sl, &xb, &xv);
+						atomicAdd(&L->freq[257 + sl], 1u);
+						dist_code(L->seq_d[s], &sl, &xb, &xv);
+						atomicAdd(&L->freq[288 + sl], 1u);
+					}
+					for (u32 i = tid; i < TILE + 4; i += NT) {
+						if (L->mark[i]) {
+							u32 pos = t + i - 4;	/* index 4 <-> t */
+							atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
+						}
+					}
+				}
+				__syncthreads();
+				/* carry the last 4 match entries to the front for the
+				 * positions the walk deferred */
+				if (tid < 4)
+					L->M[tid] = L->M[TILE + tid];
+			} else {
+				walkpos = tend;
+			}
+			__syncthreads();
+
+			/* ---- block end? ---- */
+			bool end_block = last_tile ||
+				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_CAP) ||
+				walkpos - block_start > MAX_BLOCK_SOFT;
+			if (!end_block)
+				continue;
+
+			const u32 bstart = block_start, bend = last_tile ? n : walkpos;
+			const u32 blen = bend - bstart;
+			const u32 nseq = stored_only ? 0 : L->vars[V_NSEQ];
+			const u32 is_final = last_tile ? 1 : 0;
+
+			/* ---- S5: codes, costs, block type ---- */
+			u32 btype = 0;	/* 0 stored, 1 static, 2 dynamic */
+			if (!stored_only) {
+				if (tid == 0)
+					L->freq[256]++;
+				__syncthreads();
+				if (wave == 0) {
+					make_code(L, L->freq, 288, 15, L->lens, L->codes, lane);
+					make_code(L, L->freq + 288, 32, 15, L->lens + 288,
+						  L->codes + 288, lane);
+				}
+				__syncthreads();
+				if (tid == 0) {
+					/* precode items: RLE of the lens
+					 * (deflate_compress.c:1482-1557 semantics) */
+					u32 nlit = 288, noff = 32;
+					while (nlit > 257 && L->lens[nlit - 1] == 0)
+						nlit--;
+					while (noff > 1 && L->lens[288 + noff - 1] == 0)
+						noff--;
+					for (u32 i = 0; i < 19; i++)
+						L->pre_freq[i] = 0;
+					u32 total = nlit + noff, ni = 0, i = 0;
+					while (i < total) {
+						u32 idx = i < nlit ? i : 288 + (i - nlit);
+						u32 v = L->lens[idx];
+						u32 run = 1;
+						while (i + run < total) {
+							u32 j = i + run;
+							u32 jdx = j < nlit ? j : 288 + (j - nlit);
+							if (L->lens[jdx] != v)
+								break;
+							run++;
+						}
+						u32 left = run;
+						if (v == 0) {
+							while (left >= 11) {
+								u32 r = left > 138 ? 138 : left;
+								L->pre_items[ni++] = 18 | ((r - 11) << 5);
+								L->pre_freq[18]++;
+								left -= r;
+							}
+							if (left >= 3) {
+								L->pre_items[ni++] = 17 | ((left - 3) << 5);
+								L->pre_freq[17]++;
+								left = 0;
+							}
+						} else if (left >= 4) {
+							L->pre_items[ni++] = (u16)v;
+							L->pre_freq[v]++;
+							left--;
+							while (left >= 3) {
+								u32 r = left > 6 ? 6 : left;
+								L->pre_items[ni++] = 16 | ((r - 3) << 5);
+								L->pre_freq[16]++;
+								left -= r;
+							}
+						}
+						while (left) {
+							L->pre_items[ni++] = (u16)v;
+							L->pre_freq[v]++;
+							left--;
+						}
+						i += run;
+					}
+					L->vars[V_NPRE] = ni;
+					L->vars[V_TMP1] = nlit;
+					L->vars[V_TMP2] = noff;
+				}
+				__syncthreads();
+				if (wave == 0)
+					make_code(L, L->pre_freq, 19, 7, L->pre_lens,
+						  L->pre_codes, lane);
+				__syncthreads();
+				/* exact costs (deflate_compress.c:1747-1808) */
+				u32 dyn = 0, stat = 0;
+				if (tid < 320) {
+					u32 f = L->freq[tid];
+					u32 xb = 0, sl = 8;
+					if (tid < 288) {
+						sl = tid < 144 ? 8 : tid < 256 ? 9 : tid < 280 ? 7 : 8;
+						if (tid >= 265 && tid < 285)
+							xb = (tid - 261) >> 2;
+					} else {
+						u32 ds = tid - 288;
+						sl = 5;
+						if (ds >= 4)
+							xb = (ds >> 1) - 1;
+					}
+					dyn = f * (L->lens[tid] + xb);
+					stat = f * (sl + xb);
+				}
+				if (tid < 19) {
+					u32 xb = tid == 16 ? 2 : tid == 17 ? 3 : tid == 18 ? 7 : 0;
+					dyn += L->pre_freq[tid] * (L->pre_lens[tid] + xb);
+				}
+				u32 dyn_tot, stat_tot;
+				(void)block_scan(L, dyn, &dyn_tot);
+				(void)block_scan(L, stat, &stat_tot);
+				static const u8 perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10,
+							     5, 11, 4, 12, 3, 13, 2, 14,
+							     1, 15 };
+				u32 nexp = 19;
+				while (nexp > 4 && L->pre_lens[perm[nexp - 1]] == 0)
+					nexp--;
+				u32 cost_dyn = 3 + 5 + 5 + 4 + 3 * nexp + dyn_tot;
+				u32 cost_stat = 3 + stat_tot;
+				/* stored: align + (LEN,NLEN) per <= 65535 piece */
+				u32 pieces = blen ? (blen + 65534) / 65535 : 1;
+				u32 pad = (u32)((0 - (os.bits + 3)) & 7);
+				u64 cost_stored = 3 + pad + 32 + 8ull * blen +
+						  (u64)(pieces - 1) * 40;
+				u64 best = cost_stored;
+				btype = 0;
+				if (cost_stat < best) {
+					best = cost_stat;
+					btype = 1;
+				}
+				if (cost_dyn < best) {
+					best = cost_dyn;
+					btype = 2;
+				}
+				if ((os.bits + best + 7) / 8 + ftr_bytes > os.avail)
+					overflow = true;
+				L->vars[V_TMP3] = nexp;
+			} else {
+				u32 pieces = blen ? (blen + 65534) / 65535 : 1;
+				u64 cost = (u64)pieces * 40 + 8ull * blen;
+				if ((os.bits + cost + 7) / 8 + ftr_bytes > os.avail)
+					overflow = true;
+			}
+			if (overflow)
+				break;
+
+			/* ---- S6: emit ---- */
+			stg_restore(L);
+			if (btype == 0) {
+				/* stored pieces: header by thread 0, bytes as 8-bit
+				 * "codes" through the same staging path */
+				u32 done = 0;
+				do {
+					u32 piece = blen - done > 65535 ? 65535 : blen - done;
+					u32 fin = (is_final && done + piece == blen) ? 1 : 0;
+					u32 pad = (u32)((0 - (os.bits + 3)) & 7);
+					if (tid == 0) {
+						stg_put(L, &os, os.bits, fin, 3);
+						u64 b = os.bits + 3 + pad;
+						stg_put(L, &os, b, piece | ((u64)(piece ^ 0xFFFF) << 16), 32);
+					}
+					os.bits += 3 + pad + 32;
+					__syncthreads();
+					for (u32 w0 = 0; w0 < piece; w0 += 2048) {
+						u32 cnt = piece - w0 < 2048 ? piece - w0 : 2048;
+						stg_flush(L, &os, false);
+						for (u32 j = tid; j < cnt; j += NT) {
+							u32 pos = bstart + done + w0 + j;
+							stg_put(L, &os, os.bits + 8ull * j,
+								L->in[pos & RMASK], 8);
+						}
+						os.bits += 8ull * cnt;
+						__syncthreads();
+					}
+					done += piece;
+				} while (done < blen);
+				stg_flush(L, &os, false);
+			} else {
+				if (btype == 1) {
+					/* static codes: lens fixed, canonical codewords */
+					__syncthreads();
+					for (u32 s = tid; s < 320; s += NT)
+						L->lens[s] = s < 144 ? 8 : s < 256 ? 9 :
+							     s < 280 ? 7 : s < 288 ? 8 : 5;
+					__syncthreads();
+					if (tid == 0) {
+						u32 nc[16] = { 0 }, bl[16] = { 0 };
+						for (u32 s = 0; s < 288; s++)
+							bl[L->lens[s]]++;
+						u32 code = 0;
+						for (u32 d = 1; d < 16; d++) {
+							code = (code + bl[d - 1]) << 1;
+							nc[d] = code;
+						}
+						for (u32 s = 0; s < 288; s++) {
+							u32 l = L->lens[s];
+							L->codes[s] = (u16)(__brev(nc[l]++) >> (32 - l));
+						}
+						for (u32 s = 0; s < 32; s++)
+							L->codes[288 + s] = (u16)(__brev(s) >> 27);
+					}
+					__syncthreads();
+				}
+				/* block header (thread 0; <= ~330 items) */
+				if (tid == 0) {
+					u64 b = os.bits;
+					stg_put(L, &os, b, is_final | (btype << 1), 3);
+					b += 3;
+					if (btype == 2) {
+						u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
+						u32 nexp = L->vars[V_TMP3];
+						static const u8 perm2[19] = { 16, 17, 18, 0, 8, 7,
+							9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+						stg_put(L, &os, b, (nlit - 257) | ((noff - 1) << 5) |
+							((nexp - 4) << 10), 14);
+						b += 14;
+						for (u32 i = 0; i < nexp; i++) {
+							stg_put(L, &os, b, L->pre_lens[perm2[i]], 3);
+							b += 3;
+						}
+						u32 ni = L->vars[V_NPRE];
+						for (u32 i = 0; i < ni; i++) {
+							u32 it = L->pre_items[i];
+							u32 sym = it & 31, ex = it >> 5;
+							u32 l = L->pre_lens[sym];
+							u32 xb = sym == 16 ? 2 : sym == 17 ? 3 :
+								 sym == 18 ? 7 : 0;
+							stg_put(L, &os, b, L->pre_codes[sym] |
+								((u64)ex << l), l + xb);
+							b += l + xb;
+						}
+					}
+					L->vars[V_TMP0] = (u32)(b - os.bits);
+				}
+				__syncthreads();
+				os.bits += L->vars[V_TMP0];
+				stg_flush(L, &os, false);
+
+				/* tokens, EWIN positions at a time */
+				u32 *KD = L->M;
+				u32 seq_lo = 0;
+				if (tid == 0)
+					L->vars[V_SPILL] = 0;
+				__syncthreads();
+				for (u32 w0 = bstart; w0 < bend; w0 += EWIN) {
+					u32 wend = w0 + EWIN < bend ? w0 + EWIN : bend;
+					u32 spill = L->vars[V_SPILL];	/* covered prefix */
+					__syncthreads();
+					for (u32 i = tid; i < EWIN; i += NT)
+						KD[i] = i < spill ? 0xFFFFFFFFu : 0;
+					if (tid == 0)
+						L->vars[V_SPILL] = 0;
+					__syncthreads();
+					/* matches that start in this window */
+					u32 seq_hi = seq_lo;
+					{
+						/* seqs are position-sorted: find the range by a
+						 * strided scan (each thread tests its seqs) */
+						u32 cnt = 0;
+						for (u32 s = seq_lo + tid; s < nseq; s += NT) {
+							u32 pl = L->seq_pl[s];
+							u32 pos = bstart + (pl & 0xFFFF);
+							if (pos >= wend)
+								break;
+							u32 len = pl >> 16;
+							u32 q = pos - w0;
+							KD[q] = len | ((u32)L->seq_d[s] << 16);
+							for (u32 j = 1; j < len && q + j < EWIN; j++)
+								KD[q + j] = 0xFFFFFFFFu;
+							if (pos + len > w0 + EWIN)
+								atomicMax(&L->vars[V_SPILL],
+									  pos + len - (w0 + EWIN));
+							cnt++;
+						}
+						u32 tot;
+						(void)block_scan(L, cnt, &tot);
+						seq_hi = seq_lo + tot;
+					}
+					__syncthreads();
+					/* each thread: 2 consecutive positions */
+					u64 code[2];
+					u32 nb[2];
+#pragma unroll
+					for (u32 k = 0; k < 2; k++) {
+						u32 q = tid * 2 + k;
+						u32 pos = w0 + q;
+						code[k] = 0;
+						nb[k] = 0;
+						if (pos >= wend)
+							continue;
+						u32 kd = KD[q];
+						if (kd == 0xFFFFFFFFu)
+							continue;
+						if (kd == 0) {
+							u32 b = L->in[pos & RMASK];
+							code[k] = L->codes[b];
+							nb[k] = L->lens[b];
+						} else {
+							u32 len = kd & 0xFFFF, dist = kd >> 16;
+							u32 sl, xb, xv, ds, dxb, dxv;
+							length_code(len, &sl, &xb, &xv);
+							dist_code(dist, &ds, &dxb, &dxv);
+							u32 ll = L->lens[257 + sl];
+							u32 dl = L->lens[288 + ds];
+							u64 v = L->codes[257 + sl];
+							u32 sh = ll;
+							v |= (u64)xv << sh;
+							sh += xb;
+							v |= (u64)L->codes[288 + ds] << sh;
+							sh += dl;
+							v |= (u64)dxv << sh;
+							sh += dxb;
+							code[k] = v;
+							nb[k] = sh;
+						}
+					}
+					u32 tot;
+					u32 off = block_scan(L, nb[0] + nb[1], &tot);
+					stg_put(L, &os, os.bits + off, code[0], nb[0]);
+					stg_put(L, &os, os.bits + off + nb[0], code[1], nb[1]);
+					os.bits += tot;
+					seq_lo = seq_hi;
+					stg_flush(L, &os, false);
+				}
+				/* end of block */
+				if (tid == 0)
+					stg_put(L, &os, os.bits, L->codes[256], L->lens[256]);
+				os.bits += L->lens[256];
+				__syncthreads();
+			}
+
+			/* keep the unfinished staging bytes across the next tiles
+			 * (M is reused as tile scratch) */
+			stg_save(L, &os);
+			for (u32 i = tid; i < 320; i += NT)
+				L->freq[i] = 0;
+			if (tid == 0)
+				L->vars[V_NSEQ] = 0;
+			/* restore what S1..S4 expect in M[0..3]: the deferred
+			 * entries were consumed only if the walk passed them; the
+			 * encode pass clobbered them, so re-derive from nothing:
+			 * deferred positions are re-evaluated as "no match" */
+			if (tid < 4)
+				L->M[tid] = 0;
+			block_start = bend;
+			__syncthreads();
+		}
+
+		/* ---- finish the stream ---- */
+		__syncthreads();
+		if (!overflow) {
+			stg_restore(L);
+			if (ftr_bytes) {
+				/* gzip_compress.c:73-79 / zlib_compress.c:66-72 */
+				u32 sum = sums ? sums[c] : 0;
+				u64 fb = 8 * ((os.bits + 7) / 8);
+				if (tid == 0) {
+					if (format == LDA_FMT_GZIP) {
+						stg_put(L, &os, fb, sum, 32);
+						stg_put(L, &os, fb + 32, n, 32);
+					} else {
+						stg_put(L, &os, fb, __builtin_bswap32(sum), 32);
+					}
+				}
+				os.bits = fb + 8 * ftr_bytes;
+				__syncthreads();
+			}
+			stg_flush(L, &os, true);
+			if (tid == 0)
+				out_nbytes[c] = (os.bits + 7) / 8;
+		} else if (tid == 0) {
+			out_nbytes[c] = 0;
+		}
+		__syncthreads();
+	}
+}
+
+/* host helper: dynamic LDS size the kernel needs */
+extern "C" size_t lda_deflate_lds_bytes(void)
+{
+	return sizeof(struct deflate_lds);
+}

@@ -33,6 +33,16 @@ lda_inflate_finalize_kernel(uint64_t n_chunks, int format, int exact_fill,
 			    int32_t *results, uint64_t *actual_in,
 			    uint64_t *actual_out);
 
+/* deflate_kernel.hip */
+extern "C" __global__ void
+lda_deflate_batch_kernel(uint64_t n_chunks, int format, int level,
+			 uint32_t depth, uint32_t nice, uint32_t mode,
+			 const uint8_t *in_base, const uint64_t *in_offsets,
+			 const uint64_t *in_nbytes, uint8_t *out_base,
+			 const uint64_t *out_offsets, const uint64_t *out_avail,
+			 uint64_t *out_nbytes, const uint32_t *sums);
+extern "C" size_t lda_deflate_lds_bytes(void);
+
 /* CRC constant tables, generated on the host at first use (host_api.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)
 #define LDA_CRC_XPOW_WORDS 1024

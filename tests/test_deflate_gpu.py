@@ -1,0 +1,144 @@
+"""GPU compressor (HIP) through the C-ABI.  Compressed bytes are unpinned by
+the reference (libdeflate.h:76-83); what is checked is what the reference
+guarantees and its own tests check (scripts/exec_tests.sh:23-36,
+test_litrunlen_overflow.c, test_trailing_bytes.c):
+  - the stream is valid and round-trips byte-exact through the ORACLE decoder
+    and through zlib (independent control),
+  - size <= compress_bound, container bytes/footers exact,
+  - returns 0 exactly when the output does not fit,
+  - ratio tracks the reference's at the same level (reported, loose gate)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import datagen, streams
+
+pytestmark = pytest.mark.gpu
+WBITS = {"deflate": -15, "zlib": 15, "gzip": 31}
+
+
+def _check_roundtrip(oracle, fmt, data, comp, tag):
+    assert comp is not None, tag
+    r, ain, aout, out = oracle.decompress_ex(fmt, comp, len(data))
+    assert r == 0, (tag, "oracle result", r)
+    assert ain == len(comp), (tag, "trailing bytes in stream")
+    assert out == data, (tag, "round trip differs")
+    assert zlib.decompress(comp, WBITS[fmt]) == data, (tag, "zlib control")
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 4, 5, 6, 8, 9, 12])
+def test_roundtrip_sizes_formats(level, oracle):
+    from libdeflate_amd import api
+    c = api.Compressor(level)
+    sizes = [0, 1, 18, 19, 20, 31, 32, 51, 52, 511, 512, 4999, 5000, 5001,
+             65535, 65536, 65537, 300000]
+    for fmt in ("deflate", "zlib", "gzip"):
+        chunks = [datagen.chunk(i, n, 0x0E110020 + level) for i, n in enumerate(sizes)]
+        comps = c.compress_batch_host(fmt, chunks)
+        for d, z in zip(chunks, comps):
+            _check_roundtrip(oracle, fmt, d, z, (level, fmt, len(d)))
+            assert len(z) <= c.bound(fmt, len(d))
+    c.close()
+
+
+def test_single_buffer_api_and_overflow(oracle):
+    from libdeflate_amd import api
+    c = api.Compressor(6)
+    data = streams.trailing_bytes_input()
+    for fmt in ("deflate", "zlib", "gzip"):
+        z = c.compress(fmt, data)
+        _check_roundtrip(oracle, fmt, data, z, fmt)
+        # exact fit succeeds, one byte less returns 0 (libdeflate.h:73-74)
+        assert c.compress(fmt, data, len(z)) is not None
+        assert c.compress(fmt, data, len(z) - 1) is None
+    rnd = datagen.random_chunk(70000, 5)
+    z = c.compress("deflate", rnd)
+    assert len(z) <= c.bound("deflate", len(rnd))
+    _check_roundtrip(oracle, "deflate", rnd, z, "random")
+    assert c.compress("gzip", b"abc", 18) is None     # gzip_compress.c:41-42
+    assert c.compress("zlib", b"abc", 6) is None      # zlib_compress.c:42-43
+    lit = streams.litrunlen_input()                   # test_litrunlen_overflow.c
+    for lvl in (3, 6, 12):
+        cl = api.Compressor(lvl)
+        _check_roundtrip(oracle, "deflate", lit, cl.compress("deflate", lit), lvl)
+        cl.close()
+    c.close()
+
+
+def test_container_bytes(oracle):
+    """header/footer bytes per lib/gzip_compress.c:44-79, zlib_compress.c:45-72"""
+    from libdeflate_amd import api
+    data = datagen.text_chunk(10000, 9)
+    want_zlib = {1: b"\x78\x01", 5: b"\x78\x5e", 6: b"\x78\x9c", 9: b"\x78\xda"}
+    want_xfl = {1: 4, 6: 0, 9: 2}
+    for lvl in (1, 5, 6, 9):
+        c = api.Compressor(lvl)
+        z = c.compress("zlib", data)
+        assert z[:2] == want_zlib[lvl]
+        assert int.from_bytes(z[-4:], "big") == zlib.adler32(data)
+        if lvl in want_xfl:
+            g = c.compress("gzip", data)
+            assert g[:10] == b"\x1f\x8b\x08\x00\x00\x00\x00\x00" + bytes([want_xfl[lvl], 0xFF])
+            assert int.from_bytes(g[-8:-4], "little") == zlib.crc32(data)
+            assert int.from_bytes(g[-4:], "little") == len(data)
+        c.close()
+
+
+def test_ratio_tracks_reference(oracle):
+    """Reported, loosely gated: GPU level L within 15% of the reference's
+    compressed size at level L on the 64 KiB mix."""
+    from libdeflate_amd import api
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    chunks = [datagen.chunk(i, 65536, 0x0E110003) for i in range(16)]
+    for lvl in (1, 6, 9):
+        c = api.Compressor(lvl)
+        comps = c.compress_batch_host("deflate", chunks)
+        ours = sum(len(z) for z in comps)
+        for d, z in zip(chunks, comps):
+            _check_roundtrip(oracle, "deflate", d, z, lvl)
+        if ref:
+            theirs = sum(len(ref.compress("deflate", lvl, d)) for d in chunks)
+        else:
+            theirs = sum(len(streams._zcompress("deflate", lvl, d)) for d in chunks)
+        print(f"level {lvl}: ours {ours} ref {theirs} ratio {ours/theirs:.4f}")
+        assert ours <= theirs * 1.15
+        c.close()
+
+
+def test_device_batch_roundtrip(oracle):
+    """Config 2/3 shape at reduced count: compress in HBM, decompress in HBM
+    with our own decoder, compare every byte; sizes <= bound."""
+    import torch
+    from libdeflate_amd import api
+    n, size = 256, 65536
+    chunks = datagen.batch(n, size, 0x0E110002, distinct=32)
+    data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+    for fmt, lvl in (("deflate", 1), ("gzip", 6), ("zlib", 9)):
+        c = api.Compressor(lvl)
+        d = api.Decompressor()
+        bound = (c.bound(fmt, size) + 15) // 16 * 16
+        in_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+        in_n = torch.full((n,), size, dtype=torch.int64, device="cuda")
+        comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+        c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
+        c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
+        c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
+        c.compress_batch(fmt, data, in_off, in_n, comp, c_off, c_av, c_n)
+        torch.cuda.synchronize()
+        sizes = c_n.cpu().numpy()
+        assert (sizes > 0).all() and (sizes <= c.bound(fmt, size)).all()
+        out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+        res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        d.decompress_batch(fmt, comp, c_off, c_n, out, in_off, in_n, res)
+        torch.cuda.synchronize()
+        assert res.cpu().numpy().tolist() == [0] * n
+        assert torch.equal(out, data)
+        # and the oracle agrees on a few of them
+        cb = comp.cpu().numpy()
+        for i in (0, 5, 7, n - 1):
+            z = cb[i * bound:i * bound + sizes[i]].tobytes()
+            _check_roundtrip(oracle, fmt, chunks[i], z, (fmt, i))
+        c.close()
+        d.close()

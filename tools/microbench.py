@@ -52,6 +52,39 @@ def main():
                 continue
             t = timeit(lambda: api.checksum_batch(kind, data, offs, nb, out))
             print(f"{kind}: {total/t/1e9:.1f} GB/s  ({t*1e3:.3f} ms for {total/2**20:.0f} MiB)")
+    if a.what in ("inflate", "all"):
+        bench_inflate(a)
+
+
+def bench_inflate(a, fmt="gzip", level=6):
+    from tests import oracle_util, streams
+    ref = oracle_util.load_ref()
+    distinct = 64
+    chunks = datagen.batch(a.chunks, a.size, 0x0E110004, distinct=distinct)
+    comp = [ref.compress(fmt, level, c) if ref else streams._zcompress(fmt, level, c)
+            for c in chunks[:distinct]]
+    offs, blob, sizes = [], bytearray(), []
+    for i in range(a.chunks):
+        c = comp[i % distinct]
+        offs.append(len(blob)); sizes.append(len(c))
+        blob += c
+        blob += bytes((-len(blob)) % 16)
+    blob += bytes(64)
+    d_in = torch.frombuffer(blob, dtype=torch.uint8).cuda()
+    in_off = torch.tensor(offs, dtype=torch.int64).cuda()
+    in_n = torch.tensor(sizes, dtype=torch.int64).cuda()
+    d_out = torch.zeros(a.chunks * a.size, dtype=torch.uint8, device="cuda")
+    out_off = torch.arange(a.chunks, dtype=torch.int64, device="cuda") * a.size
+    out_av = torch.full((a.chunks,), a.size, dtype=torch.int64, device="cuda")
+    res = torch.full((a.chunks,), -1, dtype=torch.int32, device="cuda")
+    dec = api.Decompressor()
+    f = lambda: dec.decompress_batch(fmt, d_in, in_off, in_n, d_out, out_off, out_av, res)
+    t = timeit(f, iters=5, warmup=1)
+    ok = int((res == 0).sum())
+    U = a.chunks * a.size
+    C = sum(sizes)
+    print(f"inflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic {(U+C)/t/1e9:.2f} GB/s, "
+          f"{t*1e3:.2f} ms, ratio {C/U:.3f}, ok {ok}/{a.chunks}")
 
 
 if __name__ == "__main__":
