@@ -200,9 +200,11 @@ enum libdeflate_amd_status {
 };
 
 /* 0 when a usable device is present; never falls back to the CPU */
-LIBDEFLATEAPI int libdeflate_amd_device_ready(void);
+LIBDEFLATEAPI int
+libdeflate_amd_device_ready(void);
 /* human-readable reason for the last non-OK status (thread-local) */
-LIBDEFLATEAPI const char *libdeflate_amd_last_error(void);
+LIBDEFLATEAPI const char *
+libdeflate_amd_last_error(void);
 
 /*
  * Chunk i of a batch occupies bytes [offsets[i], offsets[i] + nbytes[i]) of a

@@ -1,0 +1,74 @@
+"""Sharding a batch of independent chunks over the GPUs of one node.
+
+Chunks are self-contained streams (fresh match-finder state and fresh Huffman
+codes per call: lib/deflate_compress.c:2616,2630; decoder state on the stack:
+lib/decompress_template.h:50-70), so the data path needs no collective: rank g
+of G owns the contiguous index range [g*N/G, (g+1)*N/G) (contiguous keeps the
+gather a concatenation and preserves input order).  The only exchange is the
+final gather to the root, over RCCL (torch.distributed backend "nccl") on
+GPUs, gloo in the CPU tests:
+
+  gather_verdicts   fixed-size per-chunk metadata (compressed size, status)
+  gather_payload    the variable-length compressed bytes, as one padded
+                    all_gather of each rank's compacted segment
+"""
+import torch
+
+
+def partition(n_chunks, world, rank):
+    """Contiguous shard [lo, hi) of rank `rank`."""
+    lo = rank * n_chunks // world
+    hi = (rank + 1) * n_chunks // world
+    return lo, hi
+
+
+def gather_verdicts(sizes, results, dist, world):
+    """Gather (size, status) of every chunk to rank 0.  Returns
+    (total_chunks, n_failed) on rank 0 and (local count, local failed)
+    elsewhere.  sizes: int64[n]; results: int32[n]."""
+    packed = torch.stack([sizes, results.to(torch.int64)], dim=1).contiguous()
+    if dist is None or world == 1:
+        return packed.shape[0], int((packed[:, 1] != 0).sum())
+    rank = dist.get_rank()
+    # shards may differ by one chunk: pad to the largest, first row = count
+    cnt = torch.tensor([packed.shape[0]], dtype=torch.int64, device=packed.device)
+    mx = cnt.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    padded = torch.zeros((int(mx.item()) + 1, 2), dtype=torch.int64,
+                         device=packed.device)
+    padded[0, 0] = packed.shape[0]
+    padded[1:1 + packed.shape[0]] = packed
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0)
+    if rank == 0:
+        allv = torch.cat([b[1:1 + int(b[0, 0].item())] for b in bufs], dim=0)
+        return allv.shape[0], int((allv[:, 1] != 0).sum())
+    return packed.shape[0], int((packed[:, 1] != 0).sum())
+
+
+def compact(payload, offsets, sizes):
+    """Concatenate the used part of each output slot (host-side helper for the
+    payload gather; returns a uint8 tensor on payload's device)."""
+    parts = [payload[int(o):int(o) + int(s)] for o, s in
+             zip(offsets.tolist(), sizes.tolist())]
+    return torch.cat(parts) if parts else payload[:0]
+
+
+def gather_payload(segment, dist, world):
+    """All ranks contribute one compacted uint8 segment; rank 0 gets the list
+    of segments in rank order (others get None).  Lengths travel first, the
+    bytes as one padded all_gather (xGMI is point-to-point: a single large
+    transfer per peer beats many small ones)."""
+    if dist is None or world == 1:
+        return [segment]
+    n = torch.tensor([segment.numel()], dtype=torch.int64, device=segment.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    maxlen = int(max(int(x.item()) for x in lens))
+    pad = torch.zeros(maxlen, dtype=torch.uint8, device=segment.device)
+    pad[:segment.numel()] = segment
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if dist.get_rank() != 0:
+        return None
+    return [b[:int(l.item())] for b, l in zip(bufs, lens)]

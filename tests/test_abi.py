@@ -1,0 +1,86 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every
+symbol include/libdeflate_amd.h declares, the header matches the binding, and
+the calls that need no device behave (bounds, NULL rules).  No GPU compute."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from libdeflate_amd import binding
+    if not os.path.exists(binding.LIB_PATH):
+        g.build()
+    return binding.load()
+
+
+def test_header_symbols_exported(lib):
+    from libdeflate_amd import binding
+    hdr = open(os.path.join(ROOT, "include", "libdeflate_amd.h")).read()
+    declared = set(re.findall(r"^(libdeflate_[a-z0-9_]+)\(", hdr, re.M))
+    assert len([s for s in declared if not s.startswith("libdeflate_amd_")]) == 21
+    assert declared == set(binding.DROPIN_SYMBOLS) | set(binding.BATCH_SYMBOLS)
+    assert binding.MISSING == []
+    out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH],
+                         capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (libdeflate_\w+)", out))
+    assert declared <= exported
+    # nothing of the oracle leaks into the product
+    assert "oracle" not in out
+
+
+def test_bounds_and_null_rules_without_device(lib, oracle):
+    # pure functions of n: lib/deflate_compress.c:4087-4135
+    for n in (0, 1, 4999, 5000, 5001, 65536, 1 << 20, (1 << 32) + 5):
+        for f in ("deflate", "zlib", "gzip"):
+            got = getattr(lib, f"libdeflate_{f}_compress_bound")(None, n)
+            assert got == oracle.bound(f, n)
+    assert lib.libdeflate_deflate_compress_bound(None, 65536) == 65606
+    assert lib.libdeflate_gzip_compress_bound(None, 4096) == 4119
+    # NULL buffer -> initial value, before any device work
+    assert lib.libdeflate_crc32(123, None, 99) == 0
+    assert lib.libdeflate_adler32(123, None, 99) == 1
+    lib.libdeflate_free_compressor(None)
+    lib.libdeflate_free_decompressor(None)
+
+
+def test_fails_loudly_without_gpu(lib):
+    """No CPU fallback: on a box without a gfx950 device the allocators return
+    NULL and report why."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.libdeflate_amd_device_ready() != 0
+    assert not lib.libdeflate_alloc_compressor(6)
+    assert not lib.libdeflate_alloc_decompressor()
+    assert lib.libdeflate_amd_last_error()
+
+
+def test_alloc_argument_validation(lib):
+    # level outside [-1, 12] -> NULL (libdeflate.h:49-50), checked before the
+    # device is touched; bad sizeof_options -> NULL (deflate_compress.c:3885)
+    assert not lib.libdeflate_alloc_compressor(13)
+    assert not lib.libdeflate_alloc_compressor(-2)
+
+    class Opt(ctypes.Structure):
+        _fields_ = [("sizeof_options", ctypes.c_size_t),
+                    ("malloc_func", ctypes.c_void_p),
+                    ("free_func", ctypes.c_void_p)]
+    bad = Opt(8, None, None)
+    assert not lib.libdeflate_alloc_compressor_ex(6, ctypes.byref(bad))
+    assert not lib.libdeflate_alloc_decompressor_ex(ctypes.byref(bad))
+
+
+def test_product_does_not_reference_oracle():
+    """The product path must never import/link the checker."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "libdeflate_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f == "Makefile", (dirpath, f)
