@@ -12,7 +12,10 @@ from ctypes import (POINTER, c_char_p, c_int, c_int32, c_size_t, c_uint32,
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeflate_amd.so")
+# LIBDEFLATE_AMD_LIB selects another build of the same library (e.g. the
+# phase-profiling build libdeflate_amd_prof.so); never a different backend.
+LIB_PATH = os.environ.get("LIBDEFLATE_AMD_LIB",
+                          os.path.join(_HERE, "libdeflate_amd.so"))
 
 SUCCESS, BAD_DATA, SHORT_OUTPUT, INSUFFICIENT_SPACE = 0, 1, 2, 3
 FMT_DEFLATE, FMT_ZLIB, FMT_GZIP = 0, 1, 2

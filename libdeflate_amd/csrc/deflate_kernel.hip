@@ -57,7 +57,7 @@
 #define LOOKAHEAD 272u
 #define HASH_BITS 14
 #define SEQ_CAP 2048u
-#define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile */
+#define SEQ_TILE_MAX 520u	/* > TILE/4 new matches per tile (min match 4) */
 #define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
 #define EWIN 1024u		/* encode window (positions) */
 #define STG_WORDS 1024u		/* 4 KiB staging */
@@ -75,14 +75,20 @@ struct deflate_lds {
 	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
 	u8 mark[TILE + 8];	/* 1 = literal chosen at this position */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
-	u8 lens[320];
-	u16 codes[320];		/* bit-reversed codewords */
-	u16 sorted[288];
-	u32 hw[288 * 2];	/* Huffman build scratch */
-	u16 pre_items[320 + 8];	/* precode symbol | extra << 5 */
-	u32 pre_freq[19];
-	u8 pre_lens[19];
-	u16 pre_codes[19];
+	union {
+		struct {	/* live only while a block is being finished */
+			u8 lens[320];
+			u16 codes[320];	/* bit-reversed codewords */
+			u16 sorted[288];
+			u32 hw[288];	/* Huffman build scratch */
+			u16 pre_items[320 + 8];	/* precode symbol | extra << 5 */
+			u32 pre_freq[19];
+			u8 pre_lens[20];
+			u16 pre_codes[20];
+		};
+		u16 nxtB[TILE + 8];	/* live only during the token choice */
+	};
+	u16 nxtA[TILE + 8];
 	u32 scan[NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 vars[16];
@@ -101,18 +107,27 @@ struct level_params {
 
 /* ---------------- small helpers ---------------- */
 
+/*
+ * Unaligned reads from the input ring as ALIGNED dword reads + a byte funnel
+ * shift (v_alignbyte): misaligned ds_read_b32/b64 are legal on gfx950 but
+ * measured ~10x slower than aligned ones.  The ring is mirrored for 32 bytes
+ * past its end so idx+1/idx+2 never wrap.
+ */
 static __device__ __forceinline__ u32 ld32(const u8 *ring, u32 pos)
 {
-	u32 v;
-	__builtin_memcpy(&v, ring + (pos & RMASK), 4);
-	return v;
+	const u32 *r32 = (const u32 *)ring;
+	u32 o = pos & RMASK, i = o >> 2;
+	return __builtin_amdgcn_alignbyte(r32[i + 1], r32[i], o & 3);
 }
 
 static __device__ __forceinline__ u64 ld64(const u8 *ring, u32 pos)
 {
-	u64 v;
-	__builtin_memcpy(&v, ring + (pos & RMASK), 8);
-	return v;
+	const u32 *r32 = (const u32 *)ring;
+	u32 o = pos & RMASK, i = o >> 2;
+	u32 a = r32[i], b = r32[i + 1], c = r32[i + 2];
+	u32 lo = __builtin_amdgcn_alignbyte(b, a, o & 3);
+	u32 hi = __builtin_amdgcn_alignbyte(c, b, o & 3);
+	return ((u64)hi << 32) | lo;
 }
 
 static __device__ __forceinline__ u32 hash4(u32 w)
@@ -173,6 +188,37 @@ dist_code(u32 dist, u32 *slot, u32 *xbits, u32 *xval)
 		*slot = 2 * hb + ((d >> (hb - 1)) & 1);
 		*xval = d & ((1u << (hb - 1)) - 1);
 	}
+}
+
+/*
+ * How far the parse advances from a position whose best matches (len |
+ * dist << 16; 0 = none) at p, p+1, p+2 are m0, m1, m2:
+ *   1 = literal, 2 = two literals (lazy2 deferral), else the match length.
+ * Greedy / lazy / lazy2 rules: lib/deflate_compress.c:2573-2575, 2681,
+ * 2712-2725, 2742-2755.
+ */
+static __device__ __forceinline__ u32
+token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
+{
+	u32 l0 = m0 & 0xFFFF;
+
+	if (l0 == 0)
+		return 1;
+	if (mode >= 1 && l0 < nice) {
+		s32 b0 = 31 - __builtin_clz(m0 >> 16);
+		u32 l1 = m1 & 0xFFFF;
+		if (l1 >= l0 &&
+		    4 * (s32)(l1 - l0) + (b0 - (s32)(31 - __builtin_clz(m1 >> 16))) > 2)
+			return 1;
+		if (mode >= 2) {
+			u32 l2 = m2 & 0xFFFF;
+			if (l2 >= l0 &&
+			    4 * (s32)(l2 - l0) +
+			    (b0 - (s32)(31 - __builtin_clz(m2 >> 16))) > 6)
+				return 2;
+		}
+	}
+	return l0;
 }
 
 /* ---------------- Huffman code construction (wave 0) ---------------- */
@@ -442,6 +488,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
 	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	PROF_DECL;
 
 	for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
 		const u8 *inp = in_base + in_offsets[c];
@@ -465,6 +512,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 
 		/* ---- per-buffer init ---- */
 		__syncthreads();
+		PROF_START();
 		for (u32 i = tid; i < (1u << HASH_BITS) / 2; i += NT)
 			((u32 *)L->head)[i] = 0x80008000u;
 		for (u32 i = tid; i < 320; i += NT)
@@ -522,6 +570,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			const u32 tend = t + TILE < n ? t + TILE : n;
 			const bool last_tile = tile + 1 == num_tiles;
 
+			PROF_MARK(0);
 			/* ---- S0: stage input up to tend + LOOKAHEAD ---- */
 			u32 want = tend + LOOKAHEAD < n ? tend + LOOKAHEAD : n;
 			if (aligned_in) {
@@ -543,8 +592,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			loaded = want;
 			for (u32 i = tid; i < TILE + 8; i += NT)
 				L->mark[i] = 0;
+			if (tid < 4)
+				L->M[TILE + 4 + tid] = 0;
 			__syncthreads();
 
+			PROF_MARK(1);
 			if (!stored_only) {
 				/* ---- S1: hash + in-wave sort -> local links ---- */
 #pragma unroll
@@ -584,6 +636,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				}
 				__syncthreads();
 
+				PROF_MARK(2);
 				/* ---- S2: thread groups through head[] in order ---- */
 				if (wave == 0) {
 					u32 ngroups = (tend - t + 63) / 64;
@@ -602,7 +655,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				}
 				__syncthreads();
 
-				/* ---- S3: all positions search their chain ---- */
+				PROF_MARK(3);
+				/* ---- S3: all positions search their chain ----
+				 * the candidate's first 4 bytes and its chain link are
+				 * fetched together: one LDS round trip per step */
 				{
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					u32 lo_pos = lo > 0 ? (u32)lo : 0;
@@ -622,31 +678,33 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								if (d <= dprev || d > dmax)
 									break;
 								u32 cp = p - d;
-								if (ld32(L->in, cp) == cur &&
-								    (best < 4 || best >= maxlen ||
-								     L->in[(cp + best) & RMASK] ==
-								     L->in[(p + best) & RMASK])) {
-									u32 len = 4;
-									while (len < maxlen) {
-										u64 x = ld64(L->in, p + len) ^
-											ld64(L->in, cp + len);
-										if (x) {
-											len += (u32)__builtin_ctzll(x) >> 3;
-											break;
-										}
-										len += 8;
-									}
-									if (len > maxlen)
-										len = maxlen;
-									if (len > best) {
-										best = len;
-										bestd = d;
-										if (len >= nice_l)
-											break;
-									}
-								}
-								dprev = d;
+								u32 w = ld32(L->in, cp);
 								c16 = L->prev[cp & RMASK];
+								dprev = d;
+								if (w != cur)
+									continue;
+								if (best >= 4 && best < maxlen &&
+								    L->in[(cp + best) & RMASK] !=
+								    L->in[(p + best) & RMASK])
+									continue;
+								u32 len = 4;
+								while (len < maxlen) {
+									u64 x = ld64(L->in, p + len) ^
+										ld64(L->in, cp + len);
+									if (x) {
+										len += (u32)__builtin_ctzll(x) >> 3;
+										break;
+									}
+									len += 8;
+								}
+								if (len > maxlen)
+									len = maxlen;
+								if (len > best) {
+									best = len;
+									bestd = d;
+									if (len >= nice_l)
+										break;
+								}
 							}
 							if (best >= 4)
 								res = best | (bestd << 16);
@@ -656,59 +714,101 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				}
 				__syncthreads();
 
-				/* ---- S4: token choice, one lane hops through the tile ---- */
-				if (tid == 0) {
-					s32 p = (s32)L->vars[V_ENTRY];	/* tile-relative */
-					s32 limit = last_tile ? (s32)(tend - t) :
-							(s32)TILE - 2;
-					u32 nseq = L->vars[V_NSEQ];
-					while (p < limit) {
-						u32 m0 = L->M[4 + p];
-						u32 m1 = L->M[4 + p + 1];
-						u32 m2 = L->M[4 + p + 2];
-						u32 l0 = m0 & 0xFFFF;
-						if (l0 == 0) {
-							L->mark[4 + p] = 1;
-							p++;
-							continue;
-						}
-						u32 d0 = m0 >> 16;
-						if (mode >= 1 && l0 < nice) {
-							u32 l1 = m1 & 0xFFFF, d1 = m1 >> 16;
-							if (l1 >= l0 &&
-							    4 * (s32)(l1 - l0) +
-							    ((s32)(31 - __builtin_clz(d0)) -
-							     (s32)(31 - __builtin_clz(d1))) > 2) {
-								L->mark[4 + p] = 1;
-								p++;
-								continue;
-							}
-							if (mode >= 2) {
-								u32 l2 = m2 & 0xFFFF, d2 = m2 >> 16;
-								if (l2 >= l0 &&
-								    4 * (s32)(l2 - l0) +
-								    ((s32)(31 - __builtin_clz(d0)) -
-								     (s32)(31 - __builtin_clz(d2))) > 6) {
-									L->mark[4 + p] = 1;
-									L->mark[4 + p + 1] = 1;
-									p += 2;
-									continue;
-								}
-							}
-						}
-						L->seq_pl[nseq] = (u32)((s32)t + p - (s32)block_start) |
-								  (l0 << 16);
-						L->seq_d[nseq] = (u16)d0;
-						nseq++;
-						p += (s32)l0;
+				PROF_MARK(4);
+				/* ---- S4: token choice by pointer jumping ----
+				 * step(p) is a pure function of M[p..p+2]; the chosen
+				 * tokens are the positions reachable from the entry point
+				 * by p -> p + step(p).  log2(TILE) doubling rounds mark
+				 * them all; idx = p + 4. */
+				{
+					const s32 entry = (s32)L->vars[V_ENTRY];
+					const s32 limit = last_tile ? (s32)(tend - t) :
+							  (s32)TILE - 2;
+					u16 *J = L->nxtA, *Jn = L->nxtB;
+					for (s32 idx = (s32)tid; idx < (s32)TILE + 4; idx += NT) {
+						s32 p = idx - 4;
+						u32 nx = (u32)(p < 0 ? 0 : p);
+						if (p >= -2 && p < limit)
+							nx = (u32)p + token_step(L->M[idx], L->M[idx + 1],
+										 L->M[idx + 2], mode, nice);
+						J[idx] = (u16)(nx + 4);	/* stored as idx */
 					}
-					L->vars[V_TMP0] = L->vars[V_NSEQ];	/* first new seq */
-					L->vars[V_NSEQ] = nseq;
-					L->vars[V_WALKPOS_LO] = (u32)((s32)t + p);
-					L->vars[V_ENTRY] = (u32)(p - (s32)TILE);
+					if (tid == 0 && entry < limit)
+						L->mark[entry + 4] = 1;
+					__syncthreads();
+					const u32 lim_idx = (u32)(limit + 4);
+					u32 span = (u32)(limit - entry > 0 ? limit - entry : 0);
+					for (u32 reachd = 1; reachd < span; reachd <<= 1) {
+						for (u32 idx = tid; idx < lim_idx; idx += NT) {
+							if (L->mark[idx]) {
+								u32 q = J[idx];
+								if (q < lim_idx)
+									L->mark[q] = 1;
+							}
+						}
+						__syncthreads();
+						for (u32 idx = tid; idx < lim_idx; idx += NT) {
+							u32 q = J[idx];
+							Jn[idx] = q < lim_idx ? J[q] : (u16)q;
+						}
+						__syncthreads();
+						u16 *tmp = J; J = Jn; Jn = tmp;
+					}
+					/* emit: thread owns 4 consecutive idx (thread NT-1
+					 * also the last 4), in position order */
+					u32 kind[8], cnt = 0;
+					u32 nown = tid == NT - 1 ? 8 : 4;
+					for (u32 k = 0; k < nown; k++) {
+						u32 idx = tid * 4 + k;
+						kind[k] = 0;
+						if (idx < lim_idx && L->mark[idx]) {
+							u32 st = token_step(L->M[idx], L->M[idx + 1],
+									    L->M[idx + 2], mode, nice);
+							u32 l0 = L->M[idx] & 0xFFFF;
+							kind[k] = (st == l0 && l0) ? 3 : st;	/* 1,2 lits; 3 match */
+							cnt += kind[k] == 3;
+							if (idx + (kind[k] == 3 ? l0 : st) >= lim_idx) {
+								s32 np = (s32)idx - 4 + (s32)(kind[k] == 3 ? l0 : st);
+								L->vars[V_WALKPOS_LO] = (u32)((s32)t + np);
+								L->vars[V_ENTRY] = (u32)(np - (s32)TILE);
+							}
+						}
+					}
+					if (tid == 0 && entry >= limit) {
+						L->vars[V_WALKPOS_LO] = (u32)((s32)t + entry);
+						L->vars[V_ENTRY] = (u32)(entry - (s32)TILE);
+					}
+					u32 tot;
+					u32 base = block_scan(L, cnt, &tot) + L->vars[V_NSEQ];
+					for (u32 k = 0; k < nown; k++) {
+						u32 idx = tid * 4 + k;
+						if (kind[k] == 3) {
+							u32 m = L->M[idx];
+							L->seq_pl[base] = (u32)((s32)t + (s32)idx - 4 -
+										(s32)block_start) |
+									  ((m & 0xFFFF) << 16);
+							L->seq_d[base] = (u16)(m >> 16);
+							base++;
+						}
+						if (idx < lim_idx)
+							L->mark[idx] = 0;
+					}
+					__syncthreads();
+					for (u32 k = 0; k < nown; k++) {
+						u32 idx = tid * 4 + k;
+						if (kind[k] == 1 || kind[k] == 2)
+							L->mark[idx] = 1;
+						if (kind[k] == 2)
+							L->mark[idx + 1] = 1;
+					}
+					if (tid == 0) {
+						L->vars[V_TMP0] = L->vars[V_NSEQ];	/* first new seq */
+						L->vars[V_NSEQ] += tot;
+					}
 				}
 				__syncthreads();
 				walkpos = L->vars[V_WALKPOS_LO];
+				PROF_MARK(5);
 
 				/* histogram of the tokens chosen in this tile */
 				{
@@ -737,6 +837,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			}
 			__syncthreads();
 
+			PROF_MARK(6);
 			/* ---- block end? ---- */
 			bool end_block = last_tile ||
 				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_CAP) ||
@@ -883,6 +984,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			if (overflow)
 				break;
 
+			PROF_MARK(7);
 			/* ---- S6: emit ---- */
 			stg_restore(L);
 			if (btype == 0) {
@@ -975,6 +1077,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				os.bits += L->vars[V_TMP0];
 				stg_flush(L, &os, false);
 
+				PROF_MARK(9);
 				/* tokens, EWIN positions at a time */
 				u32 *KD = L->M;
 				u32 seq_lo = 0;
@@ -1071,6 +1174,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			/* keep the unfinished staging bytes across the next tiles
 			 * (M is reused as tile scratch) */
 			stg_save(L, &os);
+			PROF_MARK(8);
 			for (u32 i = tid; i < 320; i += NT)
 				L->freq[i] = 0;
 			if (tid == 0)
@@ -1119,3 +1223,5 @@ extern "C" size_t lda_deflate_lds_bytes(void)
 {
 	return sizeof(struct deflate_lds);
 }
+
+LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate)

@@ -108,4 +108,33 @@ static __device__ __forceinline__ void wave_sync(void)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/*
+ * Optional phase profiling (make PROFILE=1 builds libdeflate_amd_prof.so):
+ * thread 0 of each workgroup accumulates s_memtime deltas per phase.
+ */
+#ifdef LDA_PROFILE
+#define LDA_PROF_SLOTS 24
+static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
+/* exported reader for this translation unit's counters (reads and resets) */
+#define LDA_PROF_DEFINE_READER(name)                                          \
+	extern "C" __attribute__((visibility("default"))) void name(           \
+		unsigned long long *out)                                      \
+	{                                                                     \
+		unsigned long long z[LDA_PROF_SLOTS] = { 0 };                 \
+		(void)hipDeviceSynchronize();                                 \
+		(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lda_prof), sizeof(z)); \
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(lda_prof), z, sizeof(z));  \
+	}
+#define PROF_DECL unsigned long long prof_t_ = 0
+#define PROF_START() do { if (threadIdx.x == 0) prof_t_ = __builtin_readcyclecounter(); } while (0)
+#define PROF_MARK(slot) do { if (threadIdx.x == 0) { \
+		unsigned long long n_ = __builtin_readcyclecounter(); \
+		atomicAdd(&lda_prof[slot], n_ - prof_t_); prof_t_ = n_; } } while (0)
+#else
+#define PROF_DECL
+#define PROF_START() do { } while (0)
+#define PROF_MARK(slot) do { } while (0)
+#define LDA_PROF_DEFINE_READER(name)
+#endif
+
 #endif /* LDA_DEVICE_COMMON_H */

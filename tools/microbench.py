@@ -42,6 +42,8 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--chunks", type=int, default=16384)
     ap.add_argument("--size", type=int, default=65536)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--level", type=int, default=6)
     a = ap.parse_args()
     chunks, data, offs, nb = make_batch(a.chunks, a.size, 0x0E110003)
     total = a.chunks * a.size
@@ -54,6 +56,8 @@ def main():
             print(f"{kind}: {total/t/1e9:.1f} GB/s  ({t*1e3:.3f} ms for {total/2**20:.0f} MiB)")
     if a.what in ("inflate", "all"):
         bench_inflate(a)
+    if a.what in ("deflate", "all"):
+        bench_deflate(a, level=a.level)
 
 
 def bench_inflate(a, fmt="gzip", level=6):
@@ -85,6 +89,50 @@ def bench_inflate(a, fmt="gzip", level=6):
     C = sum(sizes)
     print(f"inflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic {(U+C)/t/1e9:.2f} GB/s, "
           f"{t*1e3:.2f} ms, ratio {C/U:.3f}, ok {ok}/{a.chunks}")
+
+
+PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
+                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header"]
+
+
+def read_profile(name, labels):
+    import ctypes
+    from libdeflate_amd import binding
+    lib = binding.load()
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        return
+    buf = (ctypes.c_ulonglong * 24)()
+    fn(buf)
+    tot = sum(buf)
+    if not tot:
+        return
+    print("  phase cycles (thread 0 of each workgroup, summed):")
+    for i, v in enumerate(buf):
+        if v:
+            lab = labels[i] if i < len(labels) else f"slot{i}"
+            print(f"    {lab:16s} {v/1e6:12.1f} Mcyc  {100*v/tot:5.1f}%")
+
+
+def bench_deflate(a, fmt="gzip", level=6):
+    chunks, data, offs, nb = make_batch(a.chunks, a.size, 0x0E110003)
+    n = a.chunks
+    c = api.Compressor(level)
+    bound = (c.bound(fmt, a.size) + 15) // 16 * 16
+    comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+    c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
+    c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
+    c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
+    f = lambda: c.compress_batch(fmt, data, offs, nb, comp, c_off, c_av, c_n)
+    f(); torch.cuda.synchronize()
+    read_profile("libdeflate_amd_profile_read_deflate", PHASES_DEFLATE)  # reset
+    t = timeit(f, iters=a.iters, warmup=0)
+    U = n * a.size
+    C = int(c_n.sum())
+    print(f"deflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic "
+          f"{(U+C)/t/1e9:.2f} GB/s, {t*1e3:.2f} ms, ratio {C/U:.4f}")
+    read_profile("libdeflate_amd_profile_read_deflate", PHASES_DEFLATE)
 
 
 if __name__ == "__main__":
