@@ -49,8 +49,8 @@
 #include "device_common.h"
 #include "kernels.h"
 
-#define NT 512
-#define NWAVES 8
+#define NT LDA_DEFLATE_THREADS
+#define NWAVES (NT / 64)
 #define TILE 2048
 #define RING 32768u
 #define RMASK (RING - 1)
@@ -96,7 +96,7 @@ struct deflate_lds {
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3
+	V_TMP2, V_TMP3, V_CTR
 };
 
 struct level_params {
@@ -638,6 +638,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 
 				PROF_MARK(2);
 				/* ---- S2: thread groups through head[] in order ---- */
+				if (tid == NT - 1)
+					L->vars[V_CTR] = 0;
 				if (wave == 0) {
 					u32 ngroups = (tend - t + 63) / 64;
 					for (u32 g = 0; g < ngroups; g++) {
@@ -657,36 +659,47 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 
 				PROF_MARK(3);
 				/* ---- S3: all positions search their chain ----
-				 * the candidate's first 4 bytes and its chain link are
-				 * fetched together: one LDS round trip per step */
+				 * Chain lengths differ wildly between positions, so the
+				 * lanes do not own fixed positions: a lane claims the next
+				 * unsearched position from a workgroup counter as soon as
+				 * it finishes one (the claim and the position's first
+				 * loads are issued one position ahead, off the critical
+				 * path).  Every loop iteration is one chain step for every
+				 * lane that has work. */
 				{
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
-					u32 lo_pos = lo > 0 ? (u32)lo : 0;
-					for (u32 i = tid; i < TILE; i += NT) {
-						u32 p = t + i;
-						u32 res = 0;
-						if (p + 4 <= n) {
-							u32 maxlen = n - p < 258 ? n - p : 258;
-							u32 nice_l = nice < maxlen ? nice : maxlen;
-							u32 cur = ld32(L->in, p);
-							u32 best = 3, bestd = 0;
-							u32 dmax = p - lo_pos;
-							u32 dprev = 0;
-							u32 c16 = L->prev[p & RMASK];
-							for (u32 dep = depth; dep; dep--) {
-								u32 d = (p - c16) & 0xFFFF;
-								if (d <= dprev || d > dmax)
-									break;
-								u32 cp = p - d;
-								u32 w = ld32(L->in, cp);
-								c16 = L->prev[cp & RMASK];
-								dprev = d;
-								if (w != cur)
-									continue;
-								if (best >= 4 && best < maxlen &&
-								    L->in[(cp + best) & RMASK] !=
-								    L->in[(p + best) & RMASK])
-									continue;
+					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
+					u32 my_i = atomicAdd(&L->vars[V_CTR], 1u);
+					u32 nx_i = atomicAdd(&L->vars[V_CTR], 1u);
+					u32 p = t + my_i;
+					u32 cur = 0, c16 = 0, ncur = 0, nc16 = 0;
+					if (my_i < TILE) {
+						cur = ld32(L->in, p);
+						c16 = L->prev[p & RMASK];
+					}
+					if (nx_i < TILE) {
+						ncur = ld32(L->in, t + nx_i);
+						nc16 = L->prev[(t + nx_i) & RMASK];
+					}
+					bool have = my_i < TILE;
+					u32 maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
+					u32 dep = p + 4 <= n ? depth : 0;
+					u32 best = 3, bestd = 0, dprev = 0;
+					while (__ballot(have)) {
+						if (!have)
+							continue;
+						u32 d = (p - c16) & 0xFFFF;
+						bool stop = !(dep && d > dprev && d <= p - lo_pos);
+						if (!stop) {
+							u32 cp = p - d;
+							u32 w = ld32(L->in, cp);
+							c16 = L->prev[cp & RMASK];
+							dprev = d;
+							dep--;
+							if (w == cur &&
+							    !(best >= 4 && best < maxlen &&
+							      L->in[(cp + best) & RMASK] !=
+							      L->in[(p + best) & RMASK])) {
 								u32 len = 4;
 								while (len < maxlen) {
 									u64 x = ld64(L->in, p + len) ^
@@ -702,14 +715,31 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								if (len > best) {
 									best = len;
 									bestd = d;
-									if (len >= nice_l)
-										break;
+									if (len >= nice || len >= maxlen)
+										stop = true;
 								}
 							}
-							if (best >= 4)
-								res = best | (bestd << 16);
 						}
-						L->M[4 + i] = res;
+						if (stop) {
+							L->M[4 + my_i] = best >= 4 ? (best | (bestd << 16)) : 0;
+							my_i = nx_i;
+							have = my_i < TILE;
+							if (have) {
+								p = t + my_i;
+								cur = ncur;
+								c16 = nc16;
+								maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
+								dep = p + 4 <= n ? depth : 0;
+								best = 3;
+								bestd = 0;
+								dprev = 0;
+								nx_i = atomicAdd(&L->vars[V_CTR], 1u);
+								if (nx_i < TILE) {
+									ncur = ld32(L->in, t + nx_i);
+									nc16 = L->prev[(t + nx_i) & RMASK];
+								}
+							}
+						}
 					}
 				}
 				__syncthreads();
@@ -754,12 +784,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						__syncthreads();
 						u16 *tmp = J; J = Jn; Jn = tmp;
 					}
-					/* emit: thread owns 4 consecutive idx (thread NT-1
+					/* emit: thread owns OWN consecutive idx (thread NT-1
 					 * also the last 4), in position order */
-					u32 kind[8], cnt = 0;
-					u32 nown = tid == NT - 1 ? 8 : 4;
+					enum { OWN = TILE / NT };
+					u32 kind[OWN + 4], cnt = 0;
+					u32 nown = tid == NT - 1 ? OWN + 4 : OWN;
 					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * 4 + k;
+						u32 idx = tid * OWN + k;
 						kind[k] = 0;
 						if (idx < lim_idx && L->mark[idx]) {
 							u32 st = token_step(L->M[idx], L->M[idx + 1],
@@ -781,7 +812,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 tot;
 					u32 base = block_scan(L, cnt, &tot) + L->vars[V_NSEQ];
 					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * 4 + k;
+						u32 idx = tid * OWN + k;
 						if (kind[k] == 3) {
 							u32 m = L->M[idx];
 							L->seq_pl[base] = (u32)((s32)t + (s32)idx - 4 -
@@ -795,7 +826,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					}
 					__syncthreads();
 					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * 4 + k;
+						u32 idx = tid * OWN + k;
 						if (kind[k] == 1 || kind[k] == 2)
 							L->mark[idx] = 1;
 						if (kind[k] == 2)
@@ -1119,12 +1150,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						seq_hi = seq_lo + tot;
 					}
 					__syncthreads();
-					/* each thread: 2 consecutive positions */
-					u64 code[2];
-					u32 nb[2];
+					/* each thread: EPT consecutive positions */
+					enum { EPT = (EWIN + NT - 1) / NT };
+					u64 code[EPT];
+					u32 nb[EPT];
 #pragma unroll
-					for (u32 k = 0; k < 2; k++) {
-						u32 q = tid * 2 + k;
+					for (u32 k = 0; k < EPT; k++) {
+						u32 q = tid * EPT + k;
 						u32 pos = w0 + q;
 						code[k] = 0;
 						nb[k] = 0;
@@ -1156,10 +1188,16 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							nb[k] = sh;
 						}
 					}
-					u32 tot;
-					u32 off = block_scan(L, nb[0] + nb[1], &tot);
-					stg_put(L, &os, os.bits + off, code[0], nb[0]);
-					stg_put(L, &os, os.bits + off + nb[0], code[1], nb[1]);
+					u32 tot, mine = 0;
+#pragma unroll
+					for (u32 k = 0; k < EPT; k++)
+						mine += nb[k];
+					u32 off = block_scan(L, mine, &tot);
+#pragma unroll
+					for (u32 k = 0; k < EPT; k++) {
+						stg_put(L, &os, os.bits + off, code[k], nb[k]);
+						off += nb[k];
+					}
 					os.bits += tot;
 					seq_lo = seq_hi;
 					stg_flush(L, &os, false);

@@ -161,7 +161,7 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
 	const level_cfg &lv = k_levels[c->level];
 	size_t grid = n < (size_t)ctx->num_cus ? n : (size_t)ctx->num_cus;
 	hipLaunchKernelGGL(lda_deflate_batch_kernel, dim3((unsigned)grid),
-			   dim3(512), lds, st, (uint64_t)n, format, c->level,
+			   dim3(LDA_DEFLATE_THREADS), lds, st, (uint64_t)n, format, c->level,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
 			   d_out_offsets, d_out_avail, d_out_nbytes, sums);

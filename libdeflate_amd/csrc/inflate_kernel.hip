@@ -337,6 +337,8 @@ lda_inflate_batch_kernel(u64 n_chunks, int format,
 	struct inflate_lds *L = &Ls;
 	const u32 lane = threadIdx.x;
 	const u64 c = blockIdx.x;
+	PROF_DECL;
+	PROF_START();
 
 	if (c >= n_chunks)
 		return;
@@ -594,9 +596,11 @@ lda_inflate_batch_kernel(u64 n_chunks, int format,
 			break;
 		}
 
+		PROF_MARK(0);	/* header + tables */
 		/* ---------------- token batches ---------------- */
 		u32 eob = 0;
 		while (!eob) {
+			PROF_MARK(3);
 			ensure_input(L, &in, bcast64(br.vpos), lane);
 			if (out_pos - flushed > WSIZE - OUT_CAP) {
 				flush_window(L, outp, flushed, out_pos, lane);
@@ -605,6 +609,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format,
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			}
+			PROF_MARK(1);	/* input staging + flush */
 			u32 ntok = 0, berr = 0, produced = 0;
 			if (lane == 0) {
 				u64 opos = out_pos;
@@ -671,6 +676,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format,
 			}
 			wave_sync();
 
+			PROF_MARK(2);	/* serial decode */
 			/* ---- apply the batch with all lanes ---- */
 			u32 t = lane < ntok ? L->tok[lane] : 0;
 			u32 dist = t & 0xFFFF;
@@ -798,3 +804,5 @@ lda_inflate_finalize_kernel(u64 n_chunks, int format, int exact_fill,
 		actual_in[c] += 8;
 	}
 }
+
+LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_inflate)

@@ -34,6 +34,7 @@ lda_inflate_finalize_kernel(uint64_t n_chunks, int format, int exact_fill,
 			    uint64_t *actual_out);
 
 /* deflate_kernel.hip */
+#define LDA_DEFLATE_THREADS 1024	/* one workgroup (16 waves) per buffer */
 extern "C" __global__ void
 lda_deflate_batch_kernel(uint64_t n_chunks, int format, int level,
 			 uint32_t depth, uint32_t nice, uint32_t mode,

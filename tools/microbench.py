@@ -60,6 +60,30 @@ def main():
         bench_deflate(a, level=a.level)
 
 
+PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
+                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header"]
+
+
+def read_profile(name, labels):
+    import ctypes
+    from libdeflate_amd import binding
+    lib = binding.load()
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        return
+    buf = (ctypes.c_ulonglong * 24)()
+    fn(buf)
+    tot = sum(buf)
+    if not tot:
+        return
+    print("  phase cycles (thread 0 of each workgroup, summed):")
+    for i, v in enumerate(buf):
+        if v:
+            lab = labels[i] if i < len(labels) else f"slot{i}"
+            print(f"    {lab:16s} {v/1e6:12.1f} Mcyc  {100*v/tot:5.1f}%")
+
+
 def bench_inflate(a, fmt="gzip", level=6):
     from tests import oracle_util, streams
     ref = oracle_util.load_ref()
@@ -87,32 +111,10 @@ def bench_inflate(a, fmt="gzip", level=6):
     ok = int((res == 0).sum())
     U = a.chunks * a.size
     C = sum(sizes)
+    read_profile("libdeflate_amd_profile_read_inflate",
+                 ["hdr+tables", "stage+flush", "decode(lane0)", "apply"])
     print(f"inflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic {(U+C)/t/1e9:.2f} GB/s, "
           f"{t*1e3:.2f} ms, ratio {C/U:.3f}, ok {ok}/{a.chunks}")
-
-
-PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
-                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header"]
-
-
-def read_profile(name, labels):
-    import ctypes
-    from libdeflate_amd import binding
-    lib = binding.load()
-    try:
-        fn = getattr(lib, name)
-    except AttributeError:
-        return
-    buf = (ctypes.c_ulonglong * 24)()
-    fn(buf)
-    tot = sum(buf)
-    if not tot:
-        return
-    print("  phase cycles (thread 0 of each workgroup, summed):")
-    for i, v in enumerate(buf):
-        if v:
-            lab = labels[i] if i < len(labels) else f"slot{i}"
-            print(f"    {lab:16s} {v/1e6:12.1f} Mcyc  {100*v/tot:5.1f}%")
 
 
 def bench_deflate(a, fmt="gzip", level=6):
