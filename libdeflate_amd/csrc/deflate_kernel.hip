@@ -226,7 +226,8 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 /*
  * Length-limited canonical code for freq[0..n) -> lens[], codes[] (codewords
  * bit-reversed, ready for LSB-first output).  Called by ONE wave.
- *   - rank sort by (freq, sym) with all lanes;
+ *   - rank sort by (freq, sym): by the whole workgroup beforehand
+ *     (presorted) or by this wave;
  *   - optimal tree by the in-place two-queue method on lane 0;
  *   - depth clamp with Kraft repair (what lib/deflate_compress.c:1022-1091
  *     achieves with its length-count shuffle);
@@ -234,31 +235,30 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
  *     (lib/deflate_compress.c:1369-1378).
  */
 static __device__ void
-make_code(struct deflate_lds *L, const u32 *freq, u32 n, u32 maxlen,
-	  u8 *lens, u16 *codes, u32 lane)
+make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
+	  u16 *sorted, u32 *A, u32 used, bool presorted, u32 lane)
 {
-	u16 *sorted = L->sorted;
-	u32 *A = L->hw;
-
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
-	/* rank sort of used symbols */
-	u32 used = 0;
-	for (u32 s0 = 0; s0 < n; s0 += 64) {
-		u32 s = s0 + lane;
-		u32 f = s < n ? freq[s] : 0;
-		used += __builtin_popcountll(__ballot(f != 0));
-	}
-	for (u32 s = lane; s < n; s += 64) {
-		u32 f = freq[s];
-		if (!f)
-			continue;
-		u32 key = (f << 9) | s, rank = 0;	/* freq < 2^22 */
-		for (u32 t = 0; t < n; t++) {
-			u32 ft = freq[t];
-			rank += (ft != 0) & (((ft << 9) | t) < key);
+	if (!presorted) {
+		/* rank sort of the used symbols by (freq, sym), one wave */
+		used = 0;
+		for (u32 s0 = 0; s0 < n; s0 += 64) {
+			u32 s = s0 + lane;
+			u32 f = s < n ? freq[s] : 0;
+			used += __builtin_popcountll(__ballot(f != 0));
 		}
-		sorted[rank] = (u16)s;
+		for (u32 s = lane; s < n; s += 64) {
+			u32 f = freq[s];
+			if (!f)
+				continue;
+			u32 key = (f << 9) | s, rank = 0;	/* freq < 2^22 */
+			for (u32 t = 0; t < n; t++) {
+				u32 ft = freq[t];
+				rank += (ft != 0) & (((ft << 9) | t) < key);
+			}
+			sorted[rank] = (u16)s;
+		}
 	}
 	wave_sync();
 	if (used < 2) {
@@ -887,10 +887,56 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				if (tid == 0)
 					L->freq[256]++;
 				__syncthreads();
-				if (wave == 0) {
-					make_code(L, L->freq, 288, 15, L->lens, L->codes, lane);
-					make_code(L, L->freq + 288, 32, 15, L->lens + 288,
-						  L->codes + 288, lane);
+				/* rank sort of both alphabets by the whole workgroup:
+				 * thread (s, part) counts the keys below key(s) in one
+				 * third of the litlen alphabet; M[] is free scratch here */
+				{
+					u32 *rk = L->M;			/* [320] ranks */
+					u32 *usedv = L->M + 320;	/* [2] used counts */
+					u16 *sortedO = (u16 *)(L->M + 324);	/* [32] */
+					for (u32 i = tid; i < 324; i += NT)
+						L->M[i] = 0;
+					__syncthreads();
+					if (tid < 864) {
+						u32 sidx = tid / 3, part = tid % 3;
+						u32 f = L->freq[sidx];
+						if (f) {
+							u32 key = (f << 9) | sidx, r = 0;
+							for (u32 q = part * 96; q < part * 96 + 96; q++) {
+								u32 ft = L->freq[q];
+								r += (ft != 0) & (((ft << 9) | q) < key);
+							}
+							atomicAdd(&rk[sidx], r);
+							if (part == 0)
+								atomicAdd(&usedv[0], 1u);
+						}
+					} else if (tid < 896) {
+						u32 sidx = tid - 864;
+						u32 f = L->freq[288 + sidx];
+						if (f) {
+							u32 key = (f << 9) | sidx, r = 0;
+							for (u32 q = 0; q < 32; q++) {
+								u32 ft = L->freq[288 + q];
+								r += (ft != 0) & (((ft << 9) | q) < key);
+							}
+							rk[288 + sidx] = r;
+							atomicAdd(&usedv[1], 1u);
+						}
+					}
+					__syncthreads();
+					if (tid < 288 && L->freq[tid])
+						L->sorted[rk[tid]] = (u16)tid;
+					else if (tid >= 288 && tid < 320 && L->freq[tid])
+						sortedO[rk[tid]] = (u16)(tid - 288);
+					__syncthreads();
+					/* the two trees are built side by side on two waves */
+					if (wave == 0)
+						make_code(L->freq, 288, 15, L->lens, L->codes,
+							  L->sorted, L->hw, usedv[0], true, lane);
+					else if (wave == 1)
+						make_code(L->freq + 288, 32, 15, L->lens + 288,
+							  L->codes + 288, sortedO, L->M + 360,
+							  usedv[1], true, lane);
 				}
 				__syncthreads();
 				if (tid == 0) {
@@ -952,8 +998,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				}
 				__syncthreads();
 				if (wave == 0)
-					make_code(L, L->pre_freq, 19, 7, L->pre_lens,
-						  L->pre_codes, lane);
+					make_code(L->pre_freq, 19, 7, L->pre_lens, L->pre_codes,
+						  L->sorted, L->hw, 0, false, lane);
 				__syncthreads();
 				/* exact costs (deflate_compress.c:1747-1808) */
 				u32 dyn = 0, stat = 0;
