@@ -152,8 +152,32 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 			 (uint64_t *)(s + sums_bytes + 8 * n);
 	int exact_fill = d_actual_out == NULL;
 
-	hipLaunchKernelGGL(lda_inflate_batch_kernel, dim3((unsigned)n), dim3(64),
-			   0, st, (uint64_t)n, format, (const uint8_t *)d_in,
+	/* streams per wave: a stream's decode is one serial dependence chain, so
+	 * per-stream speed is best with few streams per wave (less waiting for
+	 * the slowest lane, fewer divergent paths); lpw only grows once the
+	 * batch no longer fits in flight (measured best: 2 at 4096 streams, 8 at
+	 * 65536 on 256 CUs) */
+	uint32_t lpw = 2;
+	while (lpw < 64 && (size_t)lpw * 32 * (size_t)c->num_cus < n)
+		lpw <<= 1;
+	if (const char *e = getenv("LDA_INFLATE_LPW")) {	/* tuning aid */
+		int v = atoi(e);
+		if (v >= 1 && v <= 64)
+			lpw = (uint32_t)v;
+	}
+	size_t lds = lda_inflate_lds_per_stream() * lpw;
+	static bool attr_set[16];
+	if (!attr_set[c->device]) {
+		LDA_HIP_TRY(hipFuncSetAttribute(
+				(const void *)lda_inflate_batch_kernel,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)(lda_inflate_lds_per_stream() * 64)),
+			    LIBDEFLATE_AMD_NO_DEVICE);
+		attr_set[c->device] = true;
+	}
+	hipLaunchKernelGGL(lda_inflate_batch_kernel,
+			   dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64),
+			   lds, st, (uint64_t)n, format, lpw, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
 			   d_out_offsets, d_out_avail, d_results, ain, aout);
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);

@@ -10,22 +10,27 @@
  * (footer verification runs in lda_inflate_finalize_kernel after the batched
  * checksum kernel.)
  *
- * Mapping: ONE 64-lane wavefront per stream, one wave per workgroup.
+ * Huffman decoding is a serial dependence chain per stream (the next symbol
+ * starts where this one ends), so a stream can keep exactly one lane busy
+ * with entropy decoding - measured: a wave that gives all 64 lanes to one
+ * stream spends >90 % of its issue slots with 63 lanes masked off.  Mapping
+ * used here: ONE LANE PER STREAM.  A wave carries `lpw` streams (lanes
+ * 0..lpw-1); every wave instruction advances all of them:
  *
- *   - the compressed bytes are staged through a 2 KiB LDS ring, filled 1 KiB
- *     at a time with coalesced, 16-byte-aligned loads by all 64 lanes;
- *   - lane 0 is the entropy decoder: 64-bit bit buffer, one LDS table look-up
- *     per symbol (10-bit litlen table, 8-bit offset table, canonical
- *     bit-serial fallback for the rare longer codewords - no subtables);
- *     it emits up to 64 tokens {literal | (length, distance)} into LDS;
- *   - all 64 lanes then apply the batch: wave prefix-sum of token lengths
- *     gives every token its output position, literals are scattered in one
- *     step, matches are copied 64 bytes per step;
- *   - output goes through an LDS window ring (the most recent W bytes) that
- *     is drained to HBM in coalesced 16-byte stores; back-references that
- *     reach behind the window are read back from HBM (already drained);
- *   - decode tables are built by all lanes (each lane canonically decodes its
- *     own table indices), only the code-length run decoding is serial.
+ *   - per-stream state lives in registers (64-bit bit buffer, one 8-byte
+ *     word of input prefetched ahead, output cursor) and 2112 bytes of LDS
+ *     (9-bit litlen table, 7-bit offset table, 16-bit entries; canonical
+ *     first-code/count arrays for the rare longer codewords - no subtables);
+ *   - each round every lane decodes one token and writes it: literals are
+ *     byte stores, matches are copied by the lane itself with 8-byte
+ *     loads/stores from its own earlier output (same-lane program order makes
+ *     the read-after-write safe without fences);
+ *   - block headers are parsed by the lanes that need one, in lock step;
+ *     the litlen/offset tables of ONE stream are then built by ALL 64 lanes
+ *     (ballot-ranked counting sort of the code lengths, then each lane
+ *     canonically decodes its own table indices);
+ *   - the host picks lpw so that the whole batch is in flight at once with
+ *     about one wave per SIMD (lpw = 4 for 4096 streams, 64 for >= 65536).
  *
  * Result codes follow the reference bit for bit, including the implicit
  * zero-padding rule: the reference fails when a refill would need a 9th
@@ -36,293 +41,410 @@
 #include "device_common.h"
 #include "kernels.h"
 
-#define LIT_TB 10		/* litlen primary table bits */
-#define OFF_TB 8		/* offset primary table bits */
-#define IN_RING 2048u
-#define IN_HALF 1024u
-#define WBITS 13		/* output window ring: 8 KiB */
-#define WSIZE (1u << WBITS)
-#define WMASK (WSIZE - 1)
-#define OUT_CAP 2048u		/* max bytes one token batch may produce */
-#define BATCH 64
+#define LIT_TB 9
+#define OFF_TB 7
 
-/* table entry: [3:0] codeword len (0 = long codeword, use canonical path)
- *              [7:4] extra bits   [8] literal   [9] end of block
- *              [31:16] literal value / length base / offset base */
-#define E_LIT 0x100u
-#define E_EOB 0x200u
+/* 16-bit table entry: [3:0] codeword length (0 = longer than the table),
+ * [15:14] kind, [13:4] payload (literal byte / length index / offset index /
+ * precode symbol) */
+#define K_LIT (0u << 14)
+#define K_LEN (1u << 14)
+#define K_EOB (2u << 14)
+#define ENTRY(kind, payload, len) ((u16)((kind) | ((payload) << 4) | (len)))
 
-struct canon {
+struct canon16 {
 	u16 count[16];
-	u16 first[16];	/* first codeword of each length */
-	u16 index[16];	/* index into sorted[] of first symbol of each length */
+	u16 first[16];
+	u16 index[16];
 };
 
-struct inflate_lds {
-	u32 lit_tab[1 << LIT_TB];
-	u32 off_tab[1 << OFF_TB];
-	u32 pre_tab[128];
-	u32 tok[BATCH];
-	struct canon lit, off, pre;
+struct stream_lds {
+	union {
+		u16 lit_tab[1 << LIT_TB];
+		u8 lens[288 + 32 + 138 + 6];	/* during header parsing */
+	};
+	union {
+		u16 off_tab[1 << OFF_TB];
+		u16 pre_tab[128];		/* during header parsing */
+	};
+	struct canon16 lit, off;
 	u16 lit_sorted[288];
 	u16 off_sorted[32];
-	u16 pre_sorted[20];
-	u8 lens[288 + 32 + 138 + 6];
-	u8 pre_lens[20];
-	u8 in_ring[IN_RING + 16];
-	u8 win[WSIZE];
+	u8 in_ring[128 + 8];	/* this stream's next input bytes (+8 mirror) */
 };
 
-/* lib/deflate_decompress.c:555-588 (285..287 -> 258) and :615-628 */
-__constant__ u16 c_len_base[31] = {
-	3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51,
-	59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 258, 258 };
-__constant__ u8 c_len_extra[31] = {
-	0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
-	4, 5, 5, 5, 5, 0, 0, 0 };
-__constant__ u16 c_off_base[32] = {
-	1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385,
-	513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385,
-	24577, 24577, 24577 };
-__constant__ u8 c_off_extra[32] = {
-	0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10,
-	10, 11, 11, 12, 12, 13, 13, 13, 13 };
 __constant__ u8 c_pre_perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 				   12, 3, 13, 2, 14, 1, 15 };
 
-enum { KIND_LITLEN = 0, KIND_OFFSET = 1, KIND_PRECODE = 2 };
+enum { ST_HDR = 0, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
 
-static __device__ __forceinline__ u32 make_entry(int kind, u32 sym, u32 len)
+/* length / offset symbol -> base and extra-bit count, computed instead of
+ * looked up (values of lib/deflate_decompress.c:555-588, :615-628; symbols
+ * 286/287 and 30/31 alias their neighbours exactly as there) */
+static __device__ __forceinline__ void len_sym(u32 s, u32 *base, u32 *xb)
 {
-	if (kind == KIND_LITLEN) {
-		if (sym < 256)
-			return (sym << 16) | E_LIT | len;
-		if (sym == 256)
-			return E_EOB | len;
-		return ((u32)c_len_base[sym - 257] << 16) |
-		       ((u32)c_len_extra[sym - 257] << 4) | len;
+	if (s < 8) {
+		*base = 3 + s;
+		*xb = 0;
+	} else if (s >= 28) {
+		*base = 258;
+		*xb = 0;
+	} else {
+		u32 e = (s - 4) >> 2;
+		*xb = e;
+		*base = 3 + ((4 | (s & 3)) << e);
 	}
-	if (kind == KIND_OFFSET)
-		return ((u32)c_off_base[sym] << 16) |
-		       ((u32)c_off_extra[sym] << 4) | len;
-	return (sym << 16) | len;
+}
+
+static __device__ __forceinline__ void off_sym(u32 d, u32 *base, u32 *xb)
+{
+	if (d > 29)
+		d = 29;
+	if (d < 4) {
+		*base = 1 + d;
+		*xb = 0;
+	} else {
+		u32 e = (d - 2) >> 1;
+		*xb = e;
+		*base = 1 + ((2 | (d & 1)) << e);
+	}
 }
 
 /*
- * Build one decode table from lens[0..n).  Whole wave.  Returns false when
- * the code is invalid by the rules of lib/deflate_decompress.c:804-853.
- * Counting/sorting is done by lane 0 (<= 288 steps); the table itself is
- * filled by all lanes, each canonically decoding its own indices.
+ * 8 input bytes at stream position pos; bytes past the end read as zero.
+ * Two ALIGNED 8-byte loads and a funnel shift: an aligned word that contains
+ * at least one valid byte can always be read safely, and there is no
+ * per-byte tail loop in the instruction stream.
  */
-static __device__ bool
-build_table(int kind, const u8 *lens, u32 n, u32 tb, u32 *tab,
-	    struct canon *cn, u16 *sorted, u32 lane)
+static __device__ __forceinline__ u64 load_in(const u8 *inp, u64 in_n, u64 pos)
 {
-	u32 status = 0;	/* 0 ok-complete, 1 invalid, 2 incomplete(single) */
-	u32 single_entry = 0;
-
-	if (lane < 16)
-		cn->count[lane] = 0;
-	wave_sync();
-	if (lane == 0) {
-		u32 maxlen = (kind == KIND_PRECODE) ? 7 : 15;
-		u32 used = 0, idx = 0;
-
-		for (u32 s = 0; s < n; s++)
-			cn->count[lens[s]]++;
-		cn->count[0] = 0;
-		while (maxlen > 1 && cn->count[maxlen] == 0)
-			maxlen--;
-		u32 code = 0;
-		for (u32 l = 1; l <= 15; l++) {
-			u32 c = cn->count[l];
-			cn->first[l] = (u16)code;
-			cn->index[l] = (u16)idx;
-			code = (code + c) << 1;
-			idx += c;
-			if (l <= maxlen)
-				used = (used << 1) + c;
-		}
-		/* sorted[] by (len, sym): offsets via index[] copy */
-		u16 next[16];
-		for (u32 l = 1; l <= 15; l++)
-			next[l] = cn->index[l];
-		for (u32 s = 0; s < n; s++) {
-			u32 l = lens[s];
-			if (l)
-				sorted[next[l]++] = (u16)s;
-		}
-		if (used > (1u << maxlen)) {
-			status = 1;
-		} else if (used < (1u << maxlen)) {
-			u32 sym;
-			if (used == 0) {
-				sym = 0;
-				status = 2;
-			} else if (used != (1u << (maxlen - 1)) ||
-				   cn->count[1] != 1) {
-				status = 1;
-				sym = 0;
-			} else {
-				sym = sorted[0];
-				status = 2;
-			}
-			single_entry = make_entry(kind, sym, 1);
-		}
-	}
-	status = bcast_first(status);
-	single_entry = bcast_first(single_entry);
-	if (status == 1)
-		return false;
-	wave_sync();
-	if (status == 2) {
-		for (u32 e = lane; e < (1u << tb); e += 64)
-			tab[e] = single_entry;
-		wave_sync();
-		return true;
-	}
-	for (u32 e = lane; e < (1u << tb); e += 64) {
-		u32 code = 0, entry = 0;
-		for (u32 l = 1; l <= tb; l++) {
-			code = (code << 1) | ((e >> (l - 1)) & 1);
-			u32 rel = code - cn->first[l];
-			if (rel < cn->count[l]) {
-				entry = make_entry(kind, sorted[cn->index[l] + rel], l);
-				break;
-			}
-		}
-		tab[e] = entry;	/* 0 -> codeword longer than tb bits */
-	}
-	wave_sync();
-	return true;
+	if (pos >= in_n)
+		return 0;
+	uintptr_t a = (uintptr_t)(inp + pos);
+	const u64 *w = (const u64 *)(a & ~(uintptr_t)7);
+	u32 sh = (u32)(a & 7) * 8;
+	u64 avail = in_n - pos;		/* valid bytes from pos on */
+	u64 lo = w[0];
+	u64 v = lo >> sh;
+	/* the next word is needed (and valid) only if bytes beyond this one
+	 * are both wanted and inside the buffer */
+	if (sh && avail > 8 - (sh >> 3))
+		v |= w[1] << (64 - sh);
+	if (avail < 8)
+		v &= (1ull << (8 * avail)) - 1;
+	return v;
 }
 
 /* canonical bit-serial decode for codewords longer than the table */
-static __device__ __forceinline__ u32
-decode_long(int kind, const struct canon *cn, const u16 *sorted, u64 bits)
+static __device__ u32
+decode_long(const struct canon16 *cn, const u16 *sorted, u64 bits, u32 *len_ret)
 {
 	u32 code = 0;
 	for (u32 l = 1; l <= 15; l++) {
 		code = (code << 1) | (u32)((bits >> (l - 1)) & 1);
 		u32 rel = code - cn->first[l];
-		if (rel < cn->count[l])
-			return make_entry(kind, sorted[cn->index[l] + rel], l);
-	}
-	return E_EOB | 15;	/* unreachable for a complete code */
-}
-
-struct instream {
-	const u8 *base_al;	/* 16-byte aligned address at/below the stream */
-	u32 shift;		/* stream byte 0 is at base_al[shift] */
-	u64 n;			/* stream length in bytes */
-	s32 tag[2];		/* which 1 KiB block each ring half holds */
-};
-
-/* whole wave: make the ring hold 1 KiB block 'blk' of the virtual stream */
-static __device__ __forceinline__ void
-load_in_block(struct inflate_lds *L, struct instream *in, u32 blk, u32 lane)
-{
-	u32 slot = blk & 1;
-	u64 v = (u64)blk * IN_HALF + lane * 16;	/* virtual position */
-	u64 end = in->shift + in->n;		/* virtual end of stream */
-	uint4 w = make_uint4(0, 0, 0, 0);
-
-	if (v < end)
-		w = *(const uint4 *)(in->base_al + v);
-	if (v + 16 > end) {	/* zero the bytes past the end of the stream */
-		u32 keep = v < end ? (u32)(end - v) : 0;
-		u32 ww[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			u32 kb = keep > (u32)(4 * i) ? keep - 4 * i : 0;
-			if (kb < 4)
-				ww[i] &= kb ? (0xFFFFFFFFu >> (32 - 8 * kb)) : 0;
+		if (rel < cn->count[l]) {
+			*len_ret = l;
+			return sorted[cn->index[l] + rel];
 		}
-		w = make_uint4(ww[0], ww[1], ww[2], ww[3]);
 	}
-	*(uint4 *)&L->in_ring[slot * IN_HALF + lane * 16] = w;
-	if (slot == 0 && lane == 0)	/* mirror for reads that wrap */
-		*(uint4 *)&L->in_ring[IN_RING] = w;
-	in->tag[slot] = (s32)blk;
+	*len_ret = 15;	/* unreachable for a complete code */
+	return 256;
 }
 
-static __device__ __forceinline__ void
-ensure_input(struct inflate_lds *L, struct instream *in, u64 vpos, u32 lane)
+/*
+ * Per-lane (serial) build of the 7-bit precode table from 19 lengths.
+ * Validity rules of lib/deflate_decompress.c:804-853.  Returns false if the
+ * code is invalid.
+ */
+static __device__ bool build_precode(u16 *tab, const u8 *plens)
 {
-	u32 blk = (u32)(vpos / IN_HALF);
-	bool any = false;
-	if (in->tag[blk & 1] != (s32)blk) {
-		load_in_block(L, in, blk, lane);
-		any = true;
+	u32 cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	for (u32 s = 0; s < 19; s++)
+		cnt[plens[s]]++;
+	cnt[0] = 0;
+	u32 maxlen = 7;
+	while (maxlen > 1 && cnt[maxlen] == 0)
+		maxlen--;
+	u32 used = 0, next[8], code = 0;
+	for (u32 l = 1; l <= 7; l++) {
+		next[l] = code;
+		code = (code + cnt[l]) << 1;
+		if (l <= maxlen)
+			used = (used << 1) + cnt[l];
 	}
-	if (in->tag[(blk + 1) & 1] != (s32)(blk + 1)) {
-		load_in_block(L, in, blk + 1, lane);
-		any = true;
+	if (used > (1u << maxlen))
+		return false;
+	if (used < (1u << maxlen)) {
+		u32 sym = 0;
+		if (used != 0) {
+			if (used != (1u << (maxlen - 1)) || cnt[1] != 1)
+				return false;
+			for (u32 s = 0; s < 19; s++)
+				if (plens[s] == 1)
+					sym = s;
+		}
+		for (u32 i = 0; i < 128; i++)
+			tab[i] = ENTRY(0, sym, 1);
+		return true;
 	}
-	if (any)
-		wave_sync();
+	for (u32 s = 0; s < 19; s++) {
+		u32 l = plens[s];
+		if (!l)
+			continue;
+		u32 rev = __brev(next[l]++) >> (32 - l);
+		for (u32 i = rev; i < 128; i += 1u << l)
+			tab[i] = ENTRY(0, s, l);
+	}
+	return true;
 }
 
-static __device__ __forceinline__ u64 ring_load64(const struct inflate_lds *L,
-						  u64 vpos)
+/*
+ * Cooperative (all 64 lanes) build of one stream's litlen or offset table
+ * from lens[0..n).  Counting and the (len, sym) sort are done with ballots,
+ * then every lane canonically decodes its own table indices.  Returns false
+ * (uniformly) when the code is invalid.
+ */
+static __device__ bool
+build_table_coop(const u8 *lens, u32 n, u32 tb, bool is_litlen,
+		 struct canon16 *cn, u16 *sorted, u32 lane, u32 *single_ret)
+{
+	u32 c[16];
+#pragma unroll
+	for (u32 l = 0; l < 16; l++)
+		c[l] = 0;
+	for (u32 s0 = 0; s0 < n; s0 += 64) {
+		u32 s = s0 + lane;
+		u32 l = s < n ? lens[s] : 0;
+#pragma unroll
+		for (u32 L = 1; L < 16; L++)
+			c[L] += __builtin_popcountll(__ballot(l == L));
+	}
+	u32 maxlen = 15;
+	while (maxlen > 1 && c[maxlen] == 0)
+		maxlen--;
+	u32 used = 0, code = 0, idx = 0;
+	u32 first[16], index[16];
+#pragma unroll
+	for (u32 l = 1; l < 16; l++) {
+		first[l] = code;
+		index[l] = idx;
+		code = (code + c[l]) << 1;
+		idx += c[l];
+		if (l <= maxlen)
+			used = (used << 1) + c[l];
+	}
+	if (lane == 0) {
+#pragma unroll
+		for (u32 l = 1; l < 16; l++) {
+			cn->count[l] = (u16)c[l];
+			cn->first[l] = (u16)first[l];
+			cn->index[l] = (u16)index[l];
+		}
+	}
+	/* sorted[] by (len, sym) */
+	u32 run[16];
+#pragma unroll
+	for (u32 l = 1; l < 16; l++)
+		run[l] = index[l];
+	for (u32 s0 = 0; s0 < n; s0 += 64) {
+		u32 s = s0 + lane;
+		u32 l = s < n ? lens[s] : 0;
+#pragma unroll
+		for (u32 L = 1; L < 16; L++) {
+			u64 m = __ballot(l == L);
+			if (l == L)
+				sorted[run[L] + __builtin_popcountll(m & ((1ull << lane) - 1))] = (u16)s;
+			run[L] += __builtin_popcountll(m);
+		}
+	}
+	wave_sync();
+	*single_ret = 0xFFFFFFFFu;
+	if (used > (1u << maxlen))
+		return false;
+	if (used < (1u << maxlen)) {
+		if (used == 0) {
+			*single_ret = 0;
+		} else {
+			if (used != (1u << (maxlen - 1)) || c[1] != 1)
+				return false;
+			*single_ret = sorted[0];
+		}
+	}
+	(void)tb;
+	(void)is_litlen;
+	return true;
+}
+
+static __device__ __forceinline__ u16 lit_entry(u32 sym, u32 len)
+{
+	if (sym < 256)
+		return ENTRY(K_LIT, sym, len);
+	if (sym == 256)
+		return ENTRY(K_EOB, 0, len);
+	return ENTRY(K_LEN, sym - 257, len);
+}
+
+/* fill a table: each lane canonically decodes its own indices */
+static __device__ void
+fill_table(u16 *tab, u32 tb, bool is_litlen, const struct canon16 *cn,
+	   const u16 *sorted, u32 single, u32 lane)
+{
+	for (u32 e = lane; e < (1u << tb); e += 64) {
+		u16 entry = 0;
+		if (single != 0xFFFFFFFFu) {
+			entry = is_litlen ? lit_entry(single, 1) : ENTRY(0, single, 1);
+		} else {
+			u32 code = 0;
+			for (u32 l = 1; l <= tb; l++) {
+				code = (code << 1) | ((e >> (l - 1)) & 1);
+				u32 rel = code - cn->first[l];
+				if (rel < cn->count[l]) {
+					u32 sym = sorted[cn->index[l] + rel];
+					entry = is_litlen ? lit_entry(sym, l) : ENTRY(0, sym, l);
+					break;
+				}
+			}
+		}
+		tab[e] = entry;
+	}
+}
+
+/*
+ * Copy a match inside one lane's output.  Global round trips are the cost
+ * here (a load the next store depends on), so the bytes are moved in 8-byte
+ * words with all loads of a pass issued before its stores:
+ *   - dist >= 8: passes of up to 4 words, never wider than the distance, so
+ *     a pass never reads what it writes; the last word may overrun the match
+ *     by up to 7 bytes (overwritten by the following tokens) when the output
+ *     buffer has room, else the tail goes bytewise;
+ *   - dist < 8 (runs): the period is expanded in registers, no reloads.
+ * Same-lane program order makes reading back earlier stores safe.
+ */
+static __device__ __forceinline__ u64 ld8(const u8 *p)
 {
 	u64 v;
-	__builtin_memcpy(&v, &L->in_ring[vpos & (IN_RING - 1)], 8);
+	__builtin_memcpy(&v, p, 8);
 	return v;
 }
 
-/* bit reader state, meaningful in lane 0 */
-struct bitreader {
-	u64 buf;
-	u32 cnt;	/* valid bits in buf (<= 63) */
-	u64 vpos;	/* virtual position of the next byte to load */
-};
-
-#define BR_REFILL(L, br)                                                     \
-	do {                                                                 \
-		(br).buf |= ring_load64(L, (br).vpos) << (br).cnt;           \
-		(br).vpos += (63 - (br).cnt) >> 3;                           \
-		(br).cnt |= 56;                                              \
-	} while (0)
-#define BR_CONSUME(br, k)                                                    \
-	do {                                                                 \
-		(br).buf >>= (k);                                            \
-		(br).cnt -= (k);                                             \
-	} while (0)
-/* bits consumed from the stream so far */
-#define BR_CONSUMED(br, in) (8 * ((br).vpos - (in).shift) - (br).cnt)
-
-/* drain window bytes [from, to) to the output buffer; whole wave */
-static __device__ void
-flush_window(const struct inflate_lds *L, u8 *outp, u64 from, u64 to, u32 lane)
+static __device__ __forceinline__ void st8(u8 *p, u64 v)
 {
-	if (from >= to)
-		return;
-	u64 a = from;
-	/* head up to the first 16-byte aligned global address */
-	u64 head_end = from + ((0 - (uintptr_t)(outp + from)) & 15);
-	if (head_end > to)
-		head_end = to;
-	if (a + lane < head_end)
-		outp[a + lane] = L->win[(a + lane) & WMASK];
-	a = head_end;
-	if (((uintptr_t)outp & 15) == 0) {
-		/* ring index and global address are congruent mod 16 */
-		for (; a + 1024 <= to; a += 1024) {
-			u64 p = a + lane * 16;
-			*(uint4 *)(outp + p) = *(const uint4 *)&L->win[p & WMASK];
-		}
-		u64 p = a + lane * 16;
-		if (p + 16 <= to)
-			*(uint4 *)(outp + p) = *(const uint4 *)&L->win[p & WMASK];
-		a += ((to - a) / 16) * 16;
-	}
-	for (u64 p = a + lane; p < to; p += 64)
-		outp[p] = L->win[p & WMASK];
+	__builtin_memcpy(p, &v, 8);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-lda_inflate_batch_kernel(u64 n_chunks, int format,
+static __device__ void
+copy_match(u8 *outp, u64 out_pos, u64 out_avail, u32 dist, u32 length)
+{
+	u8 *dst = outp + out_pos;
+	const u8 *src = dst - dist;
+	u32 nwords = (length + 7) >> 3;
+	bool room = out_pos + 8ull * nwords <= out_avail;
+
+	if (dist >= 8 && room) {
+		u32 maxw = dist >> 3;	/* words per pass that cannot overlap */
+		if (maxw > 4)
+			maxw = 4;
+		u32 w = 0;
+		while (w < nwords) {
+			u32 cnt = nwords - w < maxw ? nwords - w : maxw;
+			u64 v0 = ld8(src + 8 * w), v1 = 0, v2 = 0, v3 = 0;
+			if (cnt > 1)
+				v1 = ld8(src + 8 * w + 8);
+			if (cnt > 2)
+				v2 = ld8(src + 8 * w + 16);
+			if (cnt > 3)
+				v3 = ld8(src + 8 * w + 24);
+			st8(dst + 8 * w, v0);
+			if (cnt > 1)
+				st8(dst + 8 * w + 8, v1);
+			if (cnt > 2)
+				st8(dst + 8 * w + 16, v2);
+			if (cnt > 3)
+				st8(dst + 8 * w + 24, v3);
+			w += cnt;
+		}
+		return;
+	}
+	if (dist < 8 && room && dist <= out_pos) {
+		/* period 'dist' (1..7): expand in registers */
+		u64 pat = 0;
+		for (u32 k = 0; k < dist; k++)
+			pat |= (u64)src[k] << (8 * k);
+		u32 ph = 0;	/* phase = (8*w) % dist */
+		for (u32 w = 0; w < nwords; w++) {
+			u64 v = 0;
+			u32 q = ph;
+			for (u32 j = 0; j < 8; j++) {
+				v |= ((pat >> (8 * q)) & 0xFF) << (8 * j);
+				q = q + 1 == dist ? 0 : q + 1;
+			}
+			st8(dst + 8 * w, v);
+			ph = q;
+		}
+		return;
+	}
+	/* near the end of the output buffer: exact, bytewise */
+	for (u32 k = 0; k < length; k++)
+		dst[k] = src[k];
+}
+
+/*
+ * Input staging: the lane keeps the 64-byte block it is reading and the next
+ * one in a 128-byte LDS ring, so bit-buffer refills are LDS reads (lgkmcnt)
+ * and never wait behind the output stores in the vector-memory queue; a new
+ * block is fetched from HBM once per 64 bytes consumed.
+ */
+static __device__ __forceinline__ void
+ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
+{
+	u32 slot = (u32)at & 64;
+#pragma unroll
+	for (u32 k = 0; k < 8; k++) {
+		u64 v = load_in(inp, in_n, at + 8 * k);
+		__builtin_memcpy(ring + slot + 8 * k, &v, 8);
+		if (slot == 0 && k == 0)
+			__builtin_memcpy(ring + 128, &v, 8);
+	}
+}
+
+#define ENSURE_INPUT()                                                        \
+	do {                                                                  \
+		while (filled < rpos + 64) {                                  \
+			ring_fill(S->in_ring, inp, in_n, filled);             \
+			filled += 64;                                         \
+		}                                                             \
+	} while (0)
+#define REFILL()                                                              \
+	do {                                                                  \
+		u64 w_;                                                       \
+		__builtin_memcpy(&w_, S->in_ring + ((u32)rpos & 127), 8);     \
+		bitbuf |= w_ << bitcnt;                                       \
+		rpos += (63 - bitcnt) >> 3;                                   \
+		bitcnt |= 56;                                                 \
+	} while (0)
+#define CONSUME(k)                                                            \
+	do {                                                                  \
+		bitbuf >>= (k);                                               \
+		bitcnt -= (k);                                                \
+	} while (0)
+#define CONSUMED() (8 * rpos - bitcnt)
+#define FLUSH_PENDING()                                                       \
+	do {                                                                  \
+		if (pend_n) {                                                 \
+			st8(pend_dst, pv0);                                   \
+			if (pend_n > 1)                                       \
+				st8(pend_dst + 8, pv1);                       \
+			if (pend_n > 2)                                       \
+				st8(pend_dst + 16, pv2);                      \
+			if (pend_n > 3)                                       \
+				st8(pend_dst + 24, pv3);                      \
+			pend_n = 0;                                           \
+		}                                                             \
+	} while (0)
+
+extern "C" __global__ void __launch_bounds__(64, 4)
+lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			 const u8 *__restrict__ in_base,
 			 const u64 *__restrict__ in_offsets,
 			 const u64 *__restrict__ in_nbytes,
@@ -330,426 +452,420 @@ lda_inflate_batch_kernel(u64 n_chunks, int format,
 			 const u64 *__restrict__ out_offsets,
 			 const u64 *__restrict__ out_avail_arr,
 			 s32 *__restrict__ results,
-			 u64 *__restrict__ actual_in,	/* stream-relative, incl. header */
+			 u64 *__restrict__ actual_in,	/* incl. container header */
 			 u64 *__restrict__ actual_out)
 {
-	__shared__ struct inflate_lds Ls;
-	struct inflate_lds *L = &Ls;
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	struct stream_lds *SL = (struct stream_lds *)lds_raw;
 	const u32 lane = threadIdx.x;
-	const u64 c = blockIdx.x;
+	const u64 c = (u64)blockIdx.x * lpw + lane;
+	const bool owner = lane < lpw && c < n_chunks;
+	struct stream_lds *S = &SL[lane < lpw ? lane : 0];
 	PROF_DECL;
 	PROF_START();
+#ifdef LDA_PROFILE
+	unsigned long long pa_dec = 0, pa_flush = 0, pa_out = 0, pa_rounds = 0, pt_ = 0;
+#define SEG_T0() do { pt_ = __builtin_readcyclecounter(); } while (0)
+#define SEG_ADD(acc) do { unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pt_; pt_ = n_; } while (0)
+#else
+#define SEG_T0() do { } while (0)
+#define SEG_ADD(acc) do { } while (0)
+#endif
 
-	if (c >= n_chunks)
-		return;
-
-	const u8 *inp = in_base + in_offsets[c];
-	u64 in_n = in_nbytes[c];
-	u8 *outp = out_base + out_offsets[c];
-	const u64 out_avail = out_avail_arr[c];
-	u32 hdr = 0;		/* container header bytes before the deflate data */
+	const u8 *inp = in_base;
+	u64 in_n = 0, out_avail = 0;
+	u8 *outp = out_base;
+	u32 hdr = 0;
 	s32 result = LDA_SUCCESS;
+	u32 state = ST_DONE;
 
-	/* ---- container header (uniform scalar code, few bytes) ---- */
-	if (format == LDA_FMT_ZLIB) {
-		/* lib/zlib_decompress.c:45-72 */
-		if (in_n < 6) {
-			result = LDA_BAD_DATA;
-		} else {
-			u32 h = ((u32)inp[0] << 8) | inp[1];
-			if (h % 31 || ((h >> 8) & 0xF) != 8 || (h >> 12) > 7 ||
-			    ((h >> 5) & 1))
+	if (owner) {
+		inp = in_base + in_offsets[c];
+		in_n = in_nbytes[c];
+		outp = out_base + out_offsets[c];
+		out_avail = out_avail_arr[c];
+		state = ST_HDR;
+		/* ---- container header ---- */
+		if (format == LDA_FMT_ZLIB) {
+			/* lib/zlib_decompress.c:45-72 */
+			if (in_n < 6) {
 				result = LDA_BAD_DATA;
-			hdr = 2;
-			in_n -= 6;
-		}
-	} else if (format == LDA_FMT_GZIP) {
-		/* lib/gzip_decompress.c:45-107 */
-		if (in_n < 18) {
-			result = LDA_BAD_DATA;
-		} else if (inp[0] != 0x1F || inp[1] != 0x8B || inp[2] != 8 ||
-			   (inp[3] & 0xE0)) {
-			result = LDA_BAD_DATA;
-		} else {
-			u32 flg = inp[3];
-			u64 p = 10, end = in_n;
-			if (flg & 0x04) {
-				u32 xlen = inp[p] | ((u32)inp[p + 1] << 8);
-				p += 2;
-				if (end - p < (u64)xlen + 8)
+			} else {
+				u32 h = ((u32)inp[0] << 8) | inp[1];
+				if (h % 31 || ((h >> 8) & 0xF) != 8 || (h >> 12) > 7 ||
+				    ((h >> 5) & 1))
 					result = LDA_BAD_DATA;
-				p += xlen;
+				hdr = 2;
+				in_n -= 6;
 			}
-			if (result == LDA_SUCCESS && (flg & 0x08)) {
-				while (inp[p++] != 0 && p != end)
-					;
-				if (end - p < 8)
-					result = LDA_BAD_DATA;
-			}
-			if (result == LDA_SUCCESS && (flg & 0x10)) {
-				while (inp[p++] != 0 && p != end)
-					;
-				if (end - p < 8)
-					result = LDA_BAD_DATA;
-			}
-			if (result == LDA_SUCCESS && (flg & 0x02)) {
-				p += 2;
-				if (end - p < 8)
-					result = LDA_BAD_DATA;
-			}
-			if (result == LDA_SUCCESS) {
-				hdr = (u32)p;
-				in_n = end - 8 - p;
-			}
-		}
-	}
-	if (result != LDA_SUCCESS) {
-		if (lane == 0) {
-			results[c] = result;
-			actual_in[c] = 0;
-			actual_out[c] = 0;
-		}
-		return;
-	}
-	inp += hdr;
-
-	struct instream in;
-	in.base_al = (const u8 *)((uintptr_t)inp & ~(uintptr_t)15);
-	in.shift = (u32)((uintptr_t)inp & 15);
-	in.n = in_n;
-	in.tag[0] = in.tag[1] = -1;
-
-	struct bitreader br;
-	br.buf = 0;
-	br.cnt = 0;
-	br.vpos = in.shift;
-
-	const u64 limit_bits = 8 * in_n + 8;	/* see header comment */
-	u64 out_pos = 0;	/* bytes produced */
-	u64 flushed = 0;	/* bytes drained to HBM */
-	u32 final_block = 0;
-
-	do {
-		/* ---------------- block header (lane 0 reads) ---------------- */
-		ensure_input(L, &in, bcast64(br.vpos), lane);
-		u32 btype = 0, nlit = 0, noff = 0, err = 0;
-		u64 stored_pos = 0;
-		u32 stored_len = 0;
-		if (lane == 0) {
-			BR_REFILL(L, br);
-			if (BR_CONSUMED(br, in) > limit_bits)
-				err = LDA_BAD_DATA;
-			final_block = (u32)br.buf & 1;
-			btype = ((u32)br.buf >> 1) & 3;
-			if (!err && btype == 0) {
-				/* stored: decompress_template.h:247-285 */
-				BR_CONSUME(br, 3);
-				u64 cons = BR_CONSUMED(br, in);
-				u64 pos = (cons + 7) / 8;
-				if (pos > in_n || in_n - pos < 4) {
-					err = LDA_BAD_DATA;
-				} else {
-					u32 len = inp[pos] | ((u32)inp[pos + 1] << 8);
-					u32 nlen = inp[pos + 2] | ((u32)inp[pos + 3] << 8);
-					pos += 4;
-					if (len != (nlen ^ 0xFFFF))
-						err = LDA_BAD_DATA;
-					else if (len > out_avail - out_pos)
-						err = LDA_INSUFFICIENT_SPACE;
-					else if (len > in_n - pos)
-						err = LDA_BAD_DATA;
-					stored_pos = pos;
-					stored_len = len;
-				}
-			} else if (!err && btype == 3) {
-				err = LDA_BAD_DATA;
-			} else if (!err && btype == 2) {
-				/* dynamic header: decompress_template.h:85-146 */
-				nlit = 257 + (((u32)br.buf >> 3) & 31);
-				noff = 1 + (((u32)br.buf >> 8) & 31);
-				u32 npre = 4 + (((u32)br.buf >> 13) & 15);
-				for (u32 i = 0; i < 19; i++)
-					L->pre_lens[i] = 0;
-				L->pre_lens[c_pre_perm[0]] = ((u32)br.buf >> 17) & 7;
-				BR_CONSUME(br, 20);
-				BR_REFILL(L, br);
-				if (BR_CONSUMED(br, in) > limit_bits)
-					err = LDA_BAD_DATA;
-				for (u32 i = 1; i < npre; i++) {
-					L->pre_lens[c_pre_perm[i]] = (u32)br.buf & 7;
-					BR_CONSUME(br, 3);
-				}
-			} else if (!err) {
-				BR_CONSUME(br, 3);	/* static */
-			}
-		}
-		err = bcast_first(err);
-		btype = bcast_first(btype);
-		final_block = bcast_first(final_block);
-		if (err) {
-			result = (s32)err;
-			break;
-		}
-
-		if (btype == 0) {
-			/* copy the stored bytes through the window, wave-wide */
-			stored_len = bcast_first(stored_len);
-			u64 sp = bcast64(stored_pos);
-			u32 done = 0;
-			while (done < stored_len) {
-				u32 piece = stored_len - done;
-				if (piece > OUT_CAP)
-					piece = OUT_CAP;
-				if (out_pos - flushed > WSIZE - OUT_CAP) {
-					flush_window(L, outp, flushed, out_pos, lane);
-					flushed = out_pos;
-				}
-				for (u32 j = lane; j < piece; j += 64)
-					L->win[(out_pos + j) & WMASK] = inp[sp + done + j];
-				wave_sync();
-				out_pos += piece;
-				done += piece;
-			}
-			/* restart the bit reader after the stored bytes */
-			br.buf = 0;
-			br.cnt = 0;
-			br.vpos = in.shift + sp + stored_len;
-			continue;
-		}
-
-		if (btype == 2) {
-			nlit = bcast_first(nlit);
-			noff = bcast_first(noff);
-			wave_sync();
-			if (!build_table(KIND_PRECODE, L->pre_lens, 19, 7,
-					 L->pre_tab, &L->pre, L->pre_sorted,
-					 lane)) {
+		} else if (format == LDA_FMT_GZIP) {
+			/* lib/gzip_decompress.c:45-107 */
+			if (in_n < 18) {
 				result = LDA_BAD_DATA;
-				break;
-			}
-			/* code length runs: decompress_template.h:150-245.
-			 * The reference refills only when fewer than 14 bits are
-			 * left; 'loaded' reproduces its refill points. */
-			u32 herr = 0;
-			if (lane == 0) {
-				u32 i = 0, total = nlit + noff;
-				/* br.cnt equals the reference's bitsleft here: both
-				 * were topped up at the same points, and a top-up only
-				 * depends on the consumed bit count */
-				do {
-					if (br.cnt < 14) {
-						BR_REFILL(L, br);
-						if (BR_CONSUMED(br, in) > limit_bits) {
-							herr = LDA_BAD_DATA;
-							break;
-						}
-					}
-					u32 e = L->pre_tab[(u32)br.buf & 127];
-					BR_CONSUME(br, e & 15);
-					u32 presym = e >> 16;
-					if (presym < 16) {
-						L->lens[i++] = (u8)presym;
-						continue;
-					}
-					u32 rep, val = 0;
-					if (presym == 16) {
-						if (i == 0) {
-							herr = LDA_BAD_DATA;
-							break;
-						}
-						val = L->lens[i - 1];
-						rep = 3 + ((u32)br.buf & 3);
-						BR_CONSUME(br, 2);
-					} else if (presym == 17) {
-						rep = 3 + ((u32)br.buf & 7);
-						BR_CONSUME(br, 3);
-					} else {
-						rep = 11 + ((u32)br.buf & 127);
-						BR_CONSUME(br, 7);
-					}
-					for (u32 k = 0; k < rep; k++)
-						L->lens[i + k] = (u8)val;
-					i += rep;
-				} while (i < total);
-				if (!herr && i != total)
-					herr = LDA_BAD_DATA;
-			}
-			herr = bcast_first(herr);
-			if (herr) {
-				result = (s32)herr;
-				break;
-			}
-		} else {
-			/* static codes: decompress_template.h:313-326 */
-			for (u32 i = lane; i < 320; i += 64)
-				L->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 :
-					     i < 288 ? 8 : 5;
-			nlit = 288;
-			noff = 32;
-		}
-		wave_sync();
-		if (!build_table(KIND_OFFSET, L->lens + nlit, noff, OFF_TB,
-				 L->off_tab, &L->off, L->off_sorted, lane) ||
-		    !build_table(KIND_LITLEN, L->lens, nlit, LIT_TB, L->lit_tab,
-				 &L->lit, L->lit_sorted, lane)) {
-			result = LDA_BAD_DATA;
-			break;
-		}
-
-		PROF_MARK(0);	/* header + tables */
-		/* ---------------- token batches ---------------- */
-		u32 eob = 0;
-		while (!eob) {
-			PROF_MARK(3);
-			ensure_input(L, &in, bcast64(br.vpos), lane);
-			if (out_pos - flushed > WSIZE - OUT_CAP) {
-				flush_window(L, outp, flushed, out_pos, lane);
-				flushed = out_pos;
-				/* make the drained bytes visible to later far reads */
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			}
-			PROF_MARK(1);	/* input staging + flush */
-			u32 ntok = 0, berr = 0, produced = 0;
-			if (lane == 0) {
-				u64 opos = out_pos;
-				/* generic_loop: decompress_template.h:680-738 */
-				while (ntok < BATCH && produced < OUT_CAP - 258) {
-					BR_REFILL(L, br);
-					if (BR_CONSUMED(br, in) > limit_bits) {
-						berr = LDA_BAD_DATA;
-						break;
-					}
-					u32 e = L->lit_tab[(u32)br.buf & ((1u << LIT_TB) - 1)];
-					if ((e & 15) == 0)
-						e = decode_long(KIND_LITLEN, &L->lit,
-								L->lit_sorted, br.buf);
-					if (e & E_LIT) {
-						BR_CONSUME(br, e & 15);
-						if (opos == out_avail) {
-							berr = LDA_INSUFFICIENT_SPACE;
-							break;
-						}
-						L->tok[ntok++] = e & 0x00FF0000u;
-						opos++;
-						produced++;
-						continue;
-					}
-					if (e & E_EOB) {
-						BR_CONSUME(br, e & 15);
-						eob = 1;
-						break;
-					}
-					u32 cl = e & 15, xb = (e >> 4) & 15;
-					u32 length = (e >> 16) +
-						(((u32)(br.buf >> cl)) & ((1u << xb) - 1));
-					BR_CONSUME(br, cl + xb);
-					if (length > out_avail - opos) {
-						berr = LDA_INSUFFICIENT_SPACE;
-						break;
-					}
-					u32 e2 = L->off_tab[(u32)br.buf & ((1u << OFF_TB) - 1)];
-					if ((e2 & 15) == 0)
-						e2 = decode_long(KIND_OFFSET, &L->off,
-								 L->off_sorted, br.buf);
-					cl = e2 & 15;
-					xb = (e2 >> 4) & 15;
-					u32 dist = (e2 >> 16) +
-						(((u32)(br.buf >> cl)) & ((1u << xb) - 1));
-					BR_CONSUME(br, cl + xb);
-					if (dist > opos) {
-						berr = LDA_BAD_DATA;
-						break;
-					}
-					L->tok[ntok++] = (length << 16) | dist;
-					opos += length;
-					produced += length;
+			} else if (inp[0] != 0x1F || inp[1] != 0x8B || inp[2] != 8 ||
+				   (inp[3] & 0xE0)) {
+				result = LDA_BAD_DATA;
+			} else {
+				u32 flg = inp[3];
+				u64 p = 10, end = in_n;
+				if (flg & 0x04) {
+					u32 xlen = inp[p] | ((u32)inp[p + 1] << 8);
+					p += 2;
+					if (end - p < (u64)xlen + 8)
+						result = LDA_BAD_DATA;
+					p += xlen;
+				}
+				if (result == LDA_SUCCESS && (flg & 0x08)) {
+					while (inp[p++] != 0 && p != end)
+						;
+					if (end - p < 8)
+						result = LDA_BAD_DATA;
+				}
+				if (result == LDA_SUCCESS && (flg & 0x10)) {
+					while (inp[p++] != 0 && p != end)
+						;
+					if (end - p < 8)
+						result = LDA_BAD_DATA;
+				}
+				if (result == LDA_SUCCESS && (flg & 0x02)) {
+					p += 2;
+					if (end - p < 8)
+						result = LDA_BAD_DATA;
+				}
+				if (result == LDA_SUCCESS) {
+					hdr = (u32)p;
+					in_n = end - 8 - p;
 				}
 			}
-			ntok = bcast_first(ntok);
-			berr = bcast_first(berr);
-			eob = bcast_first(eob);
-			produced = bcast_first(produced);
-			if (berr) {
-				result = (s32)berr;
-				break;
-			}
-			wave_sync();
-
-			PROF_MARK(2);	/* serial decode */
-			/* ---- apply the batch with all lanes ---- */
-			u32 t = lane < ntok ? L->tok[lane] : 0;
-			u32 dist = t & 0xFFFF;
-			u32 len = lane < ntok ? (dist ? (t >> 16) : 1) : 0;
-			u32 incl = wave_scan_incl(len);
-			u64 dst = out_pos + (incl - len);
-			/* positions >= lds_lo are guaranteed to be in the window */
-			s64 lds_lo = (s64)(out_pos + produced) - (s64)WSIZE;
-
-			if (lane < ntok && dist == 0)
-				L->win[dst & WMASK] = (u8)(t >> 16);
-			u64 mm = __ballot(lane < ntok && dist != 0);
-			while (mm) {
-				u32 tl = (u32)__builtin_ctzll(mm);
-				mm &= mm - 1;
-				u32 mlen = bcast_lane(len, tl);
-				u32 mdist = bcast_lane(dist, tl);
-				u64 mdst = ((u64)bcast_lane((u32)(dst >> 32), tl) << 32) |
-					   bcast_lane((u32)dst, tl);
-				u64 src0 = mdst - mdist;
-				wave_sync();
-				if (mdist >= 64) {
-					for (u32 j = lane; j < mlen; j += 64) {
-						u64 sp = src0 + j;
-						u8 b = ((s64)sp >= lds_lo) ?
-							L->win[sp & WMASK] : outp[sp];
-						L->win[(mdst + j) & WMASK] = b;
-						if (mdist < mlen)
-							wave_sync();
-					}
-				} else {
-					/* periodic fill: byte j repeats byte j % dist of
-					 * the 'dist' bytes that precede the match */
-					u32 inv = (0x100000u + mdist - 1) / mdist;
-					for (u32 j = lane; j < mlen; j += 64) {
-						u32 q = (j * inv) >> 20;
-						u64 sp = src0 + (j - q * mdist);
-						u8 b = ((s64)sp >= lds_lo) ?
-							L->win[sp & WMASK] : outp[sp];
-						L->win[(mdst + j) & WMASK] = b;
-					}
-				}
-			}
-			wave_sync();
-			out_pos += produced;
 		}
 		if (result != LDA_SUCCESS)
-			break;
-	} while (!final_block);
-
-	if (result == LDA_SUCCESS) {
-		flush_window(L, outp, flushed, out_pos, lane);
-		/* epilogue: decompress_template.h:740-771 */
-		u32 e = 0;
-		u64 ain = 0;
-		if (lane == 0) {
-			u64 cons = BR_CONSUMED(br, in);
-			ain = (cons + 7) / 8;
-			if (ain > in_n)
-				e = LDA_BAD_DATA;
-		}
-		e = bcast_first(e);
-		if (e)
-			result = (s32)e;
-		else if (lane == 0)
-			actual_in[c] = hdr + ain;
+			state = ST_DONE;
+		else
+			inp += hdr;
 	}
+
+	u64 bitbuf = 0, rpos = 0, out_pos = 0, filled = 0;
+	u32 bitcnt = 0, final_block = 0, nlit = 0, noff = 0;
+	u64 stored_left = 0;
+	u64 pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;	/* loaded, not yet stored */
+	u8 *pend_dst = outp;
+	u32 pend_n = 0;
+	const u64 limit_bits = 8 * in_n + 8;	/* see header comment */
+
+	while (__ballot(state != ST_DONE)) {
+		/* ------------ block headers (lanes that need one) ------------ */
+		if (state == ST_HDR) {
+			/* decompress_template.h:72-83 */
+			ENSURE_INPUT();
+			REFILL();
+			if (CONSUMED() > limit_bits) {
+				result = LDA_BAD_DATA;
+				state = ST_DONE;
+			} else {
+				final_block = (u32)bitbuf & 1;
+				u32 btype = ((u32)bitbuf >> 1) & 3;
+				if (btype == 0) {
+					/* stored: decompress_template.h:247-285 */
+					CONSUME(3);
+					u64 pos = (CONSUMED() + 7) / 8;
+					if (pos > in_n || in_n - pos < 4) {
+						result = LDA_BAD_DATA;
+						state = ST_DONE;
+					} else {
+						u32 len = inp[pos] | ((u32)inp[pos + 1] << 8);
+						u32 nlen = inp[pos + 2] | ((u32)inp[pos + 3] << 8);
+						pos += 4;
+						if (len != (nlen ^ 0xFFFF)) {
+							result = LDA_BAD_DATA;
+							state = ST_DONE;
+						} else if (len > out_avail - out_pos) {
+							result = LDA_INSUFFICIENT_SPACE;
+							state = ST_DONE;
+						} else if (len > in_n - pos) {
+							result = LDA_BAD_DATA;
+							state = ST_DONE;
+						} else {
+							rpos = pos;
+							stored_left = len;
+							state = ST_STORED;
+						}
+					}
+				} else if (btype == 3) {
+					result = LDA_BAD_DATA;
+					state = ST_DONE;
+				} else if (btype == 1) {
+					/* static codes: decompress_template.h:313-326 */
+					CONSUME(3);
+					for (u32 i = 0; i < 320; i++)
+						S->lens[i] = i < 144 ? 8 : i < 256 ? 9 :
+							     i < 280 ? 7 : i < 288 ? 8 : 5;
+					nlit = 288;
+					noff = 32;
+					state = ST_TABLES;
+				} else {
+					/* dynamic header: decompress_template.h:85-245 */
+					u8 plens[19];
+					nlit = 257 + (((u32)bitbuf >> 3) & 31);
+					noff = 1 + (((u32)bitbuf >> 8) & 31);
+					u32 npre = 4 + (((u32)bitbuf >> 13) & 15);
+					for (u32 i = 0; i < 19; i++)
+						plens[i] = 0;
+					plens[c_pre_perm[0]] = ((u32)bitbuf >> 17) & 7;
+					CONSUME(20);
+					ENSURE_INPUT();
+					REFILL();
+					if (CONSUMED() > limit_bits) {
+						result = LDA_BAD_DATA;
+						state = ST_DONE;
+					} else {
+						for (u32 i = 1; i < npre; i++) {
+							plens[c_pre_perm[i]] = (u32)bitbuf & 7;
+							CONSUME(3);
+						}
+						if (!build_precode(S->pre_tab, plens)) {
+							result = LDA_BAD_DATA;
+							state = ST_DONE;
+						}
+					}
+					if (state == ST_HDR) {
+						/* code length runs (:150-245); bitcnt tracks the
+						 * reference's bitsleft: both were topped up at
+						 * the same points */
+						u32 i = 0, total = nlit + noff, bad = 0;
+						do {
+							if (bitcnt < 14) {
+								ENSURE_INPUT();
+								REFILL();
+								if (CONSUMED() > limit_bits) {
+									bad = 1;
+									break;
+								}
+							}
+							u32 e = S->pre_tab[(u32)bitbuf & 127];
+							CONSUME(e & 15);
+							u32 presym = e >> 4;
+							if (presym < 16) {
+								S->lens[i++] = (u8)presym;
+								continue;
+							}
+							u32 rep, val = 0;
+							if (presym == 16) {
+								if (i == 0) {
+									bad = 1;
+									break;
+								}
+								val = S->lens[i - 1];
+								rep = 3 + ((u32)bitbuf & 3);
+								CONSUME(2);
+							} else if (presym == 17) {
+								rep = 3 + ((u32)bitbuf & 7);
+								CONSUME(3);
+							} else {
+								rep = 11 + ((u32)bitbuf & 127);
+								CONSUME(7);
+							}
+							for (u32 k = 0; k < rep; k++)
+								S->lens[i + k] = (u8)val;
+							i += rep;
+						} while (i < total);
+						if (bad || i != total) {
+							result = LDA_BAD_DATA;
+							state = ST_DONE;
+						} else {
+							state = ST_TABLES;
+						}
+					}
+				}
+			}
+		}
+		PROF_MARK(0);
+
+		/* ------------ decode tables: one stream at a time, all lanes ------------ */
+		{
+			u64 need = __ballot(state == ST_TABLES);
+			while (need) {
+				u32 who = (u32)__builtin_ctzll(need);
+				need &= need - 1;
+				struct stream_lds *T = &SL[who];
+				u32 t_nlit = bcast_lane(nlit, who);
+				u32 t_noff = bcast_lane(noff, who);
+				u32 s_lit, s_off;
+				wave_sync();
+				/* both sorts read lens[] before any table overwrites it;
+				 * offset first as in the reference (:331-332) */
+				bool ok = build_table_coop(T->lens + t_nlit, t_noff, OFF_TB,
+							   false, &T->off, T->off_sorted,
+							   lane, &s_off);
+				ok = build_table_coop(T->lens, t_nlit, LIT_TB, true, &T->lit,
+						      T->lit_sorted, lane, &s_lit) && ok;
+				wave_sync();
+				if (ok) {
+					fill_table(T->off_tab, OFF_TB, false, &T->off,
+						   T->off_sorted, s_off, lane);
+					fill_table(T->lit_tab, LIT_TB, true, &T->lit,
+						   T->lit_sorted, s_lit, lane);
+				}
+				wave_sync();
+				if (lane == who) {
+					if (ok) {
+						state = ST_TOK;
+					} else {
+						result = LDA_BAD_DATA;
+						state = ST_DONE;
+					}
+				}
+			}
+		}
+		PROF_MARK(1);
+
+		/* ------------ stored blocks: the lane copies its bytes ------------ */
+		if (state == ST_STORED) {
+			const u8 *src = inp + rpos;
+			u8 *dst = outp + out_pos;
+			u64 k = 0;
+			for (; k + 8 <= stored_left; k += 8) {
+				u64 v;
+				__builtin_memcpy(&v, src + k, 8);
+				__builtin_memcpy(dst + k, &v, 8);
+			}
+			for (; k < stored_left; k++)
+				dst[k] = src[k];
+			out_pos += stored_left;
+			rpos += stored_left;
+			bitbuf = 0;
+			bitcnt = 0;
+			filled = rpos & ~(u64)63;	/* restart the input ring */
+			state = final_block ? ST_DONE : ST_HDR;
+		}
+
+		/* ------------ tokens: one per lane per round ------------ */
+		for (u32 round = 0; round < 4096; round++) {
+			u64 tk = __ballot(state == ST_TOK);
+			if (!tk)
+				break;
+			/* leave as soon as someone needs a header or tables */
+			if (__ballot(state == ST_HDR || state == ST_TABLES))
+				break;
+#ifdef LDA_PROFILE
+			pa_out++;	/* all iterations of this wave */
+#endif
+			if (state != ST_TOK)
+				continue;
+			/* generic_loop: decompress_template.h:680-738 */
+			SEG_T0();
+			if (filled < rpos + 64)
+				ENSURE_INPUT();
+			REFILL();
+			if (CONSUMED() > limit_bits) {
+				result = LDA_BAD_DATA;
+				state = ST_DONE;
+				continue;
+			}
+			u32 e = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+			u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
+			if (cl == 0) {
+				u32 sym = decode_long(&S->lit, S->lit_sorted, bitbuf, &cl);
+				kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
+				pay = sym < 256 ? sym : sym - 257;
+			}
+			CONSUME(cl);
+			SEG_ADD(pa_dec);
+			FLUSH_PENDING();
+			SEG_ADD(pa_flush);
+#ifdef LDA_PROFILE
+			pa_rounds++;
+#endif
+			if (kind == K_LIT) {
+				if (out_pos == out_avail) {
+					result = LDA_INSUFFICIENT_SPACE;
+					state = ST_DONE;
+					continue;
+				}
+				outp[out_pos++] = (u8)pay;
+				continue;
+			}
+			if (kind == K_EOB) {
+				state = final_block ? ST_DONE : ST_HDR;
+				continue;
+			}
+			u32 base, xb;
+			len_sym(pay, &base, &xb);
+			u32 length = base + ((u32)bitbuf & ((1u << xb) - 1));
+			CONSUME(xb);
+			if (length > out_avail - out_pos) {
+				result = LDA_INSUFFICIENT_SPACE;
+				state = ST_DONE;
+				continue;
+			}
+			u32 e2 = S->off_tab[(u32)bitbuf & ((1u << OFF_TB) - 1)];
+			u32 ol = e2 & 15, osym = e2 >> 4;
+			if (ol == 0)
+				osym = decode_long(&S->off, S->off_sorted, bitbuf, &ol);
+			CONSUME(ol);
+			off_sym(osym, &base, &xb);
+			u32 dist = base + ((u32)bitbuf & ((1u << xb) - 1));
+			CONSUME(xb);
+			if (dist > out_pos) {
+				result = LDA_BAD_DATA;
+				state = ST_DONE;
+				continue;
+			}
+			/* the lane copies from its own earlier output; short
+			 * non-overlapping copies are split: loads now, stores at the
+			 * next token, so the HBM/L2 round trip overlaps the decode */
+			{
+				u32 nwords = (length + 7) >> 3;
+				u32 maxw = dist >> 3;
+				if (nwords <= 4 && nwords <= maxw &&
+				    out_pos + 8ull * nwords <= out_avail) {
+					const u8 *src = outp + out_pos - dist;
+					pend_dst = outp + out_pos;
+					pend_n = nwords;
+					pv0 = ld8(src);
+					if (nwords > 1)
+						pv1 = ld8(src + 8);
+					if (nwords > 2)
+						pv2 = ld8(src + 16);
+					if (nwords > 3)
+						pv3 = ld8(src + 24);
+				} else {
+					copy_match(outp, out_pos, out_avail, dist, length);
+				}
+			}
+			out_pos += length;
+		}
+		PROF_MARK(2);
+	}
+
+	FLUSH_PENDING();
+#ifdef LDA_PROFILE
 	if (lane == 0) {
+		atomicAdd(&lda_prof[4], pa_dec);
+		atomicAdd(&lda_prof[5], pa_flush);
+		atomicAdd(&lda_prof[6], pa_rounds);
+		atomicAdd(&lda_prof[7], pa_out);
+	}
+#endif
+	if (owner) {
+		if (result == LDA_SUCCESS) {
+			/* epilogue: decompress_template.h:740-771 */
+			u64 ain = (CONSUMED() + 7) / 8;
+			if (ain > in_n)
+				result = LDA_BAD_DATA;
+			else
+				actual_in[c] = hdr + ain;
+		}
 		results[c] = result;
 		actual_out[c] = result == LDA_SUCCESS ? out_pos : 0;
 		if (result != LDA_SUCCESS)
 			actual_in[c] = 0;
 	}
+}
+
+/* host helper: LDS bytes per stream */
+extern "C" size_t lda_inflate_lds_per_stream(void)
+{
+	return sizeof(struct stream_lds);
 }
 
 /*

@@ -21,7 +21,8 @@ lda_adler32_batch_kernel(uint64_t n_chunks, const uint8_t *base,
 
 /* inflate_kernel.hip */
 extern "C" __global__ void
-lda_inflate_batch_kernel(uint64_t n_chunks, int format, const uint8_t *in_base,
+lda_inflate_batch_kernel(uint64_t n_chunks, int format, uint32_t lpw,
+			 const uint8_t *in_base,
 			 const uint64_t *in_offsets, const uint64_t *in_nbytes,
 			 uint8_t *out_base, const uint64_t *out_offsets,
 			 const uint64_t *out_avail, int32_t *results,
@@ -43,6 +44,8 @@ lda_deflate_batch_kernel(uint64_t n_chunks, int format, int level,
 			 const uint64_t *out_offsets, const uint64_t *out_avail,
 			 uint64_t *out_nbytes, const uint32_t *sums);
 extern "C" size_t lda_deflate_lds_bytes(void);
+
+extern "C" size_t lda_inflate_lds_per_stream(void);
 
 /* CRC constant tables, generated on the host at first use (host_api.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)
