@@ -55,9 +55,10 @@
 #define RING 32768u
 #define RMASK (RING - 1)
 #define LOOKAHEAD 272u
-#define HASH_BITS 14
-#define SEQ_CAP 2048u
-#define SEQ_TILE_MAX 520u	/* > TILE/4 new matches per tile (min match 4) */
+#define HASH_BITS 13
+#define HASH3_BITS 12
+#define SEQ_CAP 3072u
+#define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile (min match 3) */
 #define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
 #define EWIN 1024u		/* encode window (positions) */
 #define STG_WORDS 1024u		/* 4 KiB staging */
@@ -70,6 +71,7 @@ struct deflate_lds {
 	u8 in[RING + 32];
 	u16 prev[RING];
 	u16 head[1u << HASH_BITS];
+	u16 head3[1u << HASH3_BITS];	/* last position per 3-byte hash (no chain) */
 	u32 seq_pl[SEQ_CAP];	/* block-relative position | length << 16 */
 	u16 seq_d[SEQ_CAP];	/* distance */
 	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
@@ -96,7 +98,7 @@ struct deflate_lds {
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3, V_CTR
+	V_TMP2, V_TMP3, V_CTR, V_MINLEN
 };
 
 struct level_params {
@@ -130,11 +132,28 @@ static __device__ __forceinline__ u64 ld64(const u8 *ring, u32 pos)
 	return ((u64)hi << 32) | lo;
 }
 
+static __device__ __forceinline__ u32 hash3(u32 w)
+{
+	/* 3-byte hash for length-3 matches, lib/hc_matchfinder.h:228-231 role */
+	return ((w & 0xFFFFFFu) * 0x1E35A7BDu) >> (32 - HASH3_BITS);
+}
+
 static __device__ __forceinline__ u32 hash4(u32 w)
 {
 	/* multiplicative hash, lib/matchfinder_common.h:168-172 */
 	return (w * 0x1E35A7BDu) >> (32 - HASH_BITS);
 }
+
+/*
+ * Length-3 match for a position whose chain search found nothing >= 4:
+ * the short distances 1..8 are compared in registers (covers strided binary
+ * records), then the single-slot 3-byte hash candidate.  Distance limits for
+ * length 3 as lib/deflate_compress.c:2573-2575 / :2666-2668.
+ */
+struct deflate_lds;
+static __device__ u32
+find_len3(const struct deflate_lds *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
+	  u32 dlim, u32 *best);
 
 /* workgroup exclusive scan of one value per thread; returns the exclusive
  * prefix and writes the total to *total.  Two barriers. */
@@ -188,6 +207,52 @@ dist_code(u32 dist, u32 *slot, u32 *xbits, u32 *xval)
 		*slot = 2 * hb + ((d >> (hb - 1)) & 1);
 		*xval = d & ((1u << (hb - 1)) - 1);
 	}
+}
+
+/*
+ * Minimum useful match length from the number of distinct literals in use:
+ * with few distinct literals a literal is so cheap that short matches lose.
+ * Policy of lib/deflate_compress.c:2295-2327 (table restated as thresholds).
+ */
+static __device__ u32 choose_min_len(u32 used_literals, u32 depth)
+{
+	u32 m = used_literals >= 80 ? 3 : used_literals >= 45 ? 4 :
+		used_literals >= 16 ? 5 : used_literals >= 10 ? 6 :
+		used_literals >= 8 ? 7 : used_literals >= 6 ? 8 : 9;
+	if (depth < 16) {
+		u32 cap = depth < 5 ? 4 : depth < 10 ? 5 : 7;
+		if (m > cap)
+			m = cap;
+	}
+	return m;
+}
+
+static __device__ u32
+find_len3(const struct deflate_lds *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
+	  u32 dlim, u32 *best)
+{
+	if (dmax > dlim)
+		dmax = dlim;
+	u32 want = cur & 0xFFFFFFu;
+	if (p >= 8) {
+		u64 w8 = ld64(L->in, p - 8);
+#pragma unroll
+		for (u32 d = 1; d <= 8; d++) {
+			u64 t = w8 >> (8 * (8 - d));
+			if (d < 3)
+				t |= (u64)cur << (8 * d);
+			if (d <= dmax && ((u32)t & 0xFFFFFFu) == want) {
+				*best = 3;
+				return d;
+			}
+		}
+	}
+	u32 d = (p - c3_16) & 0xFFFF;
+	if (d && d <= dmax && ((ld32(L->in, p - d) ^ cur) & 0xFFFFFFu) == 0) {
+		*best = 3;
+		return d;
+	}
+	return 0;
 }
 
 /*
@@ -515,6 +580,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 		PROF_START();
 		for (u32 i = tid; i < (1u << HASH_BITS) / 2; i += NT)
 			((u32 *)L->head)[i] = 0x80008000u;
+		for (u32 i = tid; i < (1u << HASH3_BITS) / 2; i += NT)
+			((u32 *)L->head3)[i] = 0x80008000u;
 		for (u32 i = tid; i < 320; i += NT)
 			L->freq[i] = 0;
 		for (u32 i = tid; i < STG_WORDS + 8; i += NT)
@@ -595,6 +662,23 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			if (tid < 4)
 				L->M[TILE + 4 + tid] = 0;
 			__syncthreads();
+			if (tile == 0 && !stored_only) {
+				/* first estimate from the bytes at hand
+				 * (calculate_min_match_len, deflate_compress.c:2329-2353) */
+				u32 *seen = L->M + 16;
+				for (u32 i = tid; i < 256; i += NT)
+					seen[i] = 0;
+				__syncthreads();
+				u32 lim = want < 4096 ? want : 4096;
+				for (u32 i = tid; i < lim; i += NT)
+					seen[L->in[i]] = 1;
+				__syncthreads();
+				u32 c1 = tid < 256 ? seen[tid] : 0, tot1;
+				(void)block_scan(L, c1, &tot1);
+				if (tid == 0)
+					L->vars[V_MINLEN] = n < 512 ? 3 : choose_min_len(tot1, depth);
+				__syncthreads();
+			}
 
 			PROF_MARK(1);
 			if (!stored_only) {
@@ -605,9 +689,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 gb = t + g * 64;
 					u32 p = gb + lane;
 					bool valid = p + 4 <= n;
-					u32 h = valid ? hash4(ld32(L->in, p)) :
-							(0x4000u | lane);
+					u32 w4 = ld32(L->in, p);
+					u32 h = valid ? hash4(w4) : (0x4000u | lane);
 					u32 key = (h << 6) | lane;
+					/* 3-byte hash rides along in M (bits 19..30) for S2;
+					 * written before the sort scatters the hash4 part */
+					u32 h3v = p + 3 <= n ? (hash3(w4) | 0x1000u) : 0;
 #pragma unroll
 					for (u32 k = 2; k <= 64; k <<= 1) {
 #pragma unroll
@@ -629,6 +716,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					if (isv && !first)
 						L->prev[(gb + orig) & RMASK] =
 							(u16)(gb + (left & 63));
+					L->nxtB[4 + g * 64 + lane] = (u16)h3v;
 					L->M[4 + g * 64 + orig] = hh |
 						(first ? M_FIRST : 0) |
 						(last ? M_LAST : 0) |
@@ -645,13 +733,22 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					for (u32 g = 0; g < ngroups; g++) {
 						u32 i = g * 64 + lane;
 						u32 m = L->M[4 + i];
-						u32 h = m & 0x3FFF;
+						u32 h = m & ((1u << HASH_BITS) - 1);
 						if (m & M_VALID) {
 							if (m & M_FIRST)
 								L->prev[(t + i) & RMASK] = L->head[h];
 							if (m & M_LAST)
 								L->head[h] = (u16)(t + i);
 						}
+						/* 3-byte table: candidate = last position of an
+						 * EARLIER group with this hash (single slot) */
+						u32 h3v = L->nxtB[4 + i];
+						u32 c3 = 0;
+						if (h3v)
+							c3 = L->head3[h3v & 0xFFF];
+						L->nxtA[4 + i] = (u16)c3;
+						if (h3v)
+							L->head3[h3v & 0xFFF] = (u16)(t + i);
 						wave_sync();
 					}
 				}
@@ -685,6 +782,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
 					u32 dep = p + 4 <= n ? depth : 0;
 					u32 best = 3, bestd = 0, dprev = 0;
+					const u32 min_len = L->vars[V_MINLEN];
 					while (__ballot(have)) {
 						if (!have)
 							continue;
@@ -721,7 +819,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							}
 						}
 						if (stop) {
-							L->M[4 + my_i] = best >= 4 ? (best | (bestd << 16)) : 0;
+							if (best < 4 && maxlen >= 3 && min_len <= 3)
+								bestd = find_len3(L, p, cur, L->nxtA[4 + my_i],
+										  p - lo_pos, mode ? 8192u : 4096u,
+										  &best);
+							L->M[4 + my_i] = best >= min_len && best >= 3 && bestd ?
+								(best | (bestd << 16)) : 0;
 							my_i = nx_i;
 							have = my_i < TILE;
 							if (have) {
@@ -1259,6 +1362,17 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			 * (M is reused as tile scratch) */
 			stg_save(L, &os);
 			PROF_MARK(8);
+			if (!stored_only) {
+				/* recalculate_min_match_len (deflate_compress.c:2359-2378):
+				 * literals used more than total/1024 times in this block */
+				u32 lf = tid < 256 ? L->freq[tid] : 0, lit_total;
+				(void)block_scan(L, lf, &lit_total);
+				u32 usedf = (tid < 256 && lf > (lit_total >> 10)) ? 1 : 0, nused;
+				(void)block_scan(L, usedf, &nused);
+				if (tid == 0)
+					L->vars[V_MINLEN] = choose_min_len(nused, depth);
+				__syncthreads();
+			}
 			for (u32 i = tid; i < 320; i += NT)
 				L->freq[i] = 0;
 			if (tid == 0)

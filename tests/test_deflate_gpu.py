@@ -86,7 +86,7 @@ def test_container_bytes(oracle):
 
 
 def test_ratio_tracks_reference(oracle):
-    """Reported, loosely gated: GPU level L within 15% of the reference's
+    """Reported, loosely gated: GPU level L within 3% of the reference's
     compressed size at level L on the 64 KiB mix."""
     from libdeflate_amd import api
     from tests import oracle_util
@@ -103,7 +103,7 @@ def test_ratio_tracks_reference(oracle):
         else:
             theirs = sum(len(streams._zcompress("deflate", lvl, d)) for d in chunks)
         print(f"level {lvl}: ours {ours} ref {theirs} ratio {ours/theirs:.4f}")
-        assert ours <= theirs * 1.15
+        assert ours <= theirs * 1.03
         c.close()
 
 
