@@ -779,69 +779,110 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						nc16 = L->prev[(t + nx_i) & RMASK];
 					}
 					bool have = my_i < TILE;
+					bool fin = false;	/* finished, result not yet stored */
 					u32 maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
 					u32 dep = p + 4 <= n ? depth : 0;
 					u32 best = 3, bestd = 0, dprev = 0;
 					const u32 min_len = L->vars[V_MINLEN];
-					while (__ballot(have)) {
-						if (!have)
+					for (;;) {
+						u64 mh = __ballot(have), mf = __ballot(fin);
+						if (!(mh | mf))
+							break;
+						/* the finish/claim path is long; run it for many
+						 * lanes at once instead of in every iteration */
+						if (mf && (__builtin_popcountll(mf) >= 20 || !mh)) {
+							if (fin) {
+								if (best < 4 && maxlen >= 3 && min_len <= 3)
+									bestd = find_len3(L, p, cur, L->nxtA[4 + my_i],
+											  p - lo_pos, mode ? 8192u : 4096u,
+											  &best);
+								L->M[4 + my_i] = best >= min_len && best >= 3 && bestd ?
+									(best | (bestd << 16)) : 0;
+								fin = false;
+								my_i = nx_i;
+								have = my_i < TILE;
+								if (have) {
+									p = t + my_i;
+									cur = ncur;
+									c16 = nc16;
+									maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
+									dep = p + 4 <= n ? depth : 0;
+									best = 3;
+									bestd = 0;
+									dprev = 0;
+									nx_i = atomicAdd(&L->vars[V_CTR], 1u);
+									if (nx_i < TILE) {
+										ncur = ld32(L->in, t + nx_i);
+										nc16 = L->prev[(t + nx_i) & RMASK];
+									}
+								}
+							}
 							continue;
+						}
+						/* one chain step, predicated (no early exit: the
+						 * cooperative part below needs all 64 lanes) */
 						u32 d = (p - c16) & 0xFFFF;
-						bool stop = !(dep && d > dprev && d <= p - lo_pos);
-						if (!stop) {
-							u32 cp = p - d;
+						bool stop = have && !(dep && d > dprev && d <= p - lo_pos);
+						bool go = have && !stop;
+						u32 cp = p - d, len = 4;
+						bool cand = false, more = false;
+						if (go) {
 							u32 w = ld32(L->in, cp);
 							c16 = L->prev[cp & RMASK];
 							dprev = d;
 							dep--;
-							if (w == cur &&
+							cand = w == cur &&
 							    !(best >= 4 && best < maxlen &&
 							      L->in[(cp + best) & RMASK] !=
-							      L->in[(p + best) & RMASK])) {
-								u32 len = 4;
-								while (len < maxlen) {
-									u64 x = ld64(L->in, p + len) ^
-										ld64(L->in, cp + len);
-									if (x) {
-										len += (u32)__builtin_ctzll(x) >> 3;
-										break;
-									}
-									len += 8;
-								}
-								if (len > maxlen)
-									len = maxlen;
-								if (len > best) {
-									best = len;
-									bestd = d;
-									if (len >= nice || len >= maxlen)
-										stop = true;
+							      L->in[(p + best) & RMASK]);
+							if (cand && len < maxlen) {
+								/* bytes 4..11 by the lane itself */
+								u64 x = ld64(L->in, p + 4) ^ ld64(L->in, cp + 4);
+								if (x) {
+									len += (u32)__builtin_ctzll(x) >> 3;
+								} else {
+									len = 12;
+									more = len < maxlen;
 								}
 							}
 						}
-						if (stop) {
-							if (best < 4 && maxlen >= 3 && min_len <= 3)
-								bestd = find_len3(L, p, cur, L->nxtA[4 + my_i],
-										  p - lo_pos, mode ? 8192u : 4096u,
-										  &best);
-							L->M[4 + my_i] = best >= min_len && best >= 3 && bestd ?
-								(best | (bestd << 16)) : 0;
-							my_i = nx_i;
-							have = my_i < TILE;
-							if (have) {
-								p = t + my_i;
-								cur = ncur;
-								c16 = nc16;
-								maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
-								dep = p + 4 <= n ? depth : 0;
-								best = 3;
-								bestd = 0;
-								dprev = 0;
-								nx_i = atomicAdd(&L->vars[V_CTR], 1u);
-								if (nx_i < TILE) {
-									ncur = ld32(L->in, t + nx_i);
-									nc16 = L->prev[(t + nx_i) & RMASK];
-								}
+						/* longer than 12 bytes: the WAVE finishes the
+						 * extension of one such lane at a time, 4 bytes per
+						 * lane = up to 256 bytes in one pass, instead of one
+						 * lane looping with 63 lanes idle */
+						for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
+							u32 src = (u32)__builtin_ctzll(mm);
+							u32 bp = bcast_lane(p, src);
+							u32 bc = bcast_lane(cp, src);
+							u32 bmax = bcast_lane(maxlen, src);
+							u32 off = 12 + 4 * lane;
+							u32 x4 = off < bmax ?
+								(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
+							u64 ne = __ballot(x4 != 0);
+							u32 tot = bmax;	/* 12 + 256 >= 258 */
+							if (ne) {
+								u32 k = (u32)__builtin_ctzll(ne);
+								u32 xk = bcast_lane(x4, k);
+								u32 o = 12 + 4 * k;
+								if (o < bmax)
+									tot = o + ((u32)__builtin_ctz(xk) >> 3);
 							}
+							if (lane == src)
+								len = tot;
+						}
+						if (cand) {
+							if (len > maxlen)
+								len = maxlen;
+							if (len > best) {
+								best = len;
+								bestd = d;
+								if (len >= nice || len >= maxlen)
+									stop = true;
+							}
+						}
+						if (stop) {
+							have = false;
+							fin = true;
 						}
 					}
 				}

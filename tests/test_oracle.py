@@ -106,3 +106,41 @@ def test_live_against_reference(oracle, ref):
     for n in (0, 1, 4999, 5000, 5001, 65536, 1 << 20):
         for fmt in ("deflate", "zlib", "gzip"):
             assert oracle.bound(fmt, n) == ref.bound(fmt, n)
+
+
+def test_oracle_compressor_roundtrip_and_bound(oracle):
+    """The restated compressor policy: valid streams (checked by the restated
+    decoder AND by zlib), within compress_bound, all levels / formats / the
+    edge sizes of SURVEY.md §8(d)."""
+    wb = {"deflate": -15, "zlib": 15, "gzip": 31}
+    sizes = [0, 1, 18, 19, 20, 31, 32, 51, 52, 511, 512, 4999, 5000, 5001,
+             65535, 65536, 65537, 125500]
+    for i, n in enumerate(sizes):
+        d = datagen.chunk(i, n, 0x0E110030) if n != 125500 else streams.litrunlen_input()
+        for lvl in (0, 1, 3, 6, 9, 12):
+            for fmt in ("deflate", "zlib", "gzip"):
+                z = oracle.compress(fmt, lvl, d)
+                assert z is not None and len(z) <= oracle.bound(fmt, n)
+                assert zlib.decompress(z, wb[fmt]) == d
+                r = oracle.decompress_ex(fmt, z, n)
+                assert (r[0], r[1], r[3]) == (0, len(z), d)
+                # "0 when it does not fit" (libdeflate.h:73-74)
+                assert oracle.compress(fmt, lvl, d, len(z) - 1) is None
+
+
+def test_oracle_compressor_tracks_reference(oracle, ref):
+    """Sizes of the restatement vs the real reference on the 64 KiB mix:
+    levels 2-9 follow the same parser / block-split / Huffman policy and land
+    within 0.5 %; level 1 uses the hash-chain finder (the reference has a
+    separate 2-way hash table there) and is allowed to be smaller."""
+    chunks = [datagen.chunk(i, 65536, 0x0E110003) for i in range(8)]
+    for lvl in (0, 1, 2, 4, 5, 6, 8, 9):
+        ours = sum(len(oracle.compress("deflate", lvl, c)) for c in chunks)
+        theirs = sum(len(ref.compress("deflate", lvl, c)) for c in chunks)
+        for c in chunks[:3]:
+            z = oracle.compress("gzip", lvl, c)
+            assert ref.decompress_ex("gzip", z, len(c))[3] == c
+        if lvl == 1:
+            assert ours <= theirs * 1.02
+        else:
+            assert abs(ours - theirs) <= theirs * 0.005, (lvl, ours, theirs)
