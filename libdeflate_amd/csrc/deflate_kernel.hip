@@ -913,17 +913,19 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					const u32 lim_idx = (u32)(limit + 4);
 					u32 span = (u32)(limit - entry > 0 ? limit - entry : 0);
 					for (u32 reachd = 1; reachd < span; reachd <<= 1) {
-						for (u32 idx = tid; idx < lim_idx; idx += NT) {
-							if (L->mark[idx]) {
-								u32 q = J[idx];
-								if (q < lim_idx)
-									L->mark[q] = 1;
-							}
-						}
-						__syncthreads();
+						/* one barrier per round: marks only ever grow, and a
+						 * mark seen "early" still marks a position that is
+						 * really on the path, so mark propagation and the
+						 * doubling of J can share a pass */
 						for (u32 idx = tid; idx < lim_idx; idx += NT) {
 							u32 q = J[idx];
-							Jn[idx] = q < lim_idx ? J[q] : (u16)q;
+							if (q < lim_idx) {
+								if (L->mark[idx])
+									L->mark[q] = 1;
+								Jn[idx] = J[q];
+							} else {
+								Jn[idx] = (u16)q;
+							}
 						}
 						__syncthreads();
 						u16 *tmp = J; J = Jn; Jn = tmp;
