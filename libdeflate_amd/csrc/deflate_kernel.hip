@@ -756,133 +756,150 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 
 				PROF_MARK(3);
 				/* ---- S3: all positions search their chain ----
-				 * Chain lengths differ wildly between positions, so the
-				 * lanes do not own fixed positions: a lane claims the next
-				 * unsearched position from a workgroup counter as soon as
-				 * it finishes one (the claim and the position's first
-				 * loads are issued one position ahead, off the critical
-				 * path).  Every loop iteration is one chain step for every
-				 * lane that has work. */
+				 * Chain lengths differ wildly between positions, so lanes
+				 * do not own fixed positions: a lane claims the next
+				 * unsearched position from a workgroup counter when it
+				 * finishes one.  Each lane walks TWO chains at a time (the
+				 * LDS round trips of the two overlap), one step of each per
+				 * loop iteration; the long finish/claim path runs for many
+				 * lanes at once; match extension beyond 12 bytes is done by
+				 * the whole wave, 256 bytes per pass. */
 				{
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
-					u32 my_i = atomicAdd(&L->vars[V_CTR], 1u);
-					u32 nx_i = atomicAdd(&L->vars[V_CTR], 1u);
-					u32 p = t + my_i;
-					u32 cur = 0, c16 = 0, ncur = 0, nc16 = 0;
-					if (my_i < TILE) {
-						cur = ld32(L->in, p);
-						c16 = L->prev[p & RMASK];
-					}
-					if (nx_i < TILE) {
-						ncur = ld32(L->in, t + nx_i);
-						nc16 = L->prev[(t + nx_i) & RMASK];
-					}
-					bool have = my_i < TILE;
-					bool fin = false;	/* finished, result not yet stored */
-					u32 maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
-					u32 dep = p + 4 <= n ? depth : 0;
-					u32 best = 3, bestd = 0, dprev = 0;
 					const u32 min_len = L->vars[V_MINLEN];
+					const u32 dlim3 = mode ? 8192u : 4096u;
+					u32 my_i[2], p[2], cur[2], c16[2], maxlen[2], dep[2],
+					    best[2], bestd[2], dprev[2];
+					bool have[2], fin[2];
+#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						my_i[k] = 0xFFFFFFFFu;
+						have[k] = false;
+						fin[k] = true;	/* "needs a position" */
+						p[k] = cur[k] = c16[k] = maxlen[k] = dep[k] = 0;
+						best[k] = 3;
+						bestd[k] = dprev[k] = 0;
+					}
 					for (;;) {
-						u64 mh = __ballot(have), mf = __ballot(fin);
-						if (!(mh | mf))
+						u64 mh = __ballot(have[0] | have[1]);
+						u32 nf = __builtin_popcountll(__ballot(fin[0])) +
+							 __builtin_popcountll(__ballot(fin[1]));
+						if (!mh && !nf)
 							break;
-						/* the finish/claim path is long; run it for many
-						 * lanes at once instead of in every iteration */
-						if (mf && (__builtin_popcountll(mf) >= 20 || !mh)) {
-							if (fin) {
-								if (best < 4 && maxlen >= 3 && min_len <= 3)
-									bestd = find_len3(L, p, cur, L->nxtA[4 + my_i],
-											  p - lo_pos, mode ? 8192u : 4096u,
-											  &best);
-								L->M[4 + my_i] = best >= min_len && best >= 3 && bestd ?
-									(best | (bestd << 16)) : 0;
-								fin = false;
-								my_i = nx_i;
-								have = my_i < TILE;
-								if (have) {
-									p = t + my_i;
-									cur = ncur;
-									c16 = nc16;
-									maxlen = p < n ? (n - p < 258 ? n - p : 258) : 0;
-									dep = p + 4 <= n ? depth : 0;
-									best = 3;
-									bestd = 0;
-									dprev = 0;
-									nx_i = atomicAdd(&L->vars[V_CTR], 1u);
-									if (nx_i < TILE) {
-										ncur = ld32(L->in, t + nx_i);
-										nc16 = L->prev[(t + nx_i) & RMASK];
+						if (nf && (nf >= 40 || !mh)) {
+#pragma unroll
+							for (int k = 0; k < 2; k++) {
+								if (!fin[k])
+									continue;
+								if (my_i[k] < TILE) {
+									if (best[k] < 4 && maxlen[k] >= 3 && min_len <= 3)
+										bestd[k] = find_len3(L, p[k], cur[k],
+											L->nxtA[4 + my_i[k]],
+											p[k] - lo_pos, dlim3, &best[k]);
+									L->M[4 + my_i[k]] =
+										best[k] >= min_len && best[k] >= 3 && bestd[k] ?
+										(best[k] | (bestd[k] << 16)) : 0;
+								}
+								fin[k] = false;
+								my_i[k] = atomicAdd(&L->vars[V_CTR], 1u);
+								if (my_i[k] < TILE) {
+									p[k] = t + my_i[k];
+									if (p[k] + 4 <= n) {
+										cur[k] = ld32(L->in, p[k]);
+										c16[k] = L->prev[p[k] & RMASK];
+										maxlen[k] = n - p[k] < 258 ? n - p[k] : 258;
+										dep[k] = depth;
+										best[k] = 3;
+										bestd[k] = 0;
+										dprev[k] = 0;
+										have[k] = true;
+									} else {
+										/* last 3 bytes: a length-3 match at most */
+										cur[k] = ld32(L->in, p[k]);
+										maxlen[k] = p[k] < n ? n - p[k] : 0;
+										best[k] = 3;
+										bestd[k] = 0;
+										fin[k] = true;
 									}
 								}
 							}
 							continue;
 						}
-						/* one chain step, predicated (no early exit: the
-						 * cooperative part below needs all 64 lanes) */
-						u32 d = (p - c16) & 0xFFFF;
-						bool stop = have && !(dep && d > dprev && d <= p - lo_pos);
-						bool go = have && !stop;
-						u32 cp = p - d, len = 4;
-						bool cand = false, more = false;
-						if (go) {
-							u32 w = ld32(L->in, cp);
-							c16 = L->prev[cp & RMASK];
-							dprev = d;
-							dep--;
-							cand = w == cur &&
-							    !(best >= 4 && best < maxlen &&
-							      L->in[(cp + best) & RMASK] !=
-							      L->in[(p + best) & RMASK]);
-							if (cand && len < maxlen) {
-								/* bytes 4..11 by the lane itself */
-								u64 x = ld64(L->in, p + 4) ^ ld64(L->in, cp + 4);
+						/* one chain step per chain, predicated */
+						u32 d[2], cp[2], len[2], w[2];
+						bool go[2], cand[2], more[2], stop[2];
+#pragma unroll
+						for (int k = 0; k < 2; k++) {
+							d[k] = (p[k] - c16[k]) & 0xFFFF;
+							stop[k] = have[k] && !(dep[k] && d[k] > dprev[k] &&
+									       d[k] <= p[k] - lo_pos);
+							go[k] = have[k] && !stop[k];
+							cp[k] = p[k] - d[k];
+							len[k] = 4;
+							w[k] = 0;
+							if (go[k]) {
+								w[k] = ld32(L->in, cp[k]);
+								c16[k] = L->prev[cp[k] & RMASK];
+								dprev[k] = d[k];
+								dep[k]--;
+							}
+						}
+#pragma unroll
+						for (int k = 0; k < 2; k++) {
+							cand[k] = go[k] && w[k] == cur[k] &&
+							    !(best[k] >= 4 && best[k] < maxlen[k] &&
+							      L->in[(cp[k] + best[k]) & RMASK] !=
+							      L->in[(p[k] + best[k]) & RMASK]);
+							more[k] = false;
+							if (cand[k] && 4 < maxlen[k]) {
+								u64 x = ld64(L->in, p[k] + 4) ^
+									ld64(L->in, cp[k] + 4);
 								if (x) {
-									len += (u32)__builtin_ctzll(x) >> 3;
+									len[k] += (u32)__builtin_ctzll(x) >> 3;
 								} else {
-									len = 12;
-									more = len < maxlen;
+									len[k] = 12;
+									more[k] = 12 < maxlen[k];
 								}
 							}
 						}
-						/* longer than 12 bytes: the WAVE finishes the
-						 * extension of one such lane at a time, 4 bytes per
-						 * lane = up to 256 bytes in one pass, instead of one
-						 * lane looping with 63 lanes idle */
-						for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
-							u32 src = (u32)__builtin_ctzll(mm);
-							u32 bp = bcast_lane(p, src);
-							u32 bc = bcast_lane(cp, src);
-							u32 bmax = bcast_lane(maxlen, src);
-							u32 off = 12 + 4 * lane;
-							u32 x4 = off < bmax ?
-								(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
-							u64 ne = __ballot(x4 != 0);
-							u32 tot = bmax;	/* 12 + 256 >= 258 */
-							if (ne) {
-								u32 k = (u32)__builtin_ctzll(ne);
-								u32 xk = bcast_lane(x4, k);
-								u32 o = 12 + 4 * k;
-								if (o < bmax)
-									tot = o + ((u32)__builtin_ctz(xk) >> 3);
+#pragma unroll
+						for (int k = 0; k < 2; k++) {
+							for (u64 mm = __ballot(more[k]); mm; mm &= mm - 1) {
+								u32 src = (u32)__builtin_ctzll(mm);
+								u32 bp = bcast_lane(p[k], src);
+								u32 bc = bcast_lane(cp[k], src);
+								u32 bmax = bcast_lane(maxlen[k], src);
+								u32 off = 12 + 4 * lane;
+								u32 x4 = off < bmax ?
+									(ld32(L->in, bp + off) ^
+									 ld32(L->in, bc + off)) : 1;
+								u64 ne = __ballot(x4 != 0);
+								u32 tot = bmax;	/* 12 + 256 >= 258 */
+								if (ne) {
+									u32 kk = (u32)__builtin_ctzll(ne);
+									u32 xk = bcast_lane(x4, kk);
+									u32 o = 12 + 4 * kk;
+									if (o < bmax)
+										tot = o + ((u32)__builtin_ctz(xk) >> 3);
+								}
+								if (lane == src)
+									len[k] = tot;
 							}
-							if (lane == src)
-								len = tot;
-						}
-						if (cand) {
-							if (len > maxlen)
-								len = maxlen;
-							if (len > best) {
-								best = len;
-								bestd = d;
-								if (len >= nice || len >= maxlen)
-									stop = true;
+							if (cand[k]) {
+								if (len[k] > maxlen[k])
+									len[k] = maxlen[k];
+								if (len[k] > best[k]) {
+									best[k] = len[k];
+									bestd[k] = d[k];
+									if (len[k] >= nice || len[k] >= maxlen[k])
+										stop[k] = true;
+								}
 							}
-						}
-						if (stop) {
-							have = false;
-							fin = true;
+							if (stop[k]) {
+								have[k] = false;
+								fin[k] = true;
+							}
 						}
 					}
 				}
