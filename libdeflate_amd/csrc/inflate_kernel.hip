@@ -439,6 +439,19 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
 				st8(pend_dst + 16, pv2);                      \
 			if (pend_n > 3)                                       \
 				st8(pend_dst + 24, pv3);                      \
+			/* the copied bytes are now known: refresh the history */ \
+			if (pend_len <= 8) {                                  \
+				hist = pend_len == 8 ? pv0 :                  \
+				       (hist >> (8 * pend_len)) |             \
+				       (pv0 << (8 * (8 - pend_len)));         \
+				hist_n = hist_n + pend_len > 8 ? 8 : hist_n + pend_len; \
+			} else {                                              \
+				u32 o_ = pend_len - 8, j_ = o_ >> 3, sh_ = (o_ & 7) * 8; \
+				u64 a_ = j_ == 0 ? pv0 : j_ == 1 ? pv1 : j_ == 2 ? pv2 : pv3; \
+				u64 b_ = j_ == 0 ? pv1 : j_ == 1 ? pv2 : pv3; \
+				hist = sh_ ? (a_ >> sh_) | (b_ << (64 - sh_)) : a_; \
+				hist_n = 8;                                   \
+			}                                                     \
 			pend_n = 0;                                           \
 		}                                                             \
 	} while (0)
@@ -464,7 +477,8 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 	PROF_DECL;
 	PROF_START();
 #ifdef LDA_PROFILE
-	unsigned long long pa_dec = 0, pa_flush = 0, pa_out = 0, pa_rounds = 0, pt_ = 0;
+	unsigned long long pc_reg = 0, pc_pipe = 0, pc_slow = 0, pc_slowbytes = 0;
+	unsigned long long pa_dec = 0, pa_flush = 0, pa_out = 0, pa_rounds = 0, pt_ = 0, pt2_ = 0;
 #define SEG_T0() do { pt_ = __builtin_readcyclecounter(); } while (0)
 #define SEG_ADD(acc) do { unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pt_; pt_ = n_; } while (0)
 #else
@@ -549,8 +563,13 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 	u64 stored_left = 0;
 	u64 pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;	/* loaded, not yet stored */
 	u8 *pend_dst = outp;
-	u32 pend_n = 0;
+	u32 pend_n = 0, pend_len = 0;
+	/* the lane's last hist_n (<= 8) output bytes, newest in the top byte:
+	 * matches at distance <= hist_n never touch memory for their source */
+	u64 hist = 0;
+	u32 hist_n = 0;
 	const u64 limit_bits = 8 * in_n + 8;	/* see header comment */
+	(void)limit_bits;
 
 	while (__ballot(state != ST_DONE)) {
 		/* ------------ block headers (lanes that need one) ------------ */
@@ -747,7 +766,13 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			if (__ballot(state == ST_HDR || state == ST_TABLES))
 				break;
 #ifdef LDA_PROFILE
-			pa_out++;	/* all iterations of this wave */
+			{	/* whole-iteration time, all iterations of this wave */
+				unsigned long long n2_ = __builtin_readcyclecounter();
+				if (pa_out)
+					pa_flush += n2_ - pt2_;
+				pt2_ = n2_;
+				pa_out++;
+			}
 #endif
 			if (state != ST_TOK)
 				continue;
@@ -756,12 +781,15 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			if (filled < rpos + 64)
 				ENSURE_INPUT();
 			REFILL();
-			if (CONSUMED() > limit_bits) {
+			/* "consumed > 8*in_n + 8" with 56..63 bits buffered is
+			 * exactly "rpos > in_n + 8" */
+			if (rpos > in_n + 8) {
 				result = LDA_BAD_DATA;
 				state = ST_DONE;
 				continue;
 			}
 			u32 e = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+			FLUSH_PENDING();
 			u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
 			if (cl == 0) {
 				u32 sym = decode_long(&S->lit, S->lit_sorted, bitbuf, &cl);
@@ -770,8 +798,6 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			}
 			CONSUME(cl);
 			SEG_ADD(pa_dec);
-			FLUSH_PENDING();
-			SEG_ADD(pa_flush);
 #ifdef LDA_PROFILE
 			pa_rounds++;
 #endif
@@ -781,7 +807,23 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 					state = ST_DONE;
 					continue;
 				}
-				outp[out_pos++] = (u8)pay;
+				/* a second literal in the same round when no end-of-input
+				 * rule can interfere (>= 16 input bytes left) and the
+				 * 41+ bits still buffered hold its whole codeword */
+				u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+				if ((e1 & 0xC00F) > K_LIT && (e1 & 0xC000) == K_LIT &&
+				    rpos + 16 < in_n && out_pos + 1 < out_avail) {
+					u16 two = (u16)(pay | (((e1 >> 4) & 0xFF) << 8));
+					__builtin_memcpy(outp + out_pos, &two, 2);
+					out_pos += 2;
+					CONSUME(e1 & 15);
+					hist = (hist >> 16) | ((u64)two << 48);
+					hist_n = hist_n + 2 > 8 ? 8 : hist_n + 2;
+				} else {
+					outp[out_pos++] = (u8)pay;
+					hist = (hist >> 8) | ((u64)pay << 56);
+					hist_n = hist_n + 1 > 8 ? 8 : hist_n + 1;
+				}
 				continue;
 			}
 			if (kind == K_EOB) {
@@ -813,7 +855,28 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			/* the lane copies from its own earlier output; short
 			 * non-overlapping copies are split: loads now, stores at the
 			 * next token, so the HBM/L2 round trip overlaps the decode */
-			{
+			if (dist <= hist_n && length <= 8 && out_pos + 8 <= out_avail) {
+				/* source entirely in the register history: expand the
+				 * period in registers, one 8-byte store (the bytes past
+				 * 'length' are overwritten by the following tokens) */
+				u64 pat = hist >> (8 * (8 - dist));
+				u32 sh = 8 * dist;
+				if (sh < 64)
+					pat |= pat << sh;
+				sh *= 2;
+				if (sh < 64)
+					pat |= pat << sh;
+				sh *= 2;
+				if (sh < 64)
+					pat |= pat << sh;
+				st8(outp + out_pos, pat);
+#ifdef LDA_PROFILE
+				pc_reg++;
+#endif
+				hist = length == 8 ? pat :
+				       (hist >> (8 * length)) | (pat << (8 * (8 - length)));
+				hist_n = hist_n + length > 8 ? 8 : hist_n + length;
+			} else {
 				u32 nwords = (length + 7) >> 3;
 				u32 maxw = dist >> 3;
 				if (nwords <= 4 && nwords <= maxw &&
@@ -821,6 +884,10 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 					const u8 *src = outp + out_pos - dist;
 					pend_dst = outp + out_pos;
 					pend_n = nwords;
+					pend_len = length;
+#ifdef LDA_PROFILE
+					pc_pipe++;
+#endif
 					pv0 = ld8(src);
 					if (nwords > 1)
 						pv1 = ld8(src + 8);
@@ -829,6 +896,10 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 					if (nwords > 3)
 						pv3 = ld8(src + 24);
 				} else {
+#ifdef LDA_PROFILE
+					pc_slow++; pc_slowbytes += length;
+#endif
+					hist_n = 0;
 					copy_match(outp, out_pos, out_avail, dist, length);
 				}
 			}
@@ -844,6 +915,12 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 		atomicAdd(&lda_prof[5], pa_flush);
 		atomicAdd(&lda_prof[6], pa_rounds);
 		atomicAdd(&lda_prof[7], pa_out);
+	}
+	{
+		atomicAdd(&lda_prof[8], pc_reg);
+		atomicAdd(&lda_prof[9], pc_pipe);
+		atomicAdd(&lda_prof[10], pc_slow);
+		atomicAdd(&lda_prof[11], pc_slowbytes);
 	}
 #endif
 	if (owner) {
