@@ -165,13 +165,14 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		if (v >= 1 && v <= 64)
 			lpw = (uint32_t)v;
 	}
-	size_t lds = lda_inflate_lds_per_stream() * lpw;
+	size_t lds = lda_inflate_lds_per_stream() * lpw + lda_inflate_lds_shared();
 	static bool attr_set[16];
 	if (!attr_set[c->device]) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_inflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)(lda_inflate_lds_per_stream() * 64)),
+				(int)(lda_inflate_lds_per_stream() * 64 +
+				      lda_inflate_lds_shared())),
 			    LIBDEFLATE_AMD_NO_DEVICE);
 		attr_set[c->device] = true;
 	}

@@ -76,6 +76,12 @@ struct stream_lds {
 __constant__ u8 c_pre_perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 				   12, 3, 13, 2, 14, 1, 15 };
 
+/* per-workgroup tables for the fast loop: symbol -> base | extra bits << 16 */
+struct shared_lds {
+	u32 len_tab[32];
+	u32 dist_tab[32];
+};
+
 enum { ST_HDR = 0, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
 
 /* length / offset symbol -> base and extra-bit count, computed instead of
@@ -399,12 +405,32 @@ static __device__ __forceinline__ void
 ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
 {
 	u32 slot = (u32)at & 64;
+
+	if (at + 72 <= in_n) {
+		/* common case: nine aligned words, all loads in flight together,
+		 * then funnel-shifted into place */
+		uintptr_t a = (uintptr_t)(inp + at);
+		const u64 *w = (const u64 *)(a & ~(uintptr_t)7);
+		u32 sh = (u32)(a & 7) * 8;
+		u64 v[9];
 #pragma unroll
+		for (u32 k = 0; k < 9; k++)
+			v[k] = w[k];
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			u64 x = sh ? (v[k] >> sh) | (v[k + 1] << (64 - sh)) : v[k];
+			__builtin_memcpy(ring + slot + 8 * k, &x, 8);
+			if (slot == 0 && k == 0)
+				__builtin_memcpy(ring + 128, &x, 8);
+		}
+		return;
+	}
+#pragma unroll 1
 	for (u32 k = 0; k < 8; k++) {
-		u64 v = load_in(inp, in_n, at + 8 * k);
-		__builtin_memcpy(ring + slot + 8 * k, &v, 8);
+		u64 x = load_in(inp, in_n, at + 8 * k);
+		__builtin_memcpy(ring + slot + 8 * k, &x, 8);
 		if (slot == 0 && k == 0)
-			__builtin_memcpy(ring + 128, &v, 8);
+			__builtin_memcpy(ring + 128, &x, 8);
 	}
 }
 
@@ -474,6 +500,15 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 	const u64 c = (u64)blockIdx.x * lpw + lane;
 	const bool owner = lane < lpw && c < n_chunks;
 	struct stream_lds *S = &SL[lane < lpw ? lane : 0];
+	struct shared_lds *SH = (struct shared_lds *)&SL[lpw];
+	if (lane < 32) {
+		u32 b, x;
+		len_sym(lane, &b, &x);
+		SH->len_tab[lane] = b | (x << 16);
+		off_sym(lane, &b, &x);
+		SH->dist_tab[lane] = b | (x << 16);
+	}
+	wave_sync();
 	PROF_DECL;
 	PROF_START();
 #ifdef LDA_PROFILE
@@ -757,8 +792,117 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			state = final_block ? ST_DONE : ST_HDR;
 		}
 
-		/* ------------ tokens: one per lane per round ------------ */
-		for (u32 round = 0; round < 4096; round++) {
+		/* ------------ fast token loop ------------
+		 * While every active stream has >= 16 input bytes and >= 272
+		 * output bytes left, none of the end-of-buffer rules can fire
+		 * (the reference's fastloop, decompress_template.h:344-671, rests
+		 * on the same argument), so the per-token checks reduce to
+		 * "distance <= bytes written".  Anything unusual - a codeword
+		 * longer than the table, a bad distance, a stream near one of its
+		 * ends, a new block - leaves to the general loop below, which
+		 * re-reads the same token with all checks. */
+		for (;;) {
+			bool tok = state == ST_TOK;
+			bool elig = tok && rpos + 16 < in_n && out_pos + 272 <= out_avail;
+			if (!__ballot(tok) || __ballot(tok != elig) ||
+			    __ballot(state == ST_HDR || state == ST_TABLES))
+				break;
+			bool punt = false;
+			if (tok) {
+				if (filled < rpos + 64)
+					ENSURE_INPUT();
+				REFILL();
+				u32 e = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+				FLUSH_PENDING();
+				u32 cl = e & 15;
+				if (cl == 0) {
+					punt = true;
+				} else if ((e & 0xC000) == K_LIT) {
+					u32 pay = (e >> 4) & 0xFF;
+					CONSUME(cl);
+					u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+					if ((e1 & 15) && (e1 & 0xC000) == K_LIT) {
+						u16 two = (u16)(pay | (((e1 >> 4) & 0xFF) << 8));
+						__builtin_memcpy(outp + out_pos, &two, 2);
+						out_pos += 2;
+						CONSUME(e1 & 15);
+						hist = (hist >> 16) | ((u64)two << 48);
+						hist_n = hist_n + 2 > 8 ? 8 : hist_n + 2;
+					} else {
+						outp[out_pos++] = (u8)pay;
+						hist = (hist >> 8) | ((u64)pay << 56);
+						hist_n = hist_n + 1 > 8 ? 8 : hist_n + 1;
+					}
+				} else if ((e & 0xC000) == K_EOB) {
+					CONSUME(cl);
+					state = final_block ? ST_DONE : ST_HDR;
+				} else {
+					/* match: decode on a copy of the bit buffer, commit
+					 * only if the distance is valid */
+					u64 bb = bitbuf >> cl;
+					u32 lt = SH->len_tab[(e >> 4) & 31];
+					u32 xb = lt >> 16;
+					u32 length = (lt & 0xFFFF) + ((u32)bb & ((1u << xb) - 1));
+					bb >>= xb;
+					u32 used = cl + xb;
+					u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
+					u32 ol = e2 & 15;
+					u32 dt = SH->dist_tab[(e2 >> 4) & 31];
+					bb >>= ol;
+					xb = dt >> 16;
+					u32 dist = (dt & 0xFFFF) + ((u32)bb & ((1u << xb) - 1));
+					bb >>= xb;
+					used += ol + xb;
+					if (ol == 0 || dist > out_pos) {
+						punt = true;
+					} else {
+						bitbuf = bb;
+						bitcnt -= used;
+						if (dist <= hist_n && length <= 8) {
+							u64 pat = hist >> (8 * (8 - dist));
+							u32 sh = 8 * dist;
+							if (sh < 64)
+								pat |= pat << sh;
+							sh *= 2;
+							if (sh < 64)
+								pat |= pat << sh;
+							sh *= 2;
+							if (sh < 64)
+								pat |= pat << sh;
+							st8(outp + out_pos, pat);
+							hist = length == 8 ? pat :
+							       (hist >> (8 * length)) |
+							       (pat << (8 * (8 - length)));
+							hist_n = hist_n + length > 8 ? 8 : hist_n + length;
+						} else {
+							u32 nwords = (length + 7) >> 3;
+							if (nwords <= 4 && nwords <= (dist >> 3)) {
+								const u8 *src = outp + out_pos - dist;
+								pend_dst = outp + out_pos;
+								pend_n = nwords;
+								pend_len = length;
+								pv0 = ld8(src);
+								if (nwords > 1)
+									pv1 = ld8(src + 8);
+								if (nwords > 2)
+									pv2 = ld8(src + 16);
+								if (nwords > 3)
+									pv3 = ld8(src + 24);
+							} else {
+								hist_n = 0;
+								copy_match(outp, out_pos, out_avail, dist, length);
+							}
+						}
+						out_pos += length;
+					}
+				}
+			}
+			if (__ballot(punt))
+				break;
+		}
+
+		/* ------------ tokens: one per lane per round (all checks) ------------ */
+		for (u32 round = 0; round < 4; round++) {
 			u64 tk = __ballot(state == ST_TOK);
 			if (!tk)
 				break;
@@ -943,6 +1087,11 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 extern "C" size_t lda_inflate_lds_per_stream(void)
 {
 	return sizeof(struct stream_lds);
+}
+
+extern "C" size_t lda_inflate_lds_shared(void)
+{
+	return sizeof(struct shared_lds);
 }
 
 /*

@@ -46,6 +46,7 @@ lda_deflate_batch_kernel(uint64_t n_chunks, int format, int level,
 extern "C" size_t lda_deflate_lds_bytes(void);
 
 extern "C" size_t lda_inflate_lds_per_stream(void);
+extern "C" size_t lda_inflate_lds_shared(void);
 
 /* CRC constant tables, generated on the host at first use (host_api.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)

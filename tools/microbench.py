@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=16384)
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--kind", type=int, default=-1, help="use only chunk kind k (0-7) of the mix")
     ap.add_argument("--level", type=int, default=6)
     a = ap.parse_args()
     chunks, data, offs, nb = make_batch(a.chunks, a.size, 0x0E110003)
@@ -89,6 +90,8 @@ def bench_inflate(a, fmt="gzip", level=6):
     ref = oracle_util.load_ref()
     distinct = 64
     chunks = datagen.batch(a.chunks, a.size, 0x0E110004, distinct=distinct)
+    if a.kind >= 0:
+        chunks = [datagen.chunk(a.kind + 8 * (i % 8), a.size, 0x0E110004) for i in range(a.chunks)]
     comp = [ref.compress(fmt, level, c) if ref else streams._zcompress(fmt, level, c)
             for c in chunks[:distinct]]
     offs, blob, sizes = [], bytearray(), []
