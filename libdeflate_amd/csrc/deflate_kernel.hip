@@ -299,9 +299,19 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
  *   - fewer than two used symbols -> two 1-bit codewords
  *     (lib/deflate_compress.c:1369-1378).
  */
-static __device__ void
+template <int N> struct huff_scratch {
+	u32 A[N];	/* leaf weights, later hop pointers */
+	u32 NW[N];	/* internal node weights, later depths */
+	u32 P[N];	/* parent of each internal node */
+	u32 cntI[40];	/* internal nodes per depth */
+	u32 cnt[40];	/* leaves per depth (code lengths) */
+	u32 start[16];	/* first index in sorted[] for each length */
+	u32 nc[16];	/* next canonical codeword per length */
+};
+
+template <int N> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
-	  u16 *sorted, u32 *A, u32 used, bool presorted, u32 lane)
+	  u16 *sorted, huff_scratch<N> *H, u32 used, bool presorted, u32 lane)
 {
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
@@ -326,111 +336,179 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		}
 	}
 	wave_sync();
-	if (used < 2) {
+	const u32 m = used;
+	if (m < 2) {
 		if (lane == 0) {
-			u32 s = used ? sorted[0] : 0;
+			u32 s = m ? sorted[0] : 0;
 			u32 other = s ? 0 : 1;
 			lens[s] = 1;
 			lens[other] = 1;
+			for (u32 d = 0; d < 16; d++)
+				H->cnt[d] = 0;
+			H->cnt[1] = 2;
 		}
 		wave_sync();
 	} else {
+		for (u32 i = lane; i < m; i += 64)
+			H->A[i] = freq[sorted[i]];
+		if (lane < 40)
+			H->cntI[lane] = 0;
+		wave_sync();
 		if (lane == 0) {
-			/* in-place Huffman (Moffat & Katajainen) on A[0..used) */
-			u32 m = used;
-			for (u32 i = 0; i < m; i++)
-				A[i] = freq[sorted[i]];
-			u32 leaf = 0, root = 0;
-			for (u32 next = 0; next + 1 < m; next++) {
+			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
+			 * creation order (ascending too); heads cached in registers */
+			u32 leaf = 0, node = 0;
+			u32 wl = H->A[0], wn = 0xFFFFFFFFu;
+			for (u32 k = 0; k + 1 < m; k++) {
 				u32 w;
-				if (leaf >= m || (root < next && A[root] < A[leaf])) {
-					w = A[root]; A[root++] = next;
+				if (leaf < m && wl <= wn) {
+					w = wl;
+					leaf++;
+					wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
 				} else {
-					w = A[leaf++];
+					w = wn;
+					H->P[node] = k;
+					node++;
+					wn = node < k ? H->NW[node] : 0xFFFFFFFFu;
 				}
-				if (leaf >= m || (root < next && A[root] < A[leaf])) {
-					w += A[root]; A[root++] = next;
+				if (leaf < m && wl <= wn) {
+					w += wl;
+					leaf++;
+					wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
 				} else {
-					w += A[leaf++];
+					w += wn;
+					H->P[node] = k;
+					node++;
+					wn = node < k ? H->NW[node] : 0xFFFFFFFFu;
 				}
-				A[next] = w;
+				H->NW[k] = w;
+				if (node == k)
+					wn = w;	/* the new node is the only one queued */
 			}
-			/* internal node depths */
-			A[m - 2] = 0;
-			for (s32 j = (s32)m - 3; j >= 0; j--)
-				A[j] = A[A[j]] + 1;
-			/* leaf depths: count per depth, clamp later */
-			u32 cnt[40];
-			for (u32 i = 0; i < 40; i++)
-				cnt[i] = 0;
-			s32 avail = 1, usedn = 0, depth = 0;
-			s32 rootj = (s32)m - 2, nextl = (s32)m - 1;
-			while (avail > 0) {
-				while (rootj >= 0 && (s32)A[rootj] == depth) {
-					usedn++;
-					rootj--;
-				}
-				while (avail > usedn) {
-					cnt[depth < 39 ? depth : 39]++;
-					nextl--;
-					avail--;
-				}
-				avail = 2 * usedn;
-				depth++;
-				usedn = 0;
+		}
+		wave_sync();
+		/* depth of every internal node by pointer jumping (root = m-2) */
+		{
+			const u32 root = m - 2;
+			u32 dd[5], hh[5];
+#pragma unroll
+			for (u32 j = 0; j < 5; j++) {
+				u32 k = lane + 64 * j;
+				dd[j] = (k < root) ? 1 : 0;
+				hh[j] = (k < root) ? H->P[k] : root;
 			}
-			(void)nextl;
+			wave_sync();
+#pragma unroll
+			for (u32 j = 0; j < 5; j++) {
+				u32 k = lane + 64 * j;
+				if (k <= root) {
+					H->NW[k] = dd[j];
+					H->A[k] = hh[j];
+				}
+			}
+			wave_sync();
+			for (u32 r = 0; r < 6; r++) {	/* depth < 64 */
+#pragma unroll
+				for (u32 j = 0; j < 5; j++) {
+					u32 k = lane + 64 * j;
+					if (k <= root) {
+						u32 h = H->A[k];
+						dd[j] = H->NW[k] + H->NW[h];
+						hh[j] = H->A[h];
+					}
+				}
+				wave_sync();
+#pragma unroll
+				for (u32 j = 0; j < 5; j++) {
+					u32 k = lane + 64 * j;
+					if (k <= root) {
+						H->NW[k] = dd[j];
+						H->A[k] = hh[j];
+					}
+				}
+				wave_sync();
+			}
+#pragma unroll
+			for (u32 j = 0; j < 5; j++) {
+				u32 k = lane + 64 * j;
+				if (k <= root)
+					atomicAdd(&H->cntI[dd[j] < 39 ? dd[j] : 39], 1u);
+			}
+			wave_sync();
+			/* leaves at depth d = 2 * internal(d-1) - internal(d) */
+			if (lane < 40)
+				H->cnt[lane] = lane ? 2 * H->cntI[lane - 1] - H->cntI[lane] : 0;
+			wave_sync();
+		}
+		if (lane == 0) {
 			/* clamp to maxlen, repair Kraft sum (zlib-style) */
 			u32 over = 0;
 			for (u32 d = maxlen + 1; d < 40; d++) {
-				over += cnt[d];
-				cnt[maxlen] += cnt[d];
-				cnt[d] = 0;
+				over += H->cnt[d];
+				H->cnt[maxlen] += H->cnt[d];
+				H->cnt[d] = 0;
 			}
 			if (over) {
-				/* kraft in units of 2^-maxlen */
 				u32 kraft = 0;
 				for (u32 d = 1; d <= maxlen; d++)
-					kraft += cnt[d] << (maxlen - d);
+					kraft += H->cnt[d] << (maxlen - d);
 				while (kraft > (1u << maxlen)) {
-					/* lengthen one codeword: pick the deepest
-					 * level < maxlen that has a leaf */
 					u32 d = maxlen - 1;
-					while (cnt[d] == 0)
+					while (H->cnt[d] == 0)
 						d--;
-					cnt[d]--;
-					cnt[d + 1] += 2;
-					cnt[maxlen]--;
-					kraft -= 1;	/* 2^-maxlen freed */
+					H->cnt[d]--;
+					H->cnt[d + 1] += 2;
+					H->cnt[maxlen]--;
+					kraft -= 1;
 				}
 			}
-			/* assign: rarest symbols get the longest codewords */
-			u32 i = 0;
-			for (u32 d = maxlen; d >= 1; d--)
-				for (u32 k = 0; k < cnt[d]; k++)
-					lens[sorted[i++]] = (u8)d;
+			/* rarest symbols get the longest codewords */
+			u32 at = 0;
+			for (u32 d = maxlen; d >= 1; d--) {
+				H->start[d] = at;
+				at += H->cnt[d];
+			}
+		}
+		wave_sync();
+		for (u32 i = lane; i < m; i += 64) {
+			u32 d = 1;
+			for (u32 q = 2; q <= maxlen; q++)
+				if (H->cnt[q] && i >= H->start[q] &&
+				    i < H->start[q] + H->cnt[q])
+					d = q;
+			lens[sorted[i]] = (u8)d;
 		}
 		wave_sync();
 	}
-	/* canonical codewords, bit-reversed (lane 0: n <= 288 steps) */
+	/* canonical codewords, bit-reversed: codes of one length go to the
+	 * symbols in increasing symbol order -> ballot ranks */
 	if (lane == 0) {
-		u32 bl[16], nc[16];
-		for (u32 d = 0; d < 16; d++)
-			bl[d] = 0;
-		for (u32 s = 0; s < n; s++)
-			bl[lens[s]]++;
-		bl[0] = 0;
 		u32 code = 0;
+		H->nc[0] = 0;
 		for (u32 d = 1; d < 16; d++) {
-			code = (code + bl[d - 1]) << 1;
-			nc[d] = code;
+			code = (code + (d > 1 ? H->cnt[d - 1] : 0)) << 1;
+			H->nc[d] = code;
 		}
-		for (u32 s = 0; s < n; s++) {
-			u32 l = lens[s];
-			if (l)
-				codes[s] = (u16)(__brev(nc[l]++) >> (32 - l));
-			else
-				codes[s] = 0;
+	}
+	wave_sync();
+	{
+		u32 run[16];
+#pragma unroll
+		for (u32 d = 1; d < 16; d++)
+			run[d] = H->nc[d];
+		for (u32 s0 = 0; s0 < n; s0 += 64) {
+			u32 s = s0 + lane;
+			u32 l = s < n ? lens[s] : 0;
+			u32 mycode = 0;
+#pragma unroll
+			for (u32 d = 1; d < 16; d++) {
+				u64 mm = __ballot(l == d);
+				if (l == d)
+					mycode = run[d] + __builtin_popcountll(mm & ((1ull << lane) - 1));
+				run[d] += __builtin_popcountll(mm);
+			}
+			if (s < n)
+				codes[s] = l ? (u16)(__brev(mycode) >> (32 - l)) : 0;
 		}
 	}
 	wave_sync();
@@ -1095,10 +1173,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					/* the two trees are built side by side on two waves */
 					if (wave == 0)
 						make_code(L->freq, 288, 15, L->lens, L->codes,
-							  L->sorted, L->hw, usedv[0], true, lane);
+							  L->sorted, (huff_scratch<288> *)(L->M + 512),
+							  usedv[0], true, lane);
 					else if (wave == 1)
 						make_code(L->freq + 288, 32, 15, L->lens + 288,
-							  L->codes + 288, sortedO, L->M + 360,
+							  L->codes + 288, sortedO,
+							  (huff_scratch<32> *)L->hw,
 							  usedv[1], true, lane);
 				}
 				__syncthreads();
@@ -1162,7 +1242,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				__syncthreads();
 				if (wave == 0)
 					make_code(L->pre_freq, 19, 7, L->pre_lens, L->pre_codes,
-						  L->sorted, L->hw, 0, false, lane);
+						  L->sorted, (huff_scratch<32> *)L->hw,
+						  0, false, lane);
 				__syncthreads();
 				/* exact costs (deflate_compress.c:1747-1808) */
 				u32 dyn = 0, stat = 0;
