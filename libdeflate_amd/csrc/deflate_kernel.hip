@@ -818,8 +818,14 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (m & M_LAST)
 								L->head[h] = (u16)(t + i);
 						}
-						/* 3-byte table: candidate = last position of an
-						 * EARLIER group with this hash (single slot) */
+						wave_sync();
+					}
+				} else if (wave == 1) {
+					/* 3-byte table, same order, on its own wave: candidate
+					 * = last position of an EARLIER group with this hash */
+					u32 ngroups = (tend - t + 63) / 64;
+					for (u32 g = 0; g < ngroups; g++) {
+						u32 i = g * 64 + lane;
 						u32 h3v = L->nxtB[4 + i];
 						u32 c3 = 0;
 						if (h3v)
