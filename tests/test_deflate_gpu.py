@@ -142,3 +142,37 @@ def test_device_batch_roundtrip(oracle):
             _check_roundtrip(oracle, fmt, chunks[i], z, (fmt, i))
         c.close()
         d.close()
+
+
+def test_small_blocks_zlib_level9(oracle):
+    """Config-5 shape at reduced count: 4 KiB filesystem-block mix, zlib,
+    level 9, device batch round trip + Adler-32 footers checked by the
+    decoder; a sample is also checked by the oracle."""
+    import torch
+    from libdeflate_amd import api
+    n, size = 8192, 4096
+    chunks = [datagen.chunk(i, size, 0x0E110005, datagen.MIX4K) for i in range(256)]
+    chunks = [chunks[i % 256] for i in range(n)]
+    data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+    c, d = api.Compressor(9), api.Decompressor()
+    bound = (c.bound("zlib", size) + 15) // 16 * 16
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+    in_n = torch.full((n,), size, dtype=torch.int64, device="cuda")
+    comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+    c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
+    c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
+    c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
+    c.compress_batch("zlib", data, in_off, in_n, comp, c_off, c_av, c_n)
+    out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+    res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    d.decompress_batch("zlib", comp, c_off, c_n, out, in_off, in_n, res)
+    torch.cuda.synchronize()
+    sizes = c_n.cpu().numpy()
+    assert (sizes > 0).all() and (sizes <= c.bound("zlib", size)).all()
+    assert int((res != 0).sum()) == 0
+    assert torch.equal(out, data)
+    cb = comp.cpu().numpy()
+    for i in range(0, 256, 17):
+        z = cb[i * bound:i * bound + sizes[i]].tobytes()
+        _check_roundtrip(oracle, "zlib", chunks[i], z, ("4k", i))
+    print("4 KiB zlib L9 ratio", sizes.sum() / (n * size))

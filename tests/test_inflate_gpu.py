@@ -152,3 +152,41 @@ def test_device_batch_bit_exact(dec):
     assert res.cpu().numpy().tolist() == [0] * n
     got = d_out.cpu().numpy().tobytes()
     assert got == b"".join(chunks)
+
+
+def test_many_streams_all_formats(dec):
+    """Config-4 shape at reduced count (16384 streams -> several streams per
+    wave): reference-compressed gzip / zlib / raw chunks of the 64 KiB mix,
+    decoded HBM to HBM with exact-fill semantics, every byte compared."""
+    import torch
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    n, size, distinct = 16384, 65536, 32
+    chunks = datagen.batch(distinct, size, 0x0E110004)
+    want = None
+    for fmt in ("gzip", "zlib", "deflate"):
+        comp = [ref.compress(fmt, 6, c) if ref else streams._zcompress(fmt, 6, c)
+                for c in chunks]
+        offs, blob, lens = [], bytearray(), []
+        for i in range(n):
+            z = comp[i % distinct]
+            offs.append(len(blob))
+            lens.append(len(z))
+            blob += z
+            blob += bytes((-len(blob)) % 16)
+        blob += bytes(64)
+        d_in = torch.frombuffer(blob, dtype=torch.uint8).cuda()
+        in_off = torch.tensor(offs, dtype=torch.int64).cuda()
+        in_n = torch.tensor(lens, dtype=torch.int64).cuda()
+        d_out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+        out_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+        out_av = torch.full((n,), size, dtype=torch.int64, device="cuda")
+        res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        dec.decompress_batch(fmt, d_in, in_off, in_n, d_out, out_off, out_av, res)
+        torch.cuda.synchronize()
+        assert int((res != 0).sum()) == 0
+        if want is None:
+            want = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+        assert torch.equal(d_out.view(n // distinct, distinct * size),
+                           want.expand(n // distinct, distinct * size))
+        del d_in, d_out

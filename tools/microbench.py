@@ -16,7 +16,8 @@ from tests import datagen
 
 
 def make_batch(count, size, seed, distinct=64):
-    chunks = datagen.batch(count, size, seed, distinct=distinct)
+    chunks = datagen.batch(count, size, seed, distinct=distinct,
+                           mix=datagen.MIX4K if size <= 4096 else datagen.MIX64K)
     blob = b"".join(chunks)
     data = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
     offs = torch.arange(count, dtype=torch.int64, device="cuda") * size
@@ -45,6 +46,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--kind", type=int, default=-1, help="use only chunk kind k (0-7) of the mix")
     ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--fmt", default="gzip")
     a = ap.parse_args()
     chunks, data, offs, nb = make_batch(a.chunks, a.size, 0x0E110003)
     total = a.chunks * a.size
@@ -56,9 +58,9 @@ def main():
             t = timeit(lambda: api.checksum_batch(kind, data, offs, nb, out))
             print(f"{kind}: {total/t/1e9:.1f} GB/s  ({t*1e3:.3f} ms for {total/2**20:.0f} MiB)")
     if a.what in ("inflate", "all"):
-        bench_inflate(a)
+        bench_inflate(a, fmt=a.fmt, level=min(a.level, 9))
     if a.what in ("deflate", "all"):
-        bench_deflate(a, level=a.level)
+        bench_deflate(a, fmt=a.fmt, level=a.level)
 
 
 PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
