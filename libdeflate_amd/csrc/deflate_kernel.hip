@@ -853,16 +853,17 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
 					const u32 min_len = L->vars[V_MINLEN];
 					const u32 dlim3 = mode ? 8192u : 4096u;
-					u32 my_i[2], cur[2], c16[2], maxlen[2], dep[2], bm[2], dprev[2];
+					u32 my_i[2], p[2], cur[2], c16[2], maxlen[2], dep[2],
+					    best[2], bestd[2], dprev[2];
 					bool have[2], fin[2];
 #pragma unroll
 					for (int k = 0; k < 2; k++) {
 						my_i[k] = 0xFFFFFFFFu;
 						have[k] = false;
 						fin[k] = true;	/* "needs a position" */
-						cur[k] = c16[k] = maxlen[k] = dep[k] = 0;
-						bm[k] = 3;
-						dprev[k] = 0;
+						p[k] = cur[k] = c16[k] = maxlen[k] = dep[k] = 0;
+						best[k] = 3;
+						bestd[k] = dprev[k] = 0;
 					}
 					for (;;) {
 						u64 mh = __ballot(have[0] | have[1]);
@@ -876,31 +877,33 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								if (!fin[k])
 									continue;
 								if (my_i[k] < TILE) {
-									u32 pk = t + my_i[k];
-									u32 bl = bm[k] & 0xFFFF, bd = bm[k] >> 16;
-									if (bl < 4 && maxlen[k] >= 3 && min_len <= 3)
-										bd = find_len3(L, pk, cur[k],
+									if (best[k] < 4 && maxlen[k] >= 3 && min_len <= 3)
+										bestd[k] = find_len3(L, p[k], cur[k],
 											L->nxtA[4 + my_i[k]],
-											pk - lo_pos, dlim3, &bl);
+											p[k] - lo_pos, dlim3, &best[k]);
 									L->M[4 + my_i[k]] =
-										bl >= min_len && bl >= 3 && bd ?
-										(bl | (bd << 16)) : 0;
+										best[k] >= min_len && best[k] >= 3 && bestd[k] ?
+										(best[k] | (bestd[k] << 16)) : 0;
 								}
 								fin[k] = false;
 								my_i[k] = atomicAdd(&L->vars[V_CTR], 1u);
 								if (my_i[k] < TILE) {
-									u32 pk = t + my_i[k];
-									cur[k] = ld32(L->in, pk);
-									bm[k] = 3;
-									if (pk + 4 <= n) {
-										c16[k] = L->prev[pk & RMASK];
-										maxlen[k] = n - pk < 258 ? n - pk : 258;
+									p[k] = t + my_i[k];
+									if (p[k] + 4 <= n) {
+										cur[k] = ld32(L->in, p[k]);
+										c16[k] = L->prev[p[k] & RMASK];
+										maxlen[k] = n - p[k] < 258 ? n - p[k] : 258;
 										dep[k] = depth;
+										best[k] = 3;
+										bestd[k] = 0;
 										dprev[k] = 0;
 										have[k] = true;
 									} else {
 										/* last 3 bytes: a length-3 match at most */
-										maxlen[k] = pk < n ? n - pk : 0;
+										cur[k] = ld32(L->in, p[k]);
+										maxlen[k] = p[k] < n ? n - p[k] : 0;
+										best[k] = 3;
+										bestd[k] = 0;
 										fin[k] = true;
 									}
 								}
@@ -908,11 +911,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							continue;
 						}
 						/* one chain step per chain, predicated */
-						u32 d[2], cp[2], len[2], w[2], p[2];
+						u32 d[2], cp[2], len[2], w[2];
 						bool go[2], cand[2], more[2], stop[2];
 #pragma unroll
 						for (int k = 0; k < 2; k++) {
-							p[k] = t + my_i[k];
 							d[k] = (p[k] - c16[k]) & 0xFFFF;
 							stop[k] = have[k] && !(dep[k] && d[k] > dprev[k] &&
 									       d[k] <= p[k] - lo_pos);
@@ -929,11 +931,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						}
 #pragma unroll
 						for (int k = 0; k < 2; k++) {
-							u32 bl = bm[k] & 0xFFFF;
 							cand[k] = go[k] && w[k] == cur[k] &&
-							    !(bl >= 4 && bl < maxlen[k] &&
-							      L->in[(cp[k] + bl) & RMASK] !=
-							      L->in[(p[k] + bl) & RMASK]);
+							    !(best[k] >= 4 && best[k] < maxlen[k] &&
+							      L->in[(cp[k] + best[k]) & RMASK] !=
+							      L->in[(p[k] + best[k]) & RMASK]);
 							more[k] = false;
 							if (cand[k] && 4 < maxlen[k]) {
 								u64 x = ld64(L->in, p[k] + 4) ^
@@ -972,8 +973,9 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (cand[k]) {
 								if (len[k] > maxlen[k])
 									len[k] = maxlen[k];
-								if (len[k] > (bm[k] & 0xFFFF)) {
-									bm[k] = len[k] | (d[k] << 16);
+								if (len[k] > best[k]) {
+									best[k] = len[k];
+									bestd[k] = d[k];
 									if (len[k] >= nice || len[k] >= maxlen[k])
 										stop[k] = true;
 								}
