@@ -144,3 +144,20 @@ def test_oracle_compressor_tracks_reference(oracle, ref):
             assert ours <= theirs * 1.02
         else:
             assert abs(ours - theirs) <= theirs * 0.005, (lvl, ours, theirs)
+
+
+def test_config1_reference_benchmark(tmp_path):
+    """BASELINE.json configs[0]: the unmodified programs/benchmark on a 1 MiB
+    enwik-style buffer, level 6, reference CPU path only (plumbing check)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "reftests",
+                       "benchmark_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/reftests/benchmark_ref not built")
+    f = tmp_path / "enwik1m.txt"
+    f.write_bytes(datagen.text_chunk(1 << 20, 0x0E110001))
+    r = subprocess.run([exe, "-6", str(f)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stdout.splitlines() if "Compressed 1048576 =>" in l][0]
+    pct = float(line.split("(")[1].split("%")[0])
+    assert 25.0 < pct < 40.0, line      # SURVEY §8(d): target ratio 30-38 %
