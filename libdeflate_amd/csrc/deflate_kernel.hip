@@ -61,6 +61,12 @@
 #define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile (min match 3) */
 #define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
 #define EWIN 1024u		/* encode window (positions) */
+#ifndef S3_WALK
+#define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
+#endif
+#ifndef S3_CLAIM
+#define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
+#endif
 #define STG_WORDS 1024u		/* 4 KiB staging */
 
 #define M_FIRST 0x10000u
@@ -843,117 +849,106 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				 * Chain lengths differ wildly between positions, so lanes
 				 * do not own fixed positions: a lane claims the next
 				 * unsearched position from a workgroup counter when it
-				 * finishes one.  Each lane walks TWO chains at a time (the
-				 * LDS round trips of the two overlap), one step of each per
-				 * loop iteration; the long finish/claim path runs for many
-				 * lanes at once; match extension beyond 12 bytes is done by
-				 * the whole wave, 256 bytes per pass. */
+				 * finishes one.  The kernel is instruction-issue bound, so
+				 * the search is split into two kinds of wave-uniform passes:
+				 *   walk      S3_WALK chain steps per lane, nothing but the
+				 *             link chase and the 4-byte compare; hits are
+				 *             queued (<= 4 distances packed in a u64);
+				 *   evaluate  every lane pops its oldest (closest) hit and
+				 *             measures it: 8 bytes against the cached bytes
+				 *             p+4..p+11, longer ones by the whole wave, 256
+				 *             bytes per pass.
+				 * Positions that end without a match >= 4 get their
+				 * length-3 probe in a separate position-parallel pass. */
 				{
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
 					const u32 min_len = L->vars[V_MINLEN];
 					const u32 dlim3 = mode ? 8192u : 4096u;
-					u32 my_i[2], p[2], cur[2], c16[2], maxlen[2], dep[2],
-					    best[2], bestd[2], dprev[2];
-					bool have[2], fin[2];
-#pragma unroll
-					for (int k = 0; k < 2; k++) {
-						my_i[k] = 0xFFFFFFFFu;
-						have[k] = false;
-						fin[k] = true;	/* "needs a position" */
-						p[k] = cur[k] = c16[k] = maxlen[k] = dep[k] = 0;
-						best[k] = 3;
-						bestd[k] = dprev[k] = 0;
-					}
+					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
+					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
+					    cnt = 0, boff = 0, curb = 0;
+					u64 nxt8 = 0, q = 0;
+					bool have = false, fin = true, ended = false;
+
 					for (;;) {
-						u64 mh = __ballot(have[0] | have[1]);
-						u32 nf = __builtin_popcountll(__ballot(fin[0])) +
-							 __builtin_popcountll(__ballot(fin[1]));
+						u64 mh = __ballot(have);
+						u32 nf = __builtin_popcountll(__ballot(fin));
 						if (!mh && !nf)
 							break;
-						if (nf && (nf >= 40 || !mh)) {
-#pragma unroll
-							for (int k = 0; k < 2; k++) {
-								if (!fin[k])
-									continue;
-								if (my_i[k] < TILE) {
-									if (best[k] < 4 && maxlen[k] >= 3 && min_len <= 3)
-										bestd[k] = find_len3(L, p[k], cur[k],
-											L->nxtA[4 + my_i[k]],
-											p[k] - lo_pos, dlim3, &best[k]);
-									L->M[4 + my_i[k]] =
-										best[k] >= min_len && best[k] >= 3 && bestd[k] ?
-										(best[k] | (bestd[k] << 16)) : 0;
-								}
-								fin[k] = false;
-								my_i[k] = atomicAdd(&L->vars[V_CTR], 1u);
-								if (my_i[k] < TILE) {
-									p[k] = t + my_i[k];
-									if (p[k] + 4 <= n) {
-										cur[k] = ld32(L->in, p[k]);
-										c16[k] = L->prev[p[k] & RMASK];
-										maxlen[k] = n - p[k] < 258 ? n - p[k] : 258;
-										dep[k] = depth;
-										best[k] = 3;
-										bestd[k] = 0;
-										dprev[k] = 0;
-										have[k] = true;
+						if (nf && (nf >= S3_CLAIM || !mh)) {
+							PROF_COUNT(12, 1);
+							PROF_COUNT(13, nf);
+							if (fin) {
+								if (my_i < TILE)
+									L->M[4 + my_i] =
+										best >= 4 && best >= min_len ?
+										(best | (bestd << 16)) : 0;
+								fin = false;
+								best = 3;
+								my_i = atomicAdd(&L->vars[V_CTR], 1u);
+								if (my_i < TILE) {
+									p = t + my_i;
+									if (p + 4 <= n) {
+										cur = ld32(L->in, p);
+										curb = cur;
+										boff = 0;
+										nxt8 = ld64(L->in, p + 4);
+										c16 = L->prev[p & RMASK];
+										maxlen = n - p < 258 ? n - p : 258;
+										dmaxp = p - lo_pos;
+										dep = depth;
+										bestd = 0;
+										dprev = 0;
+										cnt = 0;
+										ended = false;
+										have = true;
 									} else {
-										/* last 3 bytes: a length-3 match at most */
-										cur[k] = ld32(L->in, p[k]);
-										maxlen[k] = p[k] < n ? n - p[k] : 0;
-										best[k] = 3;
-										bestd[k] = 0;
-										fin[k] = true;
+										fin = true;	/* M = 0; len 3 later */
 									}
 								}
 							}
 							continue;
 						}
-						/* one chain step per chain, predicated */
-						u32 d[2], cp[2], len[2], w[2];
-						bool go[2], cand[2], more[2], stop[2];
+						/* walk */
+						PROF_COUNT(14, 1);
 #pragma unroll
-						for (int k = 0; k < 2; k++) {
-							d[k] = (p[k] - c16[k]) & 0xFFFF;
-							stop[k] = have[k] && !(dep[k] && d[k] > dprev[k] &&
-									       d[k] <= p[k] - lo_pos);
-							go[k] = have[k] && !stop[k];
-							cp[k] = p[k] - d[k];
-							len[k] = 4;
-							w[k] = 0;
-							if (go[k]) {
-								w[k] = ld32(L->in, cp[k]);
-								c16[k] = L->prev[cp[k] & RMASK];
-								dprev[k] = d[k];
-								dep[k]--;
-							}
+						for (int s = 0; s < S3_WALK; s++) {
+							u32 d = (p - c16) & 0xFFFF;
+							bool ok = !ended && dep && d > dprev && d <= dmaxp;
+							u32 cp = p - d;
+							u32 w = ld32(L->in, cp + boff);
+							u32 c16n = L->prev[cp & RMASK];
+							bool hit = ok && w == curb;
+							PROF_COUNT(15, __builtin_popcountll(__ballot(ok)));
+							PROF_COUNT(16, __builtin_popcountll(__ballot(hit)));
+							c16 = ok ? c16n : c16;
+							dprev = ok ? d : dprev;
+							dep -= ok ? 1 : 0;
+							ended = ended || !ok;
+							q = hit ? ((q << 16) | d) : q;
+							cnt += hit ? 1 : 0;
 						}
-#pragma unroll
-						for (int k = 0; k < 2; k++) {
-							cand[k] = go[k] && w[k] == cur[k] &&
-							    !(best[k] >= 4 && best[k] < maxlen[k] &&
-							      L->in[(cp[k] + best[k]) & RMASK] !=
-							      L->in[(p[k] + best[k]) & RMASK]);
-							more[k] = false;
-							if (cand[k] && 4 < maxlen[k]) {
-								u64 x = ld64(L->in, p[k] + 4) ^
-									ld64(L->in, cp[k] + 4);
-								if (x) {
-									len[k] += (u32)__builtin_ctzll(x) >> 3;
-								} else {
-									len[k] = 12;
-									more[k] = 12 < maxlen[k];
-								}
-							}
-						}
-#pragma unroll
-						for (int k = 0; k < 2; k++) {
-							for (u64 mm = __ballot(more[k]); mm; mm &= mm - 1) {
+						if (!have)
+							cnt = 0;
+						/* evaluate */
+						bool done = false;
+						while (__ballot(cnt > 0)) {
+							bool ev = cnt > 0;
+							PROF_COUNT(17, 1);
+							u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
+							cnt -= ev ? 1 : 0;
+							u32 cp = p - d;
+							u64 x = nxt8 ^ ld64(L->in, cp + 4);
+							u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
+							ev = ev && ld32(L->in, cp) == cur;
+							bool more = ev && x == 0 && 12 < maxlen;
+							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
 								u32 src = (u32)__builtin_ctzll(mm);
-								u32 bp = bcast_lane(p[k], src);
-								u32 bc = bcast_lane(cp[k], src);
-								u32 bmax = bcast_lane(maxlen[k], src);
+								PROF_COUNT(18, 1);
+								u32 bp = bcast_lane(p, src);
+								u32 bc = bcast_lane(cp, src);
+								u32 bmax = bcast_lane(maxlen, src);
 								u32 off = 12 + 4 * lane;
 								u32 x4 = off < bmax ?
 									(ld32(L->in, bp + off) ^
@@ -968,22 +963,44 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										tot = o + ((u32)__builtin_ctz(xk) >> 3);
 								}
 								if (lane == src)
-									len[k] = tot;
+									len = tot;
 							}
-							if (cand[k]) {
-								if (len[k] > maxlen[k])
-									len[k] = maxlen[k];
-								if (len[k] > best[k]) {
-									best[k] = len[k];
-									bestd[k] = d[k];
-									if (len[k] >= nice || len[k] >= maxlen[k])
-										stop[k] = true;
+							if (ev) {
+								if (len > maxlen)
+									len = maxlen;
+								if (len > best) {
+									best = len;
+									bestd = d;
+									if (len >= nice || len >= maxlen) {
+										done = true;
+										cnt = 0;
+									} else {
+										boff = len - 3;
+										curb = ld32(L->in, p + boff);
+									}
 								}
 							}
-							if (stop[k]) {
-								have[k] = false;
-								fin[k] = true;
-							}
+						}
+						if (have && (ended || done)) {
+							have = false;
+							fin = true;
+						}
+					}
+				}
+				__syncthreads();
+				/* length-3 matches for the positions left without a match */
+				if (L->vars[V_MINLEN] <= 3) {
+					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
+					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
+					const u32 dlim3 = mode ? 8192u : 4096u;
+					for (u32 i = tid; i < TILE; i += NT) {
+						u32 p = t + i, b3 = 0;
+						if (p + 3 <= n && L->M[4 + i] == 0) {
+							u32 bd = find_len3(L, p, ld32(L->in, p),
+									   L->nxtA[4 + i], p - lo_pos,
+									   dlim3, &b3);
+							if (bd)
+								L->M[4 + i] = 3 | (bd << 16);
 						}
 					}
 				}

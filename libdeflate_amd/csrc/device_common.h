@@ -130,7 +130,14 @@ static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 #define PROF_MARK(slot) do { if (threadIdx.x == 0) { \
 		unsigned long long n_ = __builtin_readcyclecounter(); \
 		atomicAdd(&lda_prof[slot], n_ - prof_t_); prof_t_ = n_; } } while (0)
+#ifdef LDA_PROFILE_COUNTS	/* event counters distort the phase times */
+#define PROF_COUNT(slot, v) do { if (threadIdx.x == 0) \
+		atomicAdd(&lda_prof[slot], (unsigned long long)(v)); } while (0)
 #else
+#define PROF_COUNT(slot, v) do { } while (0)
+#endif
+#else
+#define PROF_COUNT(slot, v) do { } while (0)
 #define PROF_DECL
 #define PROF_START() do { } while (0)
 #define PROF_MARK(slot) do { } while (0)

@@ -64,7 +64,9 @@ def main():
 
 
 PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
-                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header"]
+                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header", "-", "-",
+                  "#claim passes(w0)", "#claimed lanes", "#walk passes", "#lane steps",
+                  "#hits", "#eval rounds", "#coop passes"]
 
 
 def read_profile(name, labels):
