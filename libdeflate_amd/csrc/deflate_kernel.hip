@@ -319,6 +319,7 @@ template <int N> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 	  u16 *sorted, huff_scratch<N> *H, u32 used, bool presorted, u32 lane)
 {
+	PROF_SEC_DECL;
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
 	if (!presorted) {
@@ -360,6 +361,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		if (lane < 40)
 			H->cntI[lane] = 0;
 		wave_sync();
+		PROF_SEC(0);
 		if (lane == 0) {
 			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
 			 * creation order (ascending too); heads cached in registers */
@@ -393,6 +395,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			}
 		}
 		wave_sync();
+		PROF_SEC(1);
 		/* depth of every internal node by pointer jumping (root = m-2) */
 		{
 			const u32 root = m - 2;
@@ -446,6 +449,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 				H->cnt[lane] = lane ? 2 * H->cntI[lane - 1] - H->cntI[lane] : 0;
 			wave_sync();
 		}
+		PROF_SEC(2);
 		if (lane == 0) {
 			/* clamp to maxlen, repair Kraft sum (zlib-style) */
 			u32 over = 0;
@@ -518,6 +522,9 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		}
 	}
 	wave_sync();
+	PROF_SEC(3);
+	if (N == 288)
+		PROF_SEC_FLUSH(17);
 }
 
 /* ---------------- bit output through the LDS staging area ---------------- */
@@ -812,34 +819,63 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				/* ---- S2: thread groups through head[] in order ---- */
 				if (tid == NT - 1)
 					L->vars[V_CTR] = 0;
+				/* A wave's LDS operations execute in issue order, so the
+				 * read-old-head / write-new-head pairs of all groups are
+				 * issued back to back (no wait in between); the values read
+				 * are stored to prev[] afterwards. */
 				if (wave == 0) {
-					u32 ngroups = (tend - t + 63) / 64;
-					for (u32 g = 0; g < ngroups; g++) {
-						u32 i = g * 64 + lane;
-						u32 m = L->M[4 + i];
-						u32 h = m & ((1u << HASH_BITS) - 1);
-						if (m & M_VALID) {
-							if (m & M_FIRST)
-								L->prev[(t + i) & RMASK] = L->head[h];
-							if (m & M_LAST)
-								L->head[h] = (u16)(t + i);
+					const u32 ngroups = (tend - t + 63) / 64;
+					enum { GB = 16 };	/* groups in flight */
+					for (u32 g0 = 0; g0 < ngroups; g0 += GB) {
+						u32 v[GB];
+#pragma unroll
+						for (u32 k = 0; k < GB; k++)
+							v[k] = g0 + k < ngroups ?
+								L->M[4 + (g0 + k) * 64 + lane] : 0;
+#pragma unroll
+						for (u32 k = 0; k < GB; k++) {
+							u32 m = v[k];
+							u32 h = m & ((1u << HASH_BITS) - 1);
+							u32 old = 0xFFFFFFFFu;
+							if (m & M_VALID) {
+								if (m & M_FIRST)
+									old = L->head[h];
+								if (m & M_LAST)
+									L->head[h] = (u16)(t + (g0 + k) * 64 + lane);
+							}
+							v[k] = old;
 						}
-						wave_sync();
+#pragma unroll
+						for (u32 k = 0; k < GB; k++)
+							if (v[k] != 0xFFFFFFFFu)
+								L->prev[(t + (g0 + k) * 64 + lane) & RMASK] =
+									(u16)v[k];
 					}
 				} else if (wave == 1) {
 					/* 3-byte table, same order, on its own wave: candidate
 					 * = last position of an EARLIER group with this hash */
-					u32 ngroups = (tend - t + 63) / 64;
-					for (u32 g = 0; g < ngroups; g++) {
-						u32 i = g * 64 + lane;
-						u32 h3v = L->nxtB[4 + i];
-						u32 c3 = 0;
-						if (h3v)
-							c3 = L->head3[h3v & 0xFFF];
-						L->nxtA[4 + i] = (u16)c3;
-						if (h3v)
-							L->head3[h3v & 0xFFF] = (u16)(t + i);
-						wave_sync();
+					const u32 ngroups = (tend - t + 63) / 64;
+					enum { GB = 16 };
+					for (u32 g0 = 0; g0 < ngroups; g0 += GB) {
+						u32 v[GB];
+#pragma unroll
+						for (u32 k = 0; k < GB; k++)
+							v[k] = g0 + k < ngroups ?
+								L->nxtB[4 + (g0 + k) * 64 + lane] : 0;
+#pragma unroll
+						for (u32 k = 0; k < GB; k++) {
+							u32 h3v = v[k], c3 = 0;
+							if (h3v) {
+								c3 = L->head3[h3v & 0xFFF];
+								L->head3[h3v & 0xFFF] =
+									(u16)(t + (g0 + k) * 64 + lane);
+							}
+							v[k] = c3;
+						}
+#pragma unroll
+						for (u32 k = 0; k < GB; k++)
+							if (g0 + k < ngroups)
+								L->nxtA[4 + (g0 + k) * 64 + lane] = (u16)v[k];
 					}
 				}
 				__syncthreads();
@@ -864,21 +900,20 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
 					const u32 min_len = L->vars[V_MINLEN];
-					const u32 dlim3 = mode ? 8192u : 4096u;
 					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 					    cnt = 0, boff = 0, curb = 0;
 					u64 nxt8 = 0, q = 0;
 					bool have = false, fin = true, ended = false;
+					PROF_SEC_DECL;
 
 					for (;;) {
+						PROF_SEC(3);
 						u64 mh = __ballot(have);
 						u32 nf = __builtin_popcountll(__ballot(fin));
 						if (!mh && !nf)
 							break;
 						if (nf && (nf >= S3_CLAIM || !mh)) {
-							PROF_COUNT(12, 1);
-							PROF_COUNT(13, nf);
 							if (fin) {
 								if (my_i < TILE)
 									L->M[4 + my_i] =
@@ -908,10 +943,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									}
 								}
 							}
+							PROF_SEC(0);
 							continue;
 						}
 						/* walk */
-						PROF_COUNT(14, 1);
 #pragma unroll
 						for (int s = 0; s < S3_WALK; s++) {
 							u32 d = (p - c16) & 0xFFFF;
@@ -920,8 +955,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							u32 w = ld32(L->in, cp + boff);
 							u32 c16n = L->prev[cp & RMASK];
 							bool hit = ok && w == curb;
-							PROF_COUNT(15, __builtin_popcountll(__ballot(ok)));
-							PROF_COUNT(16, __builtin_popcountll(__ballot(hit)));
 							c16 = ok ? c16n : c16;
 							dprev = ok ? d : dprev;
 							dep -= ok ? 1 : 0;
@@ -931,11 +964,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						}
 						if (!have)
 							cnt = 0;
+						PROF_SEC(1);
 						/* evaluate */
 						bool done = false;
 						while (__ballot(cnt > 0)) {
 							bool ev = cnt > 0;
-							PROF_COUNT(17, 1);
 							u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
 							cnt -= ev ? 1 : 0;
 							u32 cp = p - d;
@@ -945,7 +978,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							bool more = ev && x == 0 && 12 < maxlen;
 							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
 								u32 src = (u32)__builtin_ctzll(mm);
-								PROF_COUNT(18, 1);
 								u32 bp = bcast_lane(p, src);
 								u32 bc = bcast_lane(cp, src);
 								u32 bmax = bcast_lane(maxlen, src);
@@ -985,7 +1017,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							have = false;
 							fin = true;
 						}
+						PROF_SEC(2);
 					}
+					PROF_SEC_FLUSH(12);
+					__syncthreads();
+					PROF_MARK(16);
 				}
 				__syncthreads();
 				/* length-3 matches for the positions left without a match */
@@ -1193,6 +1229,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					else if (tid >= 288 && tid < 320 && L->freq[tid])
 						sortedO[rk[tid]] = (u16)(tid - 288);
 					__syncthreads();
+					PROF_MARK(10);
 					/* the two trees are built side by side on two waves */
 					if (wave == 0)
 						make_code(L->freq, 288, 15, L->lens, L->codes,
@@ -1205,69 +1242,105 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							  usedv[1], true, lane);
 				}
 				__syncthreads();
-				if (tid == 0) {
-					/* precode items: RLE of the lens
-					 * (deflate_compress.c:1482-1557 semantics) */
-					u32 nlit = 288, noff = 32;
-					while (nlit > 257 && L->lens[nlit - 1] == 0)
-						nlit--;
-					while (noff > 1 && L->lens[288 + noff - 1] == 0)
-						noff--;
-					for (u32 i = 0; i < 19; i++)
-						L->pre_freq[i] = 0;
-					u32 total = nlit + noff, ni = 0, i = 0;
-					while (i < total) {
-						u32 idx = i < nlit ? i : 288 + (i - nlit);
-						u32 v = L->lens[idx];
-						u32 run = 1;
-						while (i + run < total) {
-							u32 j = i + run;
-							u32 jdx = j < nlit ? j : 288 + (j - nlit);
-							if (L->lens[jdx] != v)
-								break;
-							run++;
+				PROF_MARK(11);
+				/* precode items: run-length coding of the code lengths
+				 * (deflate_compress.c:1482-1557 semantics), one thread per
+				 * length, then one thread per run */
+				{
+					u32 *starts = L->M;		/* [<= 321] run start indices */
+					if (tid == 0) {
+						L->vars[V_TMP1] = 257;
+						L->vars[V_TMP2] = 1;
+					}
+					if (tid < 19)
+						L->pre_freq[tid] = 0;
+					__syncthreads();
+					if (tid < 288 && tid >= 257 && L->lens[tid])
+						atomicMax(&L->vars[V_TMP1], tid + 1);
+					if (tid >= 288 && tid < 320 && L->lens[tid])
+						atomicMax(&L->vars[V_TMP2], tid - 288 + 1);
+					__syncthreads();
+					const u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
+					const u32 total = nlit + noff;
+					u32 v = 0, isst = 0;
+					if (tid < total) {
+						v = L->lens[tid < nlit ? tid : 288 + (tid - nlit)];
+						u32 pv = 0xFF;
+						if (tid)
+							pv = L->lens[tid - 1 < nlit ? tid - 1 :
+								     288 + (tid - 1 - nlit)];
+						isst = pv != v;
+					}
+					u32 nruns;
+					u32 ridx = block_scan(L, isst, &nruns);
+					if (isst)
+						starts[ridx] = tid;
+					if (tid == 0)
+						starts[nruns] = total;
+					__syncthreads();
+					/* thread r < nruns owns run r */
+					u32 rv = 0, rlen = 0, nitems = 0;
+					if (tid < nruns) {
+						u32 st = starts[tid];
+						rlen = starts[tid + 1] - st;
+						rv = L->lens[st < nlit ? st : 288 + (st - nlit)];
+						if (rv == 0) {
+							u32 full = rlen / 138, rem = rlen % 138;
+							nitems = full + (rem >= 3 ? 1 : rem);
+						} else if (rlen >= 4) {
+							u32 l1 = rlen - 1;
+							nitems = 1 + l1 / 6 + (l1 % 6 >= 3 ? 1 : l1 % 6);
+						} else {
+							nitems = rlen;
 						}
-						u32 left = run;
-						if (v == 0) {
+					}
+					u32 ni;
+					u32 at = block_scan(L, nitems, &ni);
+					if (tid < nruns) {
+						u32 left = rlen;
+						if (rv == 0) {
 							while (left >= 11) {
 								u32 r = left > 138 ? 138 : left;
-								L->pre_items[ni++] = 18 | ((r - 11) << 5);
-								L->pre_freq[18]++;
+								L->pre_items[at++] = 18 | ((r - 11) << 5);
+								atomicAdd(&L->pre_freq[18], 1u);
 								left -= r;
 							}
 							if (left >= 3) {
-								L->pre_items[ni++] = 17 | ((left - 3) << 5);
-								L->pre_freq[17]++;
+								L->pre_items[at++] = 17 | ((left - 3) << 5);
+								atomicAdd(&L->pre_freq[17], 1u);
 								left = 0;
 							}
 						} else if (left >= 4) {
-							L->pre_items[ni++] = (u16)v;
-							L->pre_freq[v]++;
+							L->pre_items[at++] = (u16)rv;
 							left--;
+							u32 n16 = 0;
 							while (left >= 3) {
 								u32 r = left > 6 ? 6 : left;
-								L->pre_items[ni++] = 16 | ((r - 3) << 5);
-								L->pre_freq[16]++;
+								L->pre_items[at++] = 16 | ((r - 3) << 5);
+								n16++;
 								left -= r;
 							}
+							atomicAdd(&L->pre_freq[16], n16);
+							atomicAdd(&L->pre_freq[rv], 1u);
 						}
+						if (left)
+							atomicAdd(&L->pre_freq[rv], left);
 						while (left) {
-							L->pre_items[ni++] = (u16)v;
-							L->pre_freq[v]++;
+							L->pre_items[at++] = (u16)rv;
 							left--;
 						}
-						i += run;
 					}
-					L->vars[V_NPRE] = ni;
-					L->vars[V_TMP1] = nlit;
-					L->vars[V_TMP2] = noff;
+					if (tid == 0)
+						L->vars[V_NPRE] = ni;
 				}
 				__syncthreads();
+				PROF_MARK(21);
 				if (wave == 0)
 					make_code(L->pre_freq, 19, 7, L->pre_lens, L->pre_codes,
 						  L->sorted, (huff_scratch<32> *)L->hw,
 						  0, false, lane);
 				__syncthreads();
+				PROF_MARK(22);
 				/* exact costs (deflate_compress.c:1747-1808) */
 				u32 dyn = 0, stat = 0;
 				if (tid < 320) {
@@ -1386,39 +1459,42 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					}
 					__syncthreads();
 				}
-				/* block header (thread 0; <= ~330 items) */
-				if (tid == 0) {
-					u64 b = os.bits;
-					stg_put(L, &os, b, is_final | (btype << 1), 3);
-					b += 3;
-					if (btype == 2) {
-						u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
-						u32 nexp = L->vars[V_TMP3];
+				/* block header: thread 0 the fixed fields, threads
+				 * 1..nexp the precode lengths, then one thread per
+				 * precode item; bit offsets by a workgroup scan */
+				{
+					u64 hcode = 0;
+					u32 hbits = 0;
+					const u32 nexp = btype == 2 ? L->vars[V_TMP3] : 0;
+					const u32 ni = btype == 2 ? L->vars[V_NPRE] : 0;
+					if (tid == 0) {
+						hcode = is_final | (btype << 1);
+						hbits = 3;
+						if (btype == 2) {
+							u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
+							hcode |= (u64)((nlit - 257) | ((noff - 1) << 5) |
+								       ((nexp - 4) << 10)) << 3;
+							hbits = 17;
+						}
+					} else if (tid <= nexp) {
 						static const u8 perm2[19] = { 16, 17, 18, 0, 8, 7,
 							9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-						stg_put(L, &os, b, (nlit - 257) | ((noff - 1) << 5) |
-							((nexp - 4) << 10), 14);
-						b += 14;
-						for (u32 i = 0; i < nexp; i++) {
-							stg_put(L, &os, b, L->pre_lens[perm2[i]], 3);
-							b += 3;
-						}
-						u32 ni = L->vars[V_NPRE];
-						for (u32 i = 0; i < ni; i++) {
-							u32 it = L->pre_items[i];
-							u32 sym = it & 31, ex = it >> 5;
-							u32 l = L->pre_lens[sym];
-							u32 xb = sym == 16 ? 2 : sym == 17 ? 3 :
-								 sym == 18 ? 7 : 0;
-							stg_put(L, &os, b, L->pre_codes[sym] |
-								((u64)ex << l), l + xb);
-							b += l + xb;
-						}
+						hcode = L->pre_lens[perm2[tid - 1]];
+						hbits = 3;
+					} else if (tid <= nexp + ni) {
+						u32 it = L->pre_items[tid - nexp - 1];
+						u32 sym = it & 31, ex = it >> 5;
+						u32 l = L->pre_lens[sym];
+						u32 xb = sym == 16 ? 2 : sym == 17 ? 3 :
+							 sym == 18 ? 7 : 0;
+						hcode = L->pre_codes[sym] | ((u64)ex << l);
+						hbits = l + xb;
 					}
-					L->vars[V_TMP0] = (u32)(b - os.bits);
+					u32 htot;
+					u32 hoff = block_scan(L, hbits, &htot);
+					stg_put(L, &os, os.bits + hoff, hcode, hbits);
+					os.bits += htot;
 				}
-				__syncthreads();
-				os.bits += L->vars[V_TMP0];
 				stg_flush(L, &os, false);
 
 				PROF_MARK(9);
