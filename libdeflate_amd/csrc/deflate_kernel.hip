@@ -60,14 +60,14 @@
 #define SEQ_CAP 3072u
 #define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile (min match 3) */
 #define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
-#define EWIN 1024u		/* encode window (positions) */
+#define EWIN 2048u		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
 #endif
 #ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
 #endif
-#define STG_WORDS 1024u		/* 4 KiB staging */
+#define STG_WORDS 1020u		/* staging: STG_WORDS + 8 words = sizeof nxtA */
 
 #define M_FIRST 0x10000u
 #define M_LAST 0x20000u
@@ -96,15 +96,15 @@ struct deflate_lds {
 		};
 		u16 nxtB[TILE + 8];	/* live only during the token choice */
 	};
-	u16 nxtA[TILE + 8];
-	u32 scan[NWAVES + 1];
+	u16 nxtA[TILE + 8] __attribute__((aligned(16)));	/* S6: bit staging */
+	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 vars[16];
 };
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3, V_CTR, V_MINLEN
+	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1
 };
 
 struct level_params {
@@ -169,17 +169,44 @@ static __device__ u32 block_scan(struct deflate_lds *L, u32 v, u32 *total)
 	u32 incl = wave_scan_incl(v);
 
 	if (lane == 63)
-		L->scan[wave] = incl;
+		L->scan[0][wave] = incl;
 	__syncthreads();
 	u32 base = 0, tot = 0;
 #pragma unroll
 	for (u32 w = 0; w < NWAVES; w++) {
-		u32 s = L->scan[w];
+		u32 s = L->scan[0][w];
 		if (w < wave)
 			base += s;
 		tot += s;
 	}
 	__syncthreads();
+	*total = tot;
+	return base + incl - v;
+}
+
+/* the same with ONE barrier: the partial sums alternate between two arrays
+ * (*tog flips per call, uniformly), so a fast thread's next call cannot
+ * overwrite what a slow thread still reads.  Every second call reuses an
+ * array, and the barrier of the call in between orders that. */
+static __device__ u32 block_scan1(struct deflate_lds *L, u32 v, u32 *total,
+				  u32 *tog)
+{
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	u32 incl = wave_scan_incl(v);
+	u32 *sc = L->scan[*tog];
+
+	*tog ^= 1;
+	if (lane == 63)
+		sc[wave] = incl;
+	__syncthreads();
+	u32 base = 0, tot = 0;
+#pragma unroll
+	for (u32 w = 0; w < NWAVES; w++) {
+		u32 s = sc[w];
+		if (w < wave)
+			base += s;
+		tot += s;
+	}
 	*total = tot;
 	return base + incl - v;
 }
@@ -540,7 +567,7 @@ struct outstate {
 
 static __device__ __forceinline__ u32 *stg_of(struct deflate_lds *L)
 {
-	return &L->M[EWIN];
+	return (u32 *)L->nxtA;
 }
 
 /* OR 'nbits' (<= 57) bits of 'code' at absolute bit position 'bitpos' */
@@ -589,8 +616,8 @@ stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
 				g[b - b0] = stgb[b];
 		}
 	}
-	__syncthreads();
-	/* slide the unfinished tail to the front */
+	/* slide the unfinished tail to the front; thread i both clears word i
+	 * and (for the few tail words) rewrites it, so no barrier in between */
 	u32 keep_from = units * 16;
 	u32 total_words = (u32)((os->bits - 8 * os->sg + 31) / 32) + 1;
 	u32 keep_words = final ? 0 : total_words - keep_from / 4;
@@ -600,11 +627,10 @@ stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
 	__syncthreads();
 	for (u32 i = tid; i < STG_WORDS + 8; i += NT)
 		stg[i] = 0;
-	__syncthreads();
 	if (tid < keep_words)
 		stg[tid] = v;
 	os->sg += keep_from;
-	__syncthreads();
+	/* callers put a barrier before the next stg_put by another thread */
 }
 
 /* bring back the few unfinished bytes saved in carry[] (the staging area
@@ -1422,6 +1448,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					for (u32 w0 = 0; w0 < piece; w0 += 2048) {
 						u32 cnt = piece - w0 < 2048 ? piece - w0 : 2048;
 						stg_flush(L, &os, false);
+						__syncthreads();
 						for (u32 j = tid; j < cnt; j += NT) {
 							u32 pos = bstart + done + w0 + j;
 							stg_put(L, &os, os.bits + 8ull * j,
@@ -1498,47 +1525,56 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				stg_flush(L, &os, false);
 
 				PROF_MARK(9);
-				/* tokens, EWIN positions at a time */
+				/* tokens, EWIN positions at a time.  Four barriers per
+				 * window: after the match scatter, in the bit-offset scan,
+				 * and two in the staging flush.  KD[] (what starts at each
+				 * position: 0 literal, len | dist << 16 match, ~0 covered)
+				 * is re-initialised for the next window by the thread that
+				 * just consumed the entry; the covered prefix and the match
+				 * count travel in two alternating pairs of LDS words. */
 				u32 *KD = L->M;
-				u32 seq_lo = 0;
-				if (tid == 0)
+				u32 seq_lo = 0, tog = 0;
+				for (u32 i = tid; i < EWIN; i += NT)
+					KD[i] = 0;
+				if (tid == 0) {
 					L->vars[V_SPILL] = 0;
+					L->vars[V_SPILL1] = 0;
+					L->vars[V_SEQCNT] = 0;
+					L->vars[V_SEQCNT1] = 0;
+				}
 				__syncthreads();
-				for (u32 w0 = bstart; w0 < bend; w0 += EWIN) {
+				u32 wpar = 0;
+				for (u32 w0 = bstart; w0 < bend; w0 += EWIN, wpar ^= 1) {
 					u32 wend = w0 + EWIN < bend ? w0 + EWIN : bend;
-					u32 spill = L->vars[V_SPILL];	/* covered prefix */
-					__syncthreads();
-					for (u32 i = tid; i < EWIN; i += NT)
-						KD[i] = i < spill ? 0xFFFFFFFFu : 0;
-					if (tid == 0)
-						L->vars[V_SPILL] = 0;
-					__syncthreads();
-					/* matches that start in this window */
-					u32 seq_hi = seq_lo;
+					const u32 v_spill_next = wpar ? V_SPILL : V_SPILL1;
+					const u32 v_cnt = wpar ? V_SEQCNT1 : V_SEQCNT;
+					/* matches that start in this window (the list is
+					 * position-sorted and holds < NT of them per window) */
 					{
-						/* seqs are position-sorted: find the range by a
-						 * strided scan (each thread tests its seqs) */
-						u32 cnt = 0;
-						for (u32 s = seq_lo + tid; s < nseq; s += NT) {
-							u32 pl = L->seq_pl[s];
+						u32 sidx = seq_lo + tid;
+						bool mine = false;
+						if (sidx < nseq) {
+							u32 pl = L->seq_pl[sidx];
 							u32 pos = bstart + (pl & 0xFFFF);
-							if (pos >= wend)
-								break;
-							u32 len = pl >> 16;
-							u32 q = pos - w0;
-							KD[q] = len | ((u32)L->seq_d[s] << 16);
-							for (u32 j = 1; j < len && q + j < EWIN; j++)
-								KD[q + j] = 0xFFFFFFFFu;
-							if (pos + len > w0 + EWIN)
-								atomicMax(&L->vars[V_SPILL],
-									  pos + len - (w0 + EWIN));
-							cnt++;
+							if (pos < wend) {
+								u32 len = pl >> 16;
+								u32 q = pos - w0;
+								mine = true;
+								KD[q] = len | ((u32)L->seq_d[sidx] << 16);
+								for (u32 j = 1; j < len && q + j < EWIN; j++)
+									KD[q + j] = 0xFFFFFFFFu;
+								if (pos + len > w0 + EWIN)
+									atomicMax(&L->vars[v_spill_next],
+										  pos + len - (w0 + EWIN));
+							}
 						}
-						u32 tot;
-						(void)block_scan(L, cnt, &tot);
-						seq_hi = seq_lo + tot;
+						u32 cw = __builtin_popcountll(__ballot(mine));
+						if (lane == 0 && cw)
+							atomicAdd(&L->vars[v_cnt], cw);
 					}
 					__syncthreads();
+					seq_lo += L->vars[v_cnt];
+					const u32 spill_next = L->vars[v_spill_next];
 					/* each thread: EPT consecutive positions */
 					enum { EPT = (EWIN + NT - 1) / NT };
 					u64 code[EPT];
@@ -1549,9 +1585,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						u32 pos = w0 + q;
 						code[k] = 0;
 						nb[k] = 0;
+						u32 kd = KD[q];
+						KD[q] = q < spill_next ? 0xFFFFFFFFu : 0;
 						if (pos >= wend)
 							continue;
-						u32 kd = KD[q];
 						if (kd == 0xFFFFFFFFu)
 							continue;
 						if (kd == 0) {
@@ -1581,16 +1618,22 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 #pragma unroll
 					for (u32 k = 0; k < EPT; k++)
 						mine += nb[k];
-					u32 off = block_scan(L, mine, &tot);
+					u32 off = block_scan1(L, mine, &tot, &tog);
+					/* everyone has read this window's words: clear them for
+					 * the window after the next one */
+					if (tid == 0) {
+						L->vars[v_cnt] = 0;
+						L->vars[wpar ? V_SPILL1 : V_SPILL] = 0;
+					}
 #pragma unroll
 					for (u32 k = 0; k < EPT; k++) {
 						stg_put(L, &os, os.bits + off, code[k], nb[k]);
 						off += nb[k];
 					}
 					os.bits += tot;
-					seq_lo = seq_hi;
 					stg_flush(L, &os, false);
 				}
+				__syncthreads();
 				/* end of block */
 				if (tid == 0)
 					stg_put(L, &os, os.bits, L->codes[256], L->lens[256]);
