@@ -1072,44 +1072,94 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				/* ---- S4: token choice by pointer jumping ----
 				 * step(p) is a pure function of M[p..p+2]; the chosen
 				 * tokens are the positions reachable from the entry point
-				 * by p -> p + step(p).  log2(TILE) doubling rounds mark
-				 * them all; idx = p + 4. */
+				 * by p -> p + step(p); idx = p + 4.  Each wave owns a
+				 * segment of 128 idx (the last one 132) and works without
+				 * workgroup barriers: 8 doubling rounds give, for every idx,
+				 * the first position its path reaches outside the segment;
+				 * after ONE barrier every wave chains the segment exits up
+				 * to its own entry point and marks its part of the path by
+				 * replaying the doubling steps from the largest down. */
 				{
 					const s32 entry = (s32)L->vars[V_ENTRY];
 					const s32 limit = last_tile ? (s32)(tend - t) :
 							  (s32)TILE - 2;
-					u16 *J = L->nxtA, *Jn = L->nxtB;
-					for (s32 idx = (s32)tid; idx < (s32)TILE + 4; idx += NT) {
-						s32 p = idx - 4;
-						u32 nx = (u32)(p < 0 ? 0 : p);
-						if (p >= -2 && p < limit)
-							nx = (u32)p + token_step(L->M[idx], L->M[idx + 1],
-										 L->M[idx + 2], mode, nice);
-						J[idx] = (u16)(nx + 4);	/* stored as idx */
-					}
-					if (tid == 0 && entry < limit)
-						L->mark[entry + 4] = 1;
-					__syncthreads();
 					const u32 lim_idx = (u32)(limit + 4);
-					u32 span = (u32)(limit - entry > 0 ? limit - entry : 0);
-					for (u32 reachd = 1; reachd < span; reachd <<= 1) {
-						/* one barrier per round: marks only ever grow, and a
-						 * mark seen "early" still marks a position that is
-						 * really on the path, so mark propagation and the
-						 * doubling of J can share a pass */
-						for (u32 idx = tid; idx < lim_idx; idx += NT) {
-							u32 q = J[idx];
-							if (q < lim_idx) {
-								if (L->mark[idx])
-									L->mark[q] = 1;
-								Jn[idx] = J[q];
-							} else {
-								Jn[idx] = (u16)q;
-							}
+					enum { SEG = TILE / NWAVES, JR = 7 };
+					/* wave w owns idx [4 + SEG w, 4 + SEG (w + 1)); the
+					 * carried-in idx 2, 3 can only be the entry itself */
+					const u32 seg_lo = 4 + SEG * wave, seg_hi = seg_lo + SEG;
+					u16 *J = L->nxtA, *Jn = L->nxtB;
+					u32 jh[JR][2], jc[2];	/* J^(2^r) of the own idx */
+#pragma unroll
+					for (u32 k = 0; k < 2; k++) {
+						u32 idx = seg_lo + lane + 64 * k;
+						u32 p = idx - 4;
+						u32 nx = p;
+						if ((s32)p < limit)
+							nx = p + token_step(L->M[idx], L->M[idx + 1],
+									    L->M[idx + 2], mode, nice);
+						jc[k] = nx + 4;	/* stored as idx */
+						J[idx] = (u16)jc[k];
+					}
+					wave_sync();
+#pragma unroll
+					for (u32 r = 0; r < JR; r++) {
+#pragma unroll
+						for (u32 k = 0; k < 2; k++) {
+							u32 idx = seg_lo + lane + 64 * k;
+							u32 q = jc[k];
+							jh[r][k] = q;
+							if (q < seg_hi && q < lim_idx)
+								jc[k] = J[q];
+							Jn[idx] = (u16)jc[k];
 						}
-						__syncthreads();
+						wave_sync();
 						u16 *tmp = J; J = Jn; Jn = tmp;
 					}
+					/* JR is odd: the segment exits are in nxtB */
+					__syncthreads();
+					PROF_MARK(12);
+					u32 e = (u32)(entry + 4);
+					for (u32 pre = 0; pre < 2; pre++) {	/* idx 2, 3 */
+						if (e < 4 && e < lim_idx) {
+							if (tid == 0)
+								L->mark[e] = 1;
+							e += token_step(L->M[e], L->M[e + 1],
+									L->M[e + 2], mode, nice);
+						}
+					}
+					for (u32 sgm = 0; sgm < wave; sgm++)
+						if (e < 4 + SEG * (sgm + 1) && e < lim_idx)
+							e = J[e];
+					bool mk[2];
+#pragma unroll
+					for (u32 k = 0; k < 2; k++) {
+						u32 idx = seg_lo + lane + 64 * k;
+						mk[k] = idx == e && e < lim_idx;
+					}
+#pragma unroll
+					for (s32 r = JR - 1; r >= 0; r--) {
+#pragma unroll
+						for (u32 k = 0; k < 2; k++) {
+							u32 q = jh[r][k];
+							if (mk[k] && q < seg_hi && q < lim_idx)
+								L->mark[q] = 1;
+						}
+						wave_sync();
+#pragma unroll
+						for (u32 k = 0; k < 2; k++) {
+							u32 idx = seg_lo + lane + 64 * k;
+							mk[k] = mk[k] || L->mark[idx];
+						}
+					}
+#pragma unroll
+					for (u32 k = 0; k < 2; k++) {
+						u32 idx = seg_lo + lane + 64 * k;
+						if (mk[k])
+							L->mark[idx] = 1;
+					}
+					__syncthreads();
+					PROF_MARK(13);
 					/* emit: thread owns OWN consecutive idx (thread NT-1
 					 * also the last 4), in position order */
 					enum { OWN = TILE / NT };

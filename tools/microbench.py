@@ -65,7 +65,7 @@ def main():
 
 PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
                   "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
-                  "S3 claim (w0)", "S3 walk (w0)", "S3 evaluate (w0)", "S3 loop (w0)",
+                  "S4 doubling", "S4 chain+mark", "S3 evaluate (w0)", "S3 loop (w0)",
                   "S3 total (w0)", "huff: setup", "huff: merge (lane 0)", "huff: depths",
                   "huff: lengths+codes", "S5 precode RLE (t0)", "S5 precode tree"]
 
