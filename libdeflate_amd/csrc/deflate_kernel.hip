@@ -670,6 +670,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
 	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
 	for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -1090,13 +1091,15 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					const u32 seg_lo = 4 + SEG * wave, seg_hi = seg_lo + SEG;
 					u16 *J = L->nxtA, *Jn = L->nxtB;
 					u32 jh[JR][2], jc[2];	/* J^(2^r) of the own idx */
+					u32 m0[2];		/* M of the own idx */
 #pragma unroll
 					for (u32 k = 0; k < 2; k++) {
 						u32 idx = seg_lo + lane + 64 * k;
 						u32 p = idx - 4;
 						u32 nx = p;
+						m0[k] = L->M[idx];
 						if ((s32)p < limit)
-							nx = p + token_step(L->M[idx], L->M[idx + 1],
+							nx = p + token_step(m0[k], L->M[idx + 1],
 									    L->M[idx + 2], mode, nice);
 						jc[k] = nx + 4;	/* stored as idx */
 						J[idx] = (u16)jc[k];
@@ -1120,12 +1123,39 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					__syncthreads();
 					PROF_MARK(12);
 					u32 e = (u32)(entry + 4);
+					const u32 seq0 = L->vars[V_NSEQ];
+					u32 npre = 0;
 					for (u32 pre = 0; pre < 2; pre++) {	/* idx 2, 3 */
 						if (e < 4 && e < lim_idx) {
-							if (tid == 0)
-								L->mark[e] = 1;
-							e += token_step(L->M[e], L->M[e + 1],
-									L->M[e + 2], mode, nice);
+							u32 mm = L->M[e];
+							u32 st = token_step(mm, L->M[e + 1], L->M[e + 2],
+									    mode, nice);
+							u32 l0 = mm & 0xFFFF;
+							bool ism = st == l0 && l0;
+							if (tid == 0) {
+								s32 np = (s32)e - 4 + (s32)st;
+								u32 pos = (u32)((s32)t + (s32)e - 4);
+								if (e + st >= lim_idx) {
+									L->vars[V_WALKPOS_LO] = (u32)((s32)t + np);
+									L->vars[V_ENTRY] = (u32)(np - (s32)TILE);
+								}
+								if (ism) {
+									u32 sl, xb, xv;
+									L->seq_pl[seq0 + npre] =
+										(pos - block_start) | (l0 << 16);
+									L->seq_d[seq0 + npre] = (u16)(mm >> 16);
+									length_code(l0, &sl, &xb, &xv);
+									atomicAdd(&L->freq[257 + sl], 1u);
+									dist_code(mm >> 16, &sl, &xb, &xv);
+									atomicAdd(&L->freq[288 + sl], 1u);
+								} else {
+									atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
+									if (st == 2)
+										atomicAdd(&L->freq[L->in[(pos + 1) & RMASK]], 1u);
+								}
+							}
+							npre += ism ? 1 : 0;
+							e += st;
 						}
 					}
 					for (u32 sgm = 0; sgm < wave; sgm++)
@@ -1152,32 +1182,34 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							mk[k] = mk[k] || L->mark[idx];
 						}
 					}
+					PROF_MARK(13);
+					/* emit: the lanes on the path classify their token,
+					 * count it for the block's Huffman codes and append
+					 * the matches to seq[] in position order (ballot ranks
+					 * inside the wave, one workgroup scan across waves) */
+					bool ism[2];
 #pragma unroll
 					for (u32 k = 0; k < 2; k++) {
 						u32 idx = seg_lo + lane + 64 * k;
-						if (mk[k])
-							L->mark[idx] = 1;
-					}
-					__syncthreads();
-					PROF_MARK(13);
-					/* emit: thread owns OWN consecutive idx (thread NT-1
-					 * also the last 4), in position order */
-					enum { OWN = TILE / NT };
-					u32 kind[OWN + 4], cnt = 0;
-					u32 nown = tid == NT - 1 ? OWN + 4 : OWN;
-					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * OWN + k;
-						kind[k] = 0;
-						if (idx < lim_idx && L->mark[idx]) {
-							u32 st = token_step(L->M[idx], L->M[idx + 1],
-									    L->M[idx + 2], mode, nice);
-							u32 l0 = L->M[idx] & 0xFFFF;
-							kind[k] = (st == l0 && l0) ? 3 : st;	/* 1,2 lits; 3 match */
-							cnt += kind[k] == 3;
-							if (idx + (kind[k] == 3 ? l0 : st) >= lim_idx) {
-								s32 np = (s32)idx - 4 + (s32)(kind[k] == 3 ? l0 : st);
+						u32 st = jh[0][k] - idx, l0 = m0[k] & 0xFFFF;
+						ism[k] = mk[k] && st == l0 && l0;
+						if (mk[k]) {
+							u32 pos = t + idx - 4;
+							if (idx + st >= lim_idx) {
+								s32 np = (s32)idx - 4 + (s32)st;
 								L->vars[V_WALKPOS_LO] = (u32)((s32)t + np);
 								L->vars[V_ENTRY] = (u32)(np - (s32)TILE);
+							}
+							if (ism[k]) {
+								u32 sl, xb, xv;
+								length_code(l0, &sl, &xb, &xv);
+								atomicAdd(&L->freq[257 + sl], 1u);
+								dist_code(m0[k] >> 16, &sl, &xb, &xv);
+								atomicAdd(&L->freq[288 + sl], 1u);
+							} else {
+								atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
+								if (st == 2)
+									atomicAdd(&L->freq[L->in[(pos + 1) & RMASK]], 1u);
 							}
 						}
 					}
@@ -1185,56 +1217,41 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_WALKPOS_LO] = (u32)((s32)t + entry);
 						L->vars[V_ENTRY] = (u32)(entry - (s32)TILE);
 					}
-					u32 tot;
-					u32 base = block_scan(L, cnt, &tot) + L->vars[V_NSEQ];
-					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * OWN + k;
-						if (kind[k] == 3) {
-							u32 m = L->M[idx];
-							L->seq_pl[base] = (u32)((s32)t + (s32)idx - 4 -
-										(s32)block_start) |
-									  ((m & 0xFFFF) << 16);
-							L->seq_d[base] = (u16)(m >> 16);
-							base++;
-						}
-						if (idx < lim_idx)
-							L->mark[idx] = 0;
-					}
+					const u64 bal0 = __ballot(ism[0]), bal1 = __ballot(ism[1]);
+					const u32 c0 = __builtin_popcountll(bal0);
+					const u32 cw = c0 + __builtin_popcountll(bal1);
+					u32 *sc = L->scan[tog];
+					tog ^= 1;
+					if (lane == 0)
+						sc[wave] = cw;
 					__syncthreads();
-					for (u32 k = 0; k < nown; k++) {
-						u32 idx = tid * OWN + k;
-						if (kind[k] == 1 || kind[k] == 2)
-							L->mark[idx] = 1;
-						if (kind[k] == 2)
-							L->mark[idx + 1] = 1;
+					u32 base = seq0 + npre, tot = 0;
+#pragma unroll
+					for (u32 w = 0; w < NWAVES; w++) {
+						u32 c = sc[w];
+						if (w < wave)
+							base += c;
+						tot += c;
 					}
-					if (tid == 0) {
-						L->vars[V_TMP0] = L->vars[V_NSEQ];	/* first new seq */
-						L->vars[V_NSEQ] += tot;
+					const u64 lt = (1ull << lane) - 1;
+#pragma unroll
+					for (u32 k = 0; k < 2; k++) {
+						if (ism[k]) {
+							u32 idx = seg_lo + lane + 64 * k;
+							u32 at = base + (k ? c0 + __builtin_popcountll(bal1 & lt) :
+									 __builtin_popcountll(bal0 & lt));
+							L->seq_pl[at] = (t + idx - 4 - block_start) |
+									((m0[k] & 0xFFFF) << 16);
+							L->seq_d[at] = (u16)(m0[k] >> 16);
+						}
 					}
+					if (tid == 0)
+						L->vars[V_NSEQ] = seq0 + npre + tot;
 				}
 				__syncthreads();
 				walkpos = L->vars[V_WALKPOS_LO];
 				PROF_MARK(5);
 
-				/* histogram of the tokens chosen in this tile */
-				{
-					u32 s0 = L->vars[V_TMP0], s1 = L->vars[V_NSEQ];
-					for (u32 s = s0 + tid; s < s1; s += NT) {
-						u32 sl, xb, xv;
-						length_code(L->seq_pl[s] >> 16, &sl, &xb, &xv);
-						atomicAdd(&L->freq[257 + sl], 1u);
-						dist_code(L->seq_d[s], &sl, &xb, &xv);
-						atomicAdd(&L->freq[288 + sl], 1u);
-					}
-					for (u32 i = tid; i < TILE + 4; i += NT) {
-						if (L->mark[i]) {
-							u32 pos = t + i - 4;	/* index 4 <-> t */
-							atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
-						}
-					}
-				}
-				__syncthreads();
 				/* carry the last 4 match entries to the front for the
 				 * positions the walk deferred */
 				if (tid < 4)
@@ -1583,7 +1600,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				 * just consumed the entry; the covered prefix and the match
 				 * count travel in two alternating pairs of LDS words. */
 				u32 *KD = L->M;
-				u32 seq_lo = 0, tog = 0;
+				u32 seq_lo = 0;
 				for (u32 i = tid; i < EWIN; i += NT)
 					KD[i] = 0;
 				if (tid == 0) {
