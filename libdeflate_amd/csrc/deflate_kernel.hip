@@ -930,7 +930,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 					    cnt = 0, boff = 0, curb = 0;
-					u64 nxt8 = 0, q = 0;
+					u64 nxt8 = 0, nxt16 = 0, nxt24 = 0, q = 0;
 					bool have = false, fin = true, ended = false;
 					PROF_SEC_DECL;
 
@@ -956,6 +956,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										curb = cur;
 										boff = 0;
 										nxt8 = ld64(L->in, p + 4);
+										nxt16 = ld64(L->in, p + 12);
+										nxt24 = ld64(L->in, p + 20);
 										c16 = L->prev[p & RMASK];
 										maxlen = n - p < 258 ? n - p : 258;
 										dmaxp = p - lo_pos;
@@ -1003,21 +1005,37 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
 							ev = ev && ld32(L->in, cp) == cur;
 							bool more = ev && x == 0 && 12 < maxlen;
+							/* bytes 12..27 against the cached words, lane by
+							 * lane; only longer matches go to the wave */
+							if (__ballot(more)) {
+								u64 y = nxt16 ^ ld64(L->in, cp + 12);
+								if (more) {
+									len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
+									more = y == 0 && 20 < maxlen;
+								}
+								if (__ballot(more)) {
+									u64 z = nxt24 ^ ld64(L->in, cp + 20);
+									if (more) {
+										len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
+										more = z == 0 && 28 < maxlen;
+									}
+								}
+							}
 							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
 								u32 src = (u32)__builtin_ctzll(mm);
 								u32 bp = bcast_lane(p, src);
 								u32 bc = bcast_lane(cp, src);
 								u32 bmax = bcast_lane(maxlen, src);
-								u32 off = 12 + 4 * lane;
+								u32 off = 28 + 4 * lane;
 								u32 x4 = off < bmax ?
 									(ld32(L->in, bp + off) ^
 									 ld32(L->in, bc + off)) : 1;
 								u64 ne = __ballot(x4 != 0);
-								u32 tot = bmax;	/* 12 + 256 >= 258 */
+								u32 tot = bmax;	/* 28 + 256 >= 258 */
 								if (ne) {
 									u32 kk = (u32)__builtin_ctzll(ne);
 									u32 xk = bcast_lane(x4, kk);
-									u32 o = 12 + 4 * kk;
+									u32 o = 28 + 4 * kk;
 									if (o < bmax)
 										tot = o + ((u32)__builtin_ctz(xk) >> 3);
 								}
