@@ -64,6 +64,9 @@
 #ifndef S3_WALK
 #define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
 #endif
+#ifndef S3_EVMIN
+#define S3_EVMIN 1u		/* lanes with a queued hit that trigger an evaluate round */
+#endif
 #ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
 #endif
@@ -346,7 +349,6 @@ template <int N> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 	  u16 *sorted, huff_scratch<N> *H, u32 used, bool presorted, u32 lane)
 {
-	PROF_SEC_DECL;
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
 	if (!presorted) {
@@ -388,7 +390,6 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		if (lane < 40)
 			H->cntI[lane] = 0;
 		wave_sync();
-		PROF_SEC(0);
 		if (lane == 0) {
 			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
 			 * creation order (ascending too); heads cached in registers */
@@ -422,7 +423,6 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			}
 		}
 		wave_sync();
-		PROF_SEC(1);
 		/* depth of every internal node by pointer jumping (root = m-2) */
 		{
 			const u32 root = m - 2;
@@ -476,7 +476,6 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 				H->cnt[lane] = lane ? 2 * H->cntI[lane - 1] - H->cntI[lane] : 0;
 			wave_sync();
 		}
-		PROF_SEC(2);
 		if (lane == 0) {
 			/* clamp to maxlen, repair Kraft sum (zlib-style) */
 			u32 over = 0;
@@ -549,9 +548,6 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		}
 	}
 	wave_sync();
-	PROF_SEC(3);
-	if (N == 288)
-		PROF_SEC_FLUSH(17);
 }
 
 /* ---------------- bit output through the LDS staging area ---------------- */
@@ -930,17 +926,22 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 					    cnt = 0, boff = 0, curb = 0;
-					u64 nxt8 = 0, nxt16 = 0, nxt24 = 0, q = 0;
+					u64 nxt8 = 0, q = 0;
 					bool have = false, fin = true, ended = false;
-					PROF_SEC_DECL;
 
 					for (;;) {
-						PROF_SEC(3);
 						u64 mh = __ballot(have);
 						u32 nf = __builtin_popcountll(__ballot(fin));
 						if (!mh && !nf)
 							break;
 						if (nf && (nf >= S3_CLAIM || !mh)) {
+							PROF_COUNT(20, 1);
+							/* one counter update per wave; ranks by ballot */
+							const u64 fm = __ballot(fin);
+							u32 cbase = 0;
+							if (lane == 0)
+								cbase = atomicAdd(&L->vars[V_CTR], nf);
+							cbase = bcast_first(cbase);
 							if (fin) {
 								if (my_i < TILE)
 									L->M[4 + my_i] =
@@ -948,7 +949,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										(best | (bestd << 16)) : 0;
 								fin = false;
 								best = 3;
-								my_i = atomicAdd(&L->vars[V_CTR], 1u);
+								my_i = cbase + __builtin_popcountll(fm & ((1ull << lane) - 1));
 								if (my_i < TILE) {
 									p = t + my_i;
 									if (p + 4 <= n) {
@@ -956,8 +957,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										curb = cur;
 										boff = 0;
 										nxt8 = ld64(L->in, p + 4);
-										nxt16 = ld64(L->in, p + 12);
-										nxt24 = ld64(L->in, p + 20);
 										c16 = L->prev[p & RMASK];
 										maxlen = n - p < 258 ? n - p : 258;
 										dmaxp = p - lo_pos;
@@ -972,14 +971,17 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									}
 								}
 							}
-							PROF_SEC(0);
 							continue;
 						}
 						/* walk */
+						PROF_COUNT(14, 1);
+						PROF_COUNT(15, __builtin_popcountll(__ballot(have && !ended)));
 #pragma unroll
 						for (int s = 0; s < S3_WALK; s++) {
 							u32 d = (p - c16) & 0xFFFF;
-							bool ok = !ended && dep && d > dprev && d <= dmaxp;
+							bool chain = dep && d > dprev && d <= dmaxp;
+							bool stall = ended || cnt >= 4;
+							bool ok = !stall && chain;
 							u32 cp = p - d;
 							u32 w = ld32(L->in, cp + boff);
 							u32 c16n = L->prev[cp & RMASK];
@@ -987,17 +989,21 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							c16 = ok ? c16n : c16;
 							dprev = ok ? d : dprev;
 							dep -= ok ? 1 : 0;
-							ended = ended || !ok;
+							ended = ended || (!stall && !chain);
 							q = hit ? ((q << 16) | d) : q;
 							cnt += hit ? 1 : 0;
 						}
 						if (!have)
 							cnt = 0;
-						PROF_SEC(1);
-						/* evaluate */
+						/* evaluate: a round when enough lanes hold a hit, or
+						 * when no lane can walk any further */
 						bool done = false;
-						while (__ballot(cnt > 0)) {
+						u32 nev = __builtin_popcountll(__ballot(cnt > 0));
+						u32 nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
+						while (nev && (nev >= S3_EVMIN || !nwalk)) {
 							bool ev = cnt > 0;
+							PROF_COUNT(17, 1);
+							PROF_COUNT(19, __builtin_popcountll(__ballot(ev)));
 							u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
 							cnt -= ev ? 1 : 0;
 							u32 cp = p - d;
@@ -1005,16 +1011,16 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
 							ev = ev && ld32(L->in, cp) == cur;
 							bool more = ev && x == 0 && 12 < maxlen;
-							/* bytes 12..27 against the cached words, lane by
-							 * lane; only longer matches go to the wave */
+							/* bytes 12..27 lane by lane; only longer matches
+							 * go to the wave */
 							if (__ballot(more)) {
-								u64 y = nxt16 ^ ld64(L->in, cp + 12);
+								u64 y = ld64(L->in, p + 12) ^ ld64(L->in, cp + 12);
 								if (more) {
 									len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
 									more = y == 0 && 20 < maxlen;
 								}
 								if (__ballot(more)) {
-									u64 z = nxt24 ^ ld64(L->in, cp + 20);
+									u64 z = ld64(L->in, p + 20) ^ ld64(L->in, cp + 20);
 									if (more) {
 										len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
 										more = z == 0 && 28 < maxlen;
@@ -1023,6 +1029,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							}
 							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
 								u32 src = (u32)__builtin_ctzll(mm);
+								PROF_COUNT(18, 1);
 								u32 bp = bcast_lane(p, src);
 								u32 bc = bcast_lane(cp, src);
 								u32 bmax = bcast_lane(maxlen, src);
@@ -1057,18 +1064,22 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									}
 								}
 							}
+							if (have && (done || (ended && cnt == 0))) {
+								have = false;
+								fin = true;
+								done = false;
+							}
+							nev = __builtin_popcountll(__ballot(cnt > 0));
+							nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
 						}
-						if (have && (ended || done)) {
+						if (have && ended && cnt == 0) {
 							have = false;
 							fin = true;
 						}
-						PROF_SEC(2);
 					}
-					PROF_SEC_FLUSH(12);
-					__syncthreads();
-					PROF_MARK(16);
 				}
 				__syncthreads();
+				PROF_MARK(16);
 				/* length-3 matches for the positions left without a match */
 				if (L->vars[V_MINLEN] <= 3) {
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;

@@ -131,8 +131,8 @@ static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 		unsigned long long n_ = __builtin_readcyclecounter(); \
 		atomicAdd(&lda_prof[slot], n_ - prof_t_); prof_t_ = n_; } } while (0)
 #ifdef LDA_PROFILE_COUNTS	/* event counters distort the phase times */
-#define PROF_COUNT(slot, v) do { if (threadIdx.x == 0) \
-		atomicAdd(&lda_prof[slot], (unsigned long long)(v)); } while (0)
+#define PROF_COUNT(slot, v) do { unsigned long long v_ = (v); if (threadIdx.x == 0) \
+		atomicAdd(&lda_prof[slot], v_); } while (0)
 /* section timers kept in registers, flushed once per tile by PROF_SEC_FLUSH */
 #define PROF_SEC_DECL unsigned long long sec_[4] = { 0, 0, 0, 0 }, sec_t_ = __builtin_readcyclecounter()
 #define PROF_SEC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); \

@@ -65,9 +65,9 @@ def main():
 
 PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
                   "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
-                  "S4 doubling", "S4 chain+mark", "S3 evaluate (w0)", "S3 loop (w0)",
-                  "S3 total (w0)", "huff: setup", "huff: merge (lane 0)", "huff: depths",
-                  "huff: lengths+codes", "S5 precode RLE (t0)", "S5 precode tree"]
+                  "S4 doubling", "S4 chain+mark", "#walk passes (w0)", "#lanes walking at pass start",
+                  "S3 total (w0)", "#eval rounds", "#coop passes", "#lanes evaluating",
+                  "#claim passes", "S5 precode RLE (t0)", "S5 precode tree"]
 
 
 def read_profile(name, labels):
@@ -127,6 +127,10 @@ def bench_inflate(a, fmt="gzip", level=6):
 
 def bench_deflate(a, fmt="gzip", level=6):
     chunks, data, offs, nb = make_batch(a.chunks, a.size, 0x0E110003)
+    if a.kind >= 0:
+        one = [datagen.chunk(a.kind + 8 * (i % 8), a.size, 0x0E110003) for i in range(64)]
+        chunks = [one[i % 64] for i in range(a.chunks)]
+        data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
     n = a.chunks
     c = api.Compressor(level)
     bound = (c.bound(fmt, a.size) + 15) // 16 * 16
