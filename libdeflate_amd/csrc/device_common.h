@@ -41,8 +41,10 @@ static __device__ __forceinline__ u32 bcast_first(u32 v)
 /* 64-bit value of the first active lane */
 static __device__ __forceinline__ u64 bcast64(u64 v)
 {
-	return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) |
-	       __builtin_amdgcn_readfirstlane((u32)v);
+	/* the builtin returns int: without the casts the low half would be
+	 * sign-extended over the high half */
+	return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) |
+	       (u32)__builtin_amdgcn_readfirstlane((u32)v);
 }
 
 static __device__ __forceinline__ u32 bcast_lane(u32 v, u32 lane)

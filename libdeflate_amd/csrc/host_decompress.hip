@@ -111,6 +111,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 		return;
 	d->scratch.release();
 	d->stage.release();
+	d->tokens.release();
 	free_func_t f = d->free_func;
 	d->~libdeflate_decompressor();
 	f(d);
@@ -165,7 +166,13 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		if (v >= 1 && v <= 64)
 			lpw = (uint32_t)v;
 	}
-	size_t lds = lda_inflate_lds_per_stream() * lpw + lda_inflate_lds_shared();
+	/* wave per stream with sub-block parallel token decoding (the default):
+	 * one stream keeps all 64 lanes of its wave busy, so even a batch that
+	 * is small next to the machine (4096 streams on 1024 SIMDs) runs at the
+	 * rate of a huge one.  LDA_INFLATE_PAR=0 selects lane-per-stream. */
+	bool par = true;
+	if (const char *e = getenv("LDA_INFLATE_PAR"))
+		par = atoi(e) != 0;
 	static bool attr_set[16];
 	if (!attr_set[c->device]) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
@@ -176,12 +183,39 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 			    LIBDEFLATE_AMD_NO_DEVICE);
 		attr_set[c->device] = true;
 	}
-	hipLaunchKernelGGL(lda_inflate_batch_kernel,
-			   dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64),
-			   lds, st, (uint64_t)n, format, lpw, (const uint8_t *)d_in,
-			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
-			   d_out_offsets, d_out_avail, d_results, ain, aout);
+	if (par) {
+		size_t grid = (size_t)c->num_cus * 16;
+		if (grid > n)
+			grid = n;
+		uint32_t *tok = (uint32_t *)d->tokens.reserve(
+					grid * lda_inflate_tokcap() * 4);
+		if (!tok)
+			return LIBDEFLATE_AMD_OOM;
+		if (getenv("LDA_DEBUG_PTRS"))
+			fprintf(stderr, "tok %p (%zu B) in %p out %p results %p ain %p aout %p scratch %p\n",
+				(void *)tok, d->tokens.cap, d_in, d_out, (void *)d_results,
+				(void *)ain, (void *)aout, d->scratch.p);
+		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared();
+		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
+				   dim3(64), lds, st, (uint64_t)n, format, tok,
+				   (const uint8_t *)d_in, d_in_offsets, d_in_nbytes,
+				   (uint8_t *)d_out, d_out_offsets, d_out_avail,
+				   d_results, ain, aout);
+	} else {
+		size_t lds = lda_inflate_lds_per_stream() * lpw +
+			     lda_inflate_lds_shared();
+		hipLaunchKernelGGL(lda_inflate_batch_kernel,
+				   dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64),
+				   lds, st, (uint64_t)n, format, lpw,
+				   (const uint8_t *)d_in, d_in_offsets, d_in_nbytes,
+				   (uint8_t *)d_out, d_out_offsets, d_out_avail,
+				   d_results, ain, aout);
+	}
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
+	if (getenv("LDA_DEBUG_SYNC")) {
+		hipError_t e = hipStreamSynchronize(st);
+		fprintf(stderr, "inflate kernel done: %s\n", hipGetErrorString(e));
+	}
 	if (format != LIBDEFLATE_AMD_DEFLATE) {
 		int rc = format == LIBDEFLATE_AMD_GZIP ?
 			libdeflate_amd_crc32_batch(n, d_out, d_out_offsets, aout,

@@ -33,6 +33,7 @@ struct libdeflate_decompressor {
 	lda::free_func_t free_func;
 	lda::DevBuf scratch;	/* per-chunk u32 sums + u64 actual_in/out */
 	lda::DevBuf stage;	/* host-pointer entry points */
+	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
 };
 
 struct libdeflate_compressor {

@@ -482,22 +482,427 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
 		}                                                             \
 	} while (0)
 
-extern "C" __global__ void __launch_bounds__(64, 4)
-lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
-			 const u8 *__restrict__ in_base,
-			 const u64 *__restrict__ in_offsets,
-			 const u64 *__restrict__ in_nbytes,
-			 u8 *__restrict__ out_base,
-			 const u64 *__restrict__ out_offsets,
-			 const u64 *__restrict__ out_avail_arr,
-			 s32 *__restrict__ results,
-			 u64 *__restrict__ actual_in,	/* incl. container header */
-			 u64 *__restrict__ actual_out)
+/* ---------------- sub-block parallel token decoding ----------------
+ *
+ * A Huffman-coded DEFLATE block can only be parsed from its first bit, but a
+ * parse started at an arbitrary bit falls in step with the true parse after a
+ * few dozen bits (measured on level-6 streams of the benchmark data: median
+ * 52 bits, 99 % within 450).  One round gives each of the 64 lanes PAR_CB
+ * bits of the block:
+ *
+ *   sync   every lane parses from its (guessed) start to the end of its
+ *          chunk and reports where its last token ended, how many tokens and
+ *          output bytes it saw; lane i + 1 then restarts from lane i's end.
+ *          Lane 0 starts at a known token boundary, so after k passes lanes
+ *          0..k-1 are exact; in practice two or three passes settle all 64;
+ *   emit   with exact starts and prefix sums of the counts, every lane
+ *          parses once more and writes its tokens (literal byte, or length
+ *          and distance) to the wave's token scratch in HBM;
+ *   copy   the tokens are executed 64 at a time: output offsets by a wave
+ *          scan, literals stored at once, matches copied by their lanes as
+ *          soon as everything they read lies below the completed watermark
+ *          (the first pending match is always ready, so each iteration makes
+ *          progress).
+ *
+ * Nothing is written to the output before the round is known to be free of
+ * anything the sequential decoder has a rule for: it needs the whole input
+ * span plus 64 bytes inside the buffer, the produced bytes inside the output
+ * buffer, and every distance inside the bytes already produced - otherwise
+ * the round is abandoned and the sequential decoder takes the same bits.
+ */
+#define PAR_CB 256u		/* input bits per lane and round */
+#define PAR_TOKCAP 8192u	/* tokens per round held in the wave's scratch */
+enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
+
+struct par_bits {
+	u64 buf;
+	u64 nb;		/* next input byte to load */
+	u32 cnt;
+};
+
+#ifdef LDA_PAR_DEBUG
+static __device__ u32 g_par_fail;	/* first failed address check */
+#define PAR_CHECK(cond, code) ((cond) ? true : (atomicCAS(&g_par_fail, 0u, (u32)(code)), false))
+#else
+#define PAR_CHECK(cond, code) true
+#endif
+static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
 {
-	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+#ifdef LDA_PAR_DEBUG
+	if (!PAR_CHECK(b->nb < (1u << 20), 11))
+		return;
+#endif
+	b->buf |= ld8(inp + b->nb) << b->cnt;
+	b->nb += (63 - b->cnt) >> 3;
+	b->cnt |= 56;
+}
+
+static __device__ __forceinline__ void pb_init(struct par_bits *b, const u8 *inp, u64 pos)
+{
+	b->nb = pos >> 3;
+	b->buf = 0;
+	b->cnt = 0;
+	pb_refill(b, inp);
+	b->buf >>= (u32)pos & 7;
+	b->cnt -= (u32)pos & 7;
+}
+
+#define PB_POS(b) (8 * (b).nb - (b).cnt)
+
+/* one token at the head of b->buf (>= 56 bits): kind, literal byte or
+ * (length, distance), bits used; long codewords take the bit-serial path */
+struct par_token {
+	u32 kind, lit, length, dist, used;
+};
+
+static __device__ __forceinline__ struct par_token
+par_decode(const struct stream_lds *S, const struct shared_lds *SH, u64 buf)
+{
+	struct par_token t;
+	u32 e = S->lit_tab[(u32)buf & ((1u << LIT_TB) - 1)];
+	u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
+
+	if (cl == 0) {
+		u32 sym = decode_long(&S->lit, S->lit_sorted, buf, &cl);
+		kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
+		pay = sym < 256 ? sym : sym - 257;
+	}
+	u64 bb = buf >> cl;
+	u32 lt = SH->len_tab[pay & 31];
+	u32 xb = lt >> 16;
+	t.length = (lt & 0xFFFF) + ((u32)bb & ((1u << xb) - 1));
+	bb >>= xb;
+	u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
+	u32 ol = e2 & 15, osym = e2 >> 4;
+	if (kind == K_LEN && ol == 0)
+		osym = decode_long(&S->off, S->off_sorted, bb, &ol);
+	u32 dt = SH->dist_tab[osym & 31];
+	u32 dxb = dt >> 16;
+	t.dist = (dt & 0xFFFF) + ((u32)(bb >> ol) & ((1u << dxb) - 1));
+	t.kind = kind;
+	t.lit = pay & 0xFF;
+	t.used = cl + (kind == K_LEN ? xb + ol + dxb : 0);
+	return t;
+}
+
+/* exact-length forward copy of one match inside the output */
+static __device__ __forceinline__ void par_copy(u8 *dst, u32 dist, u32 len)
+{
+	const u8 *src = dst - dist;
+	u32 k = 0;
+
+	if (dist >= 8) {
+		for (; k + 8 <= len; k += 8)
+			st8(dst + k, ld8(src + k));
+		if (k + 4 <= len) {
+			u32 v;
+			__builtin_memcpy(&v, src + k, 4);
+			__builtin_memcpy(dst + k, &v, 4);
+			k += 4;
+		}
+		if (k + 2 <= len) {
+			u16 v;
+			__builtin_memcpy(&v, src + k, 2);
+			__builtin_memcpy(dst + k, &v, 2);
+			k += 2;
+		}
+		if (k < len)
+			dst[k] = src[k];
+		return;
+	}
+	/* period 1..7: one load, the period expanded and rotated in registers */
+	u64 w = 0;
+	for (u32 j = 0; j < dist; j++)
+		w |= (u64)src[j] << (8 * j);
+	for (u32 sh = 8 * dist; sh < 64; sh *= 2)
+		w |= w << sh;
+	const u32 r = 8 % dist;
+	for (; k + 8 <= len; k += 8) {
+		st8(dst + k, w);
+		if (r)
+			w = (w >> (8 * r)) | (w << (8 * (dist - r)));
+	}
+	for (; k < len; k++) {
+		dst[k] = (u8)w;
+		w >>= 8;
+	}
+}
+
+static __device__ __forceinline__ u64 shfl_up64(u64 v)
+{
+	u32 lo = __shfl_up((u32)v, 1, 64), hi = __shfl_up((u32)(v >> 32), 1, 64);
+	return ((u64)hi << 32) | lo;
+}
+
+static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
+{
+	return ((u64)bcast_lane((u32)(v >> 32), l) << 32) | bcast_lane((u32)v, l);
+}
+
+/*
+ * One round.  bpos0: bit position (in inp) of the next token; out0: bytes
+ * produced so far.  Returns PAR_STOP with nothing changed, or PAR_OK /
+ * PAR_EOB with *bpos_ret / *out_ret advanced (PAR_EOB: the end-of-block
+ * symbol was consumed).
+ */
+static __device__ u32
+par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
+	  const struct stream_lds *S, const struct shared_lds *SH,
+	  u32 *__restrict__ tok, u32 lane, u64 bpos0, u64 out0,
+	  u64 *bpos_ret, u64 *out_ret)
+{
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 8
+	if (lane == 0)
+		tok[0] = 123;
+	return PAR_STOP;
+#endif
+	u32 cb = PAR_CB;
+	if ((bpos0 >> 3) + 8 * cb + 64 > in_n) {	/* 64 lanes * cb / 8 bytes */
+		cb = PAR_CB / 2;
+		if ((bpos0 >> 3) + 8 * cb + 64 > in_n)
+			return PAR_STOP;
+	}
+	const u64 cend = bpos0 + (u64)(lane + 1) * cb;
+	u64 start = bpos0 + (u64)lane * cb, end = 0;
+	u32 nbytes = 0, ntok = 0;
+	bool eob = false, dirty = true;
+	u32 K = 63;		/* last lane of the round */
+	bool has_eob = false;
+
+	/* ---- sync passes ---- */
+	for (u32 pass = 0; pass < 64; pass++) {
+		struct par_bits b;
+		bool run = dirty;
+		pb_init(&b, inp, start);
+		if (dirty) {
+			nbytes = 0;
+			ntok = 0;
+			eob = false;
+		}
+		while (__ballot(run)) {
+			run = run && PB_POS(b) < cend;
+			pb_refill(&b, inp);
+			struct par_token t = par_decode(S, SH, b.buf);
+			if (run) {
+				if (t.kind == K_EOB) {
+					eob = true;
+					run = false;
+					b.buf >>= t.used;
+					b.cnt -= t.used;
+				} else {
+					b.buf >>= t.used;
+					b.cnt -= t.used;
+					nbytes += t.kind == K_LEN ? t.length : 1;
+					ntok++;
+				}
+			}
+		}
+		if (dirty)
+			end = PB_POS(b);
+		u64 ns = shfl_up64(end);
+		if (lane == 0)
+			ns = bpos0;
+		dirty = ns != start;
+		start = ns;
+		const u64 dm = __ballot(dirty), em = __ballot(eob);
+		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
+		if (em & exact) {	/* end of block on the exact prefix */
+			K = (u32)__builtin_ctzll(em & exact);
+			has_eob = true;
+			break;
+		}
+		if (!dm)
+			break;
+	}
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 1
+	return PAR_STOP;
+#endif
+	/* ---- counts -> offsets; clip the round to the token scratch ---- */
+	bool valid = lane <= K;
+	u32 tcnt = valid ? ntok : 0;
+	u32 tbase = wave_scan_incl(tcnt) - tcnt;
+	if (tbase + tcnt > PAR_TOKCAP)
+		valid = false;
+	{
+		const u64 vm = __ballot(valid);
+		const u32 nv = __builtin_popcountll(vm);	/* a prefix of lanes */
+		if (nv == 0)
+			return PAR_STOP;
+		if (nv - 1 < K) {
+			K = nv - 1;
+			has_eob = false;
+		}
+		valid = lane <= K;
+	}
+	const u32 bcnt = valid ? nbytes : 0;
+	const u32 obase = wave_scan_incl(bcnt) - bcnt;
+	const u32 total_tok = bcast_lane(tbase + tcnt, K);
+	const u64 total_bytes = bcast_lane(obase + bcnt, K);
+	if (total_bytes > out_avail - out0)
+		return PAR_STOP;
+	const u64 end_bits = readlane64(end, K);
+
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 2
+	return PAR_STOP;
+#endif
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 4
+	{
+		u32 *dbg = (u32 *)outp;
+		if (lane == 0) {
+			dbg[0] = K; dbg[1] = total_tok; dbg[2] = (u32)total_bytes;
+			dbg[3] = (u32)(end_bits - bpos0); dbg[4] = has_eob; dbg[5] = cb;
+			dbg[6] = (u32)(uintptr_t)tok; dbg[7] = (u32)((uintptr_t)tok >> 32);
+			dbg[8] = (u32)(uintptr_t)outp; dbg[9] = (u32)((uintptr_t)outp >> 32);
+			dbg[10] = (u32)(uintptr_t)inp; dbg[11] = (u32)((uintptr_t)inp >> 32);
+		}
+		dbg[16 + 4 * lane] = ntok; dbg[17 + 4 * lane] = nbytes;
+		dbg[18 + 4 * lane] = (u32)(start - bpos0); dbg[19 + 4 * lane] = (u32)(end - bpos0);
+		return 77;
+	}
+#endif
+	/* ---- emit the tokens ---- */
+	{
+		struct par_bits b;
+		bool run = valid, bad = false;
+		u32 k = tbase;
+		u64 opos = out0 + obase;
+		pb_init(&b, inp, start);
+		while (__ballot(run)) {
+			run = run && PB_POS(b) < cend;
+			pb_refill(&b, inp);
+			struct par_token t = par_decode(S, SH, b.buf);
+			if (run) {
+				b.buf >>= t.used;
+				b.cnt -= t.used;
+				if (t.kind == K_EOB) {
+					run = false;
+				} else if (t.kind == K_LEN) {
+					if (t.dist > opos)
+						bad = true;
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
+					if (k < PAR_TOKCAP)
+#endif
+					if (PAR_CHECK(k < PAR_TOKCAP, 12))
+					tok[k] = 0x80000000u | t.length | (t.dist << 9);
+					k++;
+					opos += t.length;
+				} else {
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
+					if (k < PAR_TOKCAP)
+#endif
+					if (PAR_CHECK(k < PAR_TOKCAP, 13))
+					tok[k] = t.lit;
+					k++;
+					opos++;
+				}
+			}
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
+			if (k > tbase + 1000)
+				run = false;
+#endif
+		}
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
+		{
+			u32 *dbg = (u32 *)outp;
+			if (lane == 0) {
+				dbg[0] = K; dbg[1] = total_tok; dbg[2] = (u32)total_bytes;
+				dbg[3] = (u32)(end_bits - bpos0); dbg[4] = has_eob; dbg[5] = cb;
+			}
+			dbg[16 + 4 * lane] = ntok; dbg[17 + 4 * lane] = k - tbase;
+			dbg[18 + 4 * lane] = tbase; dbg[19 + 4 * lane] = (u32)(PB_POS(b) - bpos0);
+			return 77;
+		}
+#endif
+		if (__ballot(bad))
+			return PAR_STOP;
+#ifdef LDA_PAR_DEBUG
+		if (__ballot(valid && (k - tbase != ntok || opos - (out0 + obase) != nbytes))) {
+			*bpos_ret = 1;
+			return 77;
+		}
+#endif
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 5
+		if (k == 0xFFFFFFFFu)
+			tok[0] = (u32)opos;
+		return PAR_STOP;
+#endif
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 3
+	return PAR_STOP;
+#endif
+	/* ---- execute the tokens, 64 at a time ---- */
+	u64 gbase = out0;
+	for (u32 g = 0; g < total_tok; g += 64) {
+		const bool have = g + lane < total_tok;
+		const u32 t = have && PAR_CHECK(g + lane < PAR_TOKCAP, 14) ? tok[g + lane] : 0;
+		const bool ism = have && (t >> 31);
+		const u32 len = !have ? 0 : ism ? (t & 0x1FF) : 1;
+		const u32 dist = (t >> 9) & 0xFFFF;
+		const u32 incl = wave_scan_incl(len);
+		const u64 o = gbase + incl - len;
+
+#ifdef LDA_PAR_DEBUG
+		if (__ballot(have && (o + len > out0 + total_bytes || (ism && dist > o)))) {
+			*bpos_ret = 2;
+			return 77;
+		}
+#endif
+		if (have && !ism && PAR_CHECK(o < out_avail, 15))
+			outp[o] = (u8)t;
+		/* bytes of other tokens this match reads end here */
+		const u64 src_end = o - dist + len;
+		const u64 need_end = src_end < o ? src_end : o;
+		u64 pending = __ballot(ism);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		bool mine = ism;
+		while (pending) {
+			const u32 f = (u32)__builtin_ctzll(pending);
+			const u64 wmark = readlane64(o, f);
+			const bool ready = mine && need_end <= wmark;
+			if (ready) {
+				if (PAR_CHECK(o + len <= out_avail && dist <= o && dist >= 1, 16))
+				par_copy(outp + o, dist, len);
+				mine = false;
+			}
+			pending &= ~__ballot(ready);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+		gbase += bcast_lane(incl, 63);
+	}
+	*bpos_ret = end_bits;
+	*out_ret = out0 + total_bytes;
+	return has_eob ? PAR_EOB : PAR_OK;
+}
+
+/*
+ * One workgroup's worth of streams: streams blk * lpw .. blk * lpw + lpw - 1
+ * on lanes 0..lpw-1.  With par != 0 (lpw == 1: a wave per stream) the token
+ * phase of a block runs sub-block parallel rounds (par_round above) wherever
+ * the stream is far enough from both buffer ends; everything else - headers,
+ * stored blocks, the last bytes of a stream, every error path - is the
+ * sequential decoder below, so result codes do not depend on the mode.
+ */
+static __device__ __forceinline__ void
+inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
+	      u64 n_chunks, int format, u32 lpw,
+	      const u8 *__restrict__ in_base,
+	      const u64 *__restrict__ in_offsets,
+	      const u64 *__restrict__ in_nbytes,
+	      u8 *__restrict__ out_base,
+	      const u64 *__restrict__ out_offsets,
+	      const u64 *__restrict__ out_avail_arr,
+	      s32 *__restrict__ results,
+	      u64 *__restrict__ actual_in,	/* incl. container header */
+	      u64 *__restrict__ actual_out)
+{
 	struct stream_lds *SL = (struct stream_lds *)lds_raw;
 	const u32 lane = threadIdx.x;
-	const u64 c = (u64)blockIdx.x * lpw + lane;
+	const u64 c = blk * lpw + lane;
 	const bool owner = lane < lpw && c < n_chunks;
 	struct stream_lds *S = &SL[lane < lpw ? lane : 0];
 	struct shared_lds *SH = (struct shared_lds *)&SL[lpw];
@@ -792,6 +1197,55 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			state = final_block ? ST_DONE : ST_HDR;
 		}
 
+		/* ------------ sub-block parallel rounds (wave per stream) ------------ */
+		if (par) {
+			for (;;) {
+				if (!bcast_first(state == ST_TOK ? 1u : 0u))
+					break;
+				if (lane == 0)
+					FLUSH_PENDING();
+				const u64 bpos0 = bcast64(CONSUMED());
+				const u64 o0 = bcast64(out_pos);
+				const u8 *inp0 = (const u8 *)bcast64((u64)(uintptr_t)inp);
+				u8 *outp0 = (u8 *)bcast64((u64)(uintptr_t)outp);
+				u64 nb = 0, no = 0;
+				u32 pr = par_round(inp0, bcast64(in_n), outp0,
+						   bcast64(out_avail), &SL[0], SH, tok,
+						   lane, bpos0, o0, &nb, &no);
+#ifdef LDA_PAR_DEBUG
+				if (g_par_fail) {
+					pr = 77;
+					nb = g_par_fail;
+				}
+				if (pr == 77) {
+					if (lane == 0) {
+						result = 100 + (s32)nb;
+						state = ST_DONE;
+					}
+					break;
+				}
+#endif
+				if (pr == PAR_STOP)
+					break;
+				if (lane == 0) {
+					/* back to the sequential decoder's state */
+					rpos = nb >> 3;
+					bitbuf = 0;
+					bitcnt = 0;
+					filled = rpos & ~(u64)63;
+					ENSURE_INPUT();
+					REFILL();
+					CONSUME((u32)nb & 7);
+					out_pos = no;
+					hist_n = 0;
+					if (pr == PAR_EOB)
+						state = final_block ? ST_DONE : ST_HDR;
+				}
+				if (pr == PAR_EOB)
+					break;
+			}
+		}
+
 		/* ------------ fast token loop ------------
 		 * While every active stream has >= 16 input bytes and >= 272
 		 * output bytes left, none of the end-of-buffer rules can fire
@@ -1081,6 +1535,62 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 		if (result != LDA_SUCCESS)
 			actual_in[c] = 0;
 	}
+}
+
+extern "C" __global__ void __launch_bounds__(64, 4)
+lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
+			 const u8 *__restrict__ in_base,
+			 const u64 *__restrict__ in_offsets,
+			 const u64 *__restrict__ in_nbytes,
+			 u8 *__restrict__ out_base,
+			 const u64 *__restrict__ out_offsets,
+			 const u64 *__restrict__ out_avail_arr,
+			 s32 *__restrict__ results,
+			 u64 *__restrict__ actual_in,
+			 u64 *__restrict__ actual_out)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+
+	inflate_block(blockIdx.x, lds_raw, 0, NULL, n_chunks, format, lpw, in_base,
+		      in_offsets, in_nbytes, out_base, out_offsets, out_avail_arr,
+		      results, actual_in, actual_out);
+}
+
+/*
+ * Wave per stream with sub-block parallel token decoding; persistent grid
+ * (each wave owns PAR_TOKCAP words of the token scratch and walks the
+ * streams blockIdx.x, blockIdx.x + gridDim.x, ...).
+ */
+extern "C" __global__ void __launch_bounds__(64, 3)
+lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
+			const u8 *__restrict__ in_base,
+			const u64 *__restrict__ in_offsets,
+			const u64 *__restrict__ in_nbytes,
+			u8 *__restrict__ out_base,
+			const u64 *__restrict__ out_offsets,
+			const u64 *__restrict__ out_avail_arr,
+			s32 *__restrict__ results,
+			u64 *__restrict__ actual_in,
+			u64 *__restrict__ actual_out)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_TOKCAP;
+#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 9
+	if (threadIdx.x == 0)
+		tok[0] = 123;
+#endif
+
+	for (u64 blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
+		inflate_block(blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
+			      in_offsets, in_nbytes, out_base, out_offsets,
+			      out_avail_arr, results, actual_in, actual_out);
+		wave_sync();
+	}
+}
+
+extern "C" size_t lda_inflate_tokcap(void)
+{
+	return PAR_TOKCAP;
 }
 
 /* host helper: LDS bytes per stream */
