@@ -195,7 +195,8 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 			fprintf(stderr, "tok %p (%zu B) in %p out %p results %p ain %p aout %p scratch %p\n",
 				(void *)tok, d->tokens.cap, d_in, d_out, (void *)d_results,
 				(void *)ain, (void *)aout, d->scratch.p);
-		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared();
+		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared() +
+			     lda_inflate_window_bytes();
 		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
 				   dim3(64), lds, st, (uint64_t)n, format, tok,
 				   (const uint8_t *)d_in, d_in_offsets, d_in_nbytes,

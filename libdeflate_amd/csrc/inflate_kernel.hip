@@ -502,7 +502,10 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
  *          scan, literals stored at once, matches copied by their lanes as
  *          soon as everything they read lies below the completed watermark
  *          (the first pending match is always ready, so each iteration makes
- *          progress).
+ *          progress).  A wave's vector memory operations reach its L1 in
+ *          issue order, so a later load sees an earlier store of another
+ *          lane without waiting for the write to be acknowledged; only the
+ *          compiler has to be kept from reordering them (wave_sync).
  *
  * Nothing is written to the output before the round is known to be free of
  * anything the sequential decoder has a rule for: it needs the whole input
@@ -628,6 +631,62 @@ static __device__ __forceinline__ void par_copy(u8 *dst, u32 dist, u32 len)
 	}
 }
 
+/*
+ * The wave's most recent PAR_RW output bytes are mirrored in an LDS ring
+ * (byte at output offset p lives at win[p % PAR_RW]): nearly every match
+ * reads from there, an LDS round trip instead of an HBM one on the dependent
+ * path of the copy phase.
+ */
+#define PAR_RW 8192u
+
+static __device__ __forceinline__ u32 win_ld32(const u8 *win, u32 pos)
+{
+	const u32 *w = (const u32 *)win;
+	u32 i = (pos & (PAR_RW - 1)) >> 2;
+	return __builtin_amdgcn_alignbyte(w[(i + 1) & (PAR_RW / 4 - 1)], w[i], pos & 3);
+}
+
+/* copy one match: source from the ring (in_ring) or from the output itself;
+ * destination to both.  s = o - dist. */
+static __device__ __forceinline__ void
+win_copy(u8 *win, u8 *outp, u64 o, u32 dist, u32 len, bool in_ring)
+{
+	const u64 s = o - dist;
+	u32 k = 0;
+
+	if (dist >= 4) {
+		for (; k + 4 <= len; k += 4) {
+			u32 v;
+			if (in_ring)
+				v = win_ld32(win, (u32)(s + k));
+			else
+				__builtin_memcpy(&v, outp + s + k, 4);
+			__builtin_memcpy(outp + o + k, &v, 4);
+#pragma unroll
+			for (u32 j = 0; j < 4; j++)
+				win[(u32)(o + k + j) & (PAR_RW - 1)] = (u8)(v >> (8 * j));
+		}
+		if (k < len) {
+			u32 v;	/* the 4 bytes at s + k exist: dist >= 4 */
+			if (in_ring)
+				v = win_ld32(win, (u32)(s + k));
+			else
+				__builtin_memcpy(&v, outp + s + k, 4);
+			for (; k < len; k++) {
+				outp[o + k] = (u8)v;
+				win[(u32)(o + k) & (PAR_RW - 1)] = (u8)v;
+				v >>= 8;
+			}
+		}
+		return;
+	}
+	for (; k < len; k++) {
+		u8 b = in_ring ? win[(u32)(s + k) & (PAR_RW - 1)] : outp[s + k];
+		outp[o + k] = b;
+		win[(u32)(o + k) & (PAR_RW - 1)] = b;
+	}
+}
+
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
 {
 	u32 lo = __shfl_up((u32)v, 1, 64), hi = __shfl_up((u32)(v >> 32), 1, 64);
@@ -648,8 +707,8 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 static __device__ u32
 par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	  const struct stream_lds *S, const struct shared_lds *SH,
-	  u32 *__restrict__ tok, u32 lane, u64 bpos0, u64 out0,
-	  u64 *bpos_ret, u64 *out_ret)
+	  u32 *__restrict__ tok, u8 *win, u64 ring_lo, u32 lane, u64 bpos0,
+	  u64 out0, u64 *bpos_ret, u64 *out_ret)
 {
 #if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 8
 	if (lane == 0)
@@ -669,6 +728,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	u32 K = 63;		/* last lane of the round */
 	bool has_eob = false;
 
+	PROF_SEC_DECL;
 	/* ---- sync passes ---- */
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
@@ -704,6 +764,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			ns = bpos0;
 		dirty = ns != start;
 		start = ns;
+		PROF_COUNT(15, 1);
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {	/* end of block on the exact prefix */
@@ -717,6 +778,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 #if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 1
 	return PAR_STOP;
 #endif
+	PROF_SEC(0);
 	/* ---- counts -> offsets; clip the round to the token scratch ---- */
 	bool valid = lane <= K;
 	u32 tcnt = valid ? ntok : 0;
@@ -827,8 +889,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		return PAR_STOP;
 #endif
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	wave_sync();
 
 #if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 3
 	return PAR_STOP;
@@ -850,30 +911,39 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			return 77;
 		}
 #endif
-		if (have && !ism && PAR_CHECK(o < out_avail, 15))
+		const u32 gtot = bcast_lane(incl, 63);
+		if (have && !ism && PAR_CHECK(o < out_avail, 15)) {
 			outp[o] = (u8)t;
+			win[(u32)o & (PAR_RW - 1)] = (u8)t;
+		}
 		/* bytes of other tokens this match reads end here */
 		const u64 src_end = o - dist + len;
 		const u64 need_end = src_end < o ? src_end : o;
+		/* the source is in the ring if the ring has held it since it was
+		 * written and this group's own bytes cannot have replaced it */
+		const bool in_ring = o - dist >= ring_lo &&
+				     gbase + gtot - (o - dist) <= PAR_RW;
 		u64 pending = __ballot(ism);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		wave_sync();
 		bool mine = ism;
+		PROF_COUNT(16, 1);
 		while (pending) {
+			PROF_COUNT(17, 1);
 			const u32 f = (u32)__builtin_ctzll(pending);
 			const u64 wmark = readlane64(o, f);
 			const bool ready = mine && need_end <= wmark;
 			if (ready) {
 				if (PAR_CHECK(o + len <= out_avail && dist <= o && dist >= 1, 16))
-				par_copy(outp + o, dist, len);
+					win_copy(win, outp, o, dist, len, in_ring);
 				mine = false;
 			}
 			pending &= ~__ballot(ready);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			wave_sync();
 		}
-		gbase += bcast_lane(incl, 63);
+		gbase += gtot;
 	}
+	PROF_SEC(2);
+	PROF_SEC_FLUSH(18);
 	*bpos_ret = end_bits;
 	*out_ret = out0 + total_bytes;
 	return has_eob ? PAR_EOB : PAR_OK;
@@ -1199,6 +1269,9 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 
 		/* ------------ sub-block parallel rounds (wave per stream) ------------ */
 		if (par) {
+			/* the ring mirrors the output only while parallel rounds
+			 * follow one another */
+			u64 ring_lo = ~0ull;
 			for (;;) {
 				if (!bcast_first(state == ST_TOK ? 1u : 0u))
 					break;
@@ -1209,9 +1282,12 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				const u8 *inp0 = (const u8 *)bcast64((u64)(uintptr_t)inp);
 				u8 *outp0 = (u8 *)bcast64((u64)(uintptr_t)outp);
 				u64 nb = 0, no = 0;
+				if (ring_lo == ~0ull)
+					ring_lo = o0;
 				u32 pr = par_round(inp0, bcast64(in_n), outp0,
 						   bcast64(out_avail), &SL[0], SH, tok,
-						   lane, bpos0, o0, &nb, &no);
+						   (u8 *)(SH + 1), ring_lo, lane, bpos0, o0,
+						   &nb, &no);
 #ifdef LDA_PAR_DEBUG
 				if (g_par_fail) {
 					pr = 77;
@@ -1225,6 +1301,7 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					break;
 				}
 #endif
+				PROF_COUNT(12 + pr, 1);
 				if (pr == PAR_STOP)
 					break;
 				if (lane == 0) {
@@ -1591,6 +1668,11 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 extern "C" size_t lda_inflate_tokcap(void)
 {
 	return PAR_TOKCAP;
+}
+
+extern "C" size_t lda_inflate_window_bytes(void)
+{
+	return PAR_RW;
 }
 
 /* host helper: LDS bytes per stream */

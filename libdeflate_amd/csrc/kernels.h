@@ -35,6 +35,7 @@ lda_inflate_wave_kernel(uint64_t n_chunks, int format, uint32_t *tokscratch,
 			const uint64_t *out_avail, int32_t *results,
 			uint64_t *actual_in, uint64_t *actual_out);
 extern "C" size_t lda_inflate_tokcap(void);
+extern "C" size_t lda_inflate_window_bytes(void);
 extern "C" __global__ void
 lda_inflate_finalize_kernel(uint64_t n_chunks, int format, int exact_fill,
 			    const uint8_t *in_base, const uint64_t *in_offsets,
