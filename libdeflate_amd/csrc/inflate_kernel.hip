@@ -529,13 +529,20 @@ static __device__ u32 g_par_fail;	/* first failed address check */
 #else
 #define PAR_CHECK(cond, code) true
 #endif
+/* 'inp' is the round's input span staged in LDS (8-byte aligned, PAR_SPAN
+ * bytes); b->nb and all bit positions of a round are relative to it */
+#define PAR_SPAN (64u * PAR_CB / 8 + 80)
+
 static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
 {
-#ifdef LDA_PAR_DEBUG
-	if (!PAR_CHECK(b->nb < (1u << 20), 11))
-		return;
-#endif
-	b->buf |= ld8(inp + b->nb) << b->cnt;
+	const u32 *w = (const u32 *)inp;
+	u32 i = (u32)b->nb >> 2, sh = (u32)b->nb & 3;
+	if (i + 2 >= PAR_SPAN / 4)	/* stopped lanes only; keeps reads inside */
+		i = PAR_SPAN / 4 - 3;
+	u32 a = w[i], c = w[i + 1], d = w[i + 2];
+	u64 v = ((u64)__builtin_amdgcn_alignbyte(d, c, sh) << 32) |
+		__builtin_amdgcn_alignbyte(c, a, sh);
+	b->buf |= v << b->cnt;
 	b->nb += (63 - b->cnt) >> 3;
 	b->cnt |= 56;
 }
@@ -558,17 +565,61 @@ struct par_token {
 	u32 kind, lit, length, dist, used;
 };
 
+/*
+ * Codewords longer than the primary tables.  All lanes of a wave parse the
+ * same block, so the canonical first-code / count / index triples of the
+ * lengths beyond the table are wave-uniform: they are fetched once per round
+ * (par_long_init) and the search over the remaining lengths is branch-free.
+ */
+struct par_long {
+	u32 first[16], count[16], index[16];
+};
+
+static __device__ __forceinline__ void
+par_long_init(struct par_long *pl, const struct canon16 *cn, u32 from)
+{
+#pragma unroll
+	for (u32 l = 1; l < 16; l++) {
+		if (l >= from) {
+			pl->first[l] = bcast_first(cn->first[l]);
+			pl->count[l] = bcast_first(cn->count[l]);
+			pl->index[l] = bcast_first(cn->index[l]);
+		}
+	}
+}
+
+template <u32 FROM> static __device__ __forceinline__ u32
+par_long_decode(const struct par_long *pl, const u16 *sorted, u64 bits, u32 *len_ret)
+{
+	const u32 rev = __brev((u32)bits);	/* first code bit on top */
+	u32 idx = 0, len = 15;
+#pragma unroll
+	for (u32 l = 15; l >= FROM; l--) {	/* prefix-free: at most one hit */
+		u32 rel = (rev >> (32 - l)) - pl->first[l];
+		bool hit = rel < pl->count[l];
+		idx = hit ? pl->index[l] + rel : idx;
+		len = hit ? l : len;
+	}
+	*len_ret = len;
+	return sorted[idx];
+}
+
 static __device__ __forceinline__ struct par_token
-par_decode(const struct stream_lds *S, const struct shared_lds *SH, u64 buf)
+par_decode(const struct stream_lds *S, const struct shared_lds *SH,
+	   const struct par_long *pll, const struct par_long *plo, u64 buf)
 {
 	struct par_token t;
 	u32 e = S->lit_tab[(u32)buf & ((1u << LIT_TB) - 1)];
 	u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
 
-	if (cl == 0) {
-		u32 sym = decode_long(&S->lit, S->lit_sorted, buf, &cl);
-		kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
-		pay = sym < 256 ? sym : sym - 257;
+	if (__ballot(cl == 0)) {
+		u32 l2;
+		u32 sym = par_long_decode<LIT_TB + 1>(pll, S->lit_sorted, buf, &l2);
+		if (cl == 0) {
+			cl = l2;
+			kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
+			pay = sym < 256 ? sym : sym - 257;
+		}
 	}
 	u64 bb = buf >> cl;
 	u32 lt = SH->len_tab[pay & 31];
@@ -577,8 +628,14 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH, u64 buf)
 	bb >>= xb;
 	u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
 	u32 ol = e2 & 15, osym = e2 >> 4;
-	if (kind == K_LEN && ol == 0)
-		osym = decode_long(&S->off, S->off_sorted, bb, &ol);
+	if (__ballot(kind == K_LEN && ol == 0)) {
+		u32 l2;
+		u32 sym = par_long_decode<OFF_TB + 1>(plo, S->off_sorted, bb, &l2);
+		if (ol == 0) {
+			ol = l2;
+			osym = sym;
+		}
+	}
 	u32 dt = SH->dist_tab[osym & 31];
 	u32 dxb = dt >> 16;
 	t.dist = (dt & 0xFFFF) + ((u32)(bb >> ol) & ((1u << dxb) - 1));
@@ -707,8 +764,8 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 static __device__ u32
 par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	  const struct stream_lds *S, const struct shared_lds *SH,
-	  u32 *__restrict__ tok, u8 *win, u64 ring_lo, u32 lane, u64 bpos0,
-	  u64 out0, u64 *bpos_ret, u64 *out_ret)
+	  u32 *__restrict__ tok, u8 *win, u8 *stage, u64 ring_lo, u32 lane,
+	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret)
 {
 #if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 8
 	if (lane == 0)
@@ -716,11 +773,24 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	return PAR_STOP;
 #endif
 	u32 cb = PAR_CB;
-	if ((bpos0 >> 3) + 8 * cb + 64 > in_n) {	/* 64 lanes * cb / 8 bytes */
+	if ((bpos_abs >> 3) + 8 * cb + 80 > in_n) {	/* 64 lanes * cb / 8 bytes */
 		cb = PAR_CB / 2;
-		if ((bpos0 >> 3) + 8 * cb + 64 > in_n)
+		if ((bpos_abs >> 3) + 8 * cb + 80 > in_n)
 			return PAR_STOP;
 	}
+	/* stage the span: 8-byte words, unaligned in HBM, aligned in LDS */
+	{
+		const u8 *src = inp + (bpos_abs >> 3);
+		const u32 nw = (8 * cb + 80) / 8;
+		for (u32 w = lane; w < nw; w += 64)
+			*(u64 *)(stage + 8 * w) = ld8(src + 8 * w);
+		wave_sync();
+	}
+	inp = stage;
+	const u64 bpos0 = bpos_abs & 7;	/* positions relative to the span */
+	struct par_long pll, plo;
+	par_long_init(&pll, &S->lit, LIT_TB + 1);
+	par_long_init(&plo, &S->off, OFF_TB + 1);
 	const u64 cend = bpos0 + (u64)(lane + 1) * cb;
 	u64 start = bpos0 + (u64)lane * cb, end = 0;
 	u32 nbytes = 0, ntok = 0;
@@ -742,7 +812,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		while (__ballot(run)) {
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, inp);
-			struct par_token t = par_decode(S, SH, b.buf);
+			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
 			if (run) {
 				if (t.kind == K_EOB) {
 					eob = true;
@@ -764,7 +834,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			ns = bpos0;
 		dirty = ns != start;
 		start = ns;
-		PROF_COUNT(15, 1);
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {	/* end of block on the exact prefix */
@@ -802,7 +871,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	const u64 total_bytes = bcast_lane(obase + bcnt, K);
 	if (total_bytes > out_avail - out0)
 		return PAR_STOP;
-	const u64 end_bits = readlane64(end, K);
+	const u64 end_bits = readlane64(end, K) - bpos0 + bpos_abs;
 
 #if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 2
 	return PAR_STOP;
@@ -832,7 +901,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		while (__ballot(run)) {
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, inp);
-			struct par_token t = par_decode(S, SH, b.buf);
+			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
 			if (run) {
 				b.buf >>= t.used;
 				b.cnt -= t.used;
@@ -926,9 +995,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		u64 pending = __ballot(ism);
 		wave_sync();
 		bool mine = ism;
-		PROF_COUNT(16, 1);
 		while (pending) {
-			PROF_COUNT(17, 1);
 			const u32 f = (u32)__builtin_ctzll(pending);
 			const u64 wmark = readlane64(o, f);
 			const bool ready = mine && need_end <= wmark;
@@ -1286,7 +1353,8 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					ring_lo = o0;
 				u32 pr = par_round(inp0, bcast64(in_n), outp0,
 						   bcast64(out_avail), &SL[0], SH, tok,
-						   (u8 *)(SH + 1), ring_lo, lane, bpos0, o0,
+						   (u8 *)(SH + 1), (u8 *)(SH + 1) + PAR_RW,
+						   ring_lo, lane, bpos0, o0,
 						   &nb, &no);
 #ifdef LDA_PAR_DEBUG
 				if (g_par_fail) {
@@ -1672,7 +1740,7 @@ extern "C" size_t lda_inflate_tokcap(void)
 
 extern "C" size_t lda_inflate_window_bytes(void)
 {
-	return PAR_RW;
+	return PAR_RW + PAR_SPAN;	/* output mirror + staged input span */
 }
 
 /* host helper: LDS bytes per stream */
