@@ -767,21 +767,18 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	  u32 *__restrict__ tok, u8 *win, u8 *stage, u64 ring_lo, u32 lane,
 	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret)
 {
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 8
-	if (lane == 0)
-		tok[0] = 123;
-	return PAR_STOP;
-#endif
-	u32 cb = PAR_CB;
-	if ((bpos_abs >> 3) + 8 * cb + 80 > in_n) {	/* 64 lanes * cb / 8 bytes */
-		cb = PAR_CB / 2;
-		if ((bpos_abs >> 3) + 8 * cb + 80 > in_n)
-			return PAR_STOP;
-	}
+	/* lanes in this round: as many PAR_CB-bit chunks as fit in front of the
+	 * last 80 input bytes (the sequential decoder finishes the stream) */
+	const u32 cb = PAR_CB;
+	const u64 byte0 = bpos_abs >> 3;
+	if (byte0 + 80 + 4 * (cb / 8) > in_n)
+		return PAR_STOP;
+	const u64 room = (in_n - 80 - byte0) / (cb / 8);
+	const u32 NL = room < 64 ? (u32)room : 64;
 	/* stage the span: 8-byte words, unaligned in HBM, aligned in LDS */
 	{
-		const u8 *src = inp + (bpos_abs >> 3);
-		const u32 nw = (8 * cb + 80) / 8;
+		const u8 *src = inp + byte0;
+		const u32 nw = (NL * (cb / 8) + 80) / 8;
 		for (u32 w = lane; w < nw; w += 64)
 			*(u64 *)(stage + 8 * w) = ld8(src + 8 * w);
 		wave_sync();
@@ -794,8 +791,8 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	const u64 cend = bpos0 + (u64)(lane + 1) * cb;
 	u64 start = bpos0 + (u64)lane * cb, end = 0;
 	u32 nbytes = 0, ntok = 0;
-	bool eob = false, dirty = true;
-	u32 K = 63;		/* last lane of the round */
+	bool eob = false, dirty = lane < NL;
+	u32 K = NL - 1;		/* last lane of the round */
 	bool has_eob = false;
 
 	PROF_SEC_DECL;
@@ -832,7 +829,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		u64 ns = shfl_up64(end);
 		if (lane == 0)
 			ns = bpos0;
-		dirty = ns != start;
+		dirty = ns != start && lane < NL;
 		start = ns;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
@@ -844,9 +841,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		if (!dm)
 			break;
 	}
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 1
-	return PAR_STOP;
-#endif
 	PROF_SEC(0);
 	/* ---- counts -> offsets; clip the round to the token scratch ---- */
 	bool valid = lane <= K;
@@ -873,24 +867,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		return PAR_STOP;
 	const u64 end_bits = readlane64(end, K) - bpos0 + bpos_abs;
 
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 2
-	return PAR_STOP;
-#endif
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 4
-	{
-		u32 *dbg = (u32 *)outp;
-		if (lane == 0) {
-			dbg[0] = K; dbg[1] = total_tok; dbg[2] = (u32)total_bytes;
-			dbg[3] = (u32)(end_bits - bpos0); dbg[4] = has_eob; dbg[5] = cb;
-			dbg[6] = (u32)(uintptr_t)tok; dbg[7] = (u32)((uintptr_t)tok >> 32);
-			dbg[8] = (u32)(uintptr_t)outp; dbg[9] = (u32)((uintptr_t)outp >> 32);
-			dbg[10] = (u32)(uintptr_t)inp; dbg[11] = (u32)((uintptr_t)inp >> 32);
-		}
-		dbg[16 + 4 * lane] = ntok; dbg[17 + 4 * lane] = nbytes;
-		dbg[18 + 4 * lane] = (u32)(start - bpos0); dbg[19 + 4 * lane] = (u32)(end - bpos0);
-		return 77;
-	}
-#endif
 	/* ---- emit the tokens ---- */
 	{
 		struct par_bits b;
@@ -910,40 +886,18 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				} else if (t.kind == K_LEN) {
 					if (t.dist > opos)
 						bad = true;
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
-					if (k < PAR_TOKCAP)
-#endif
 					if (PAR_CHECK(k < PAR_TOKCAP, 12))
 					tok[k] = 0x80000000u | t.length | (t.dist << 9);
 					k++;
 					opos += t.length;
 				} else {
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
-					if (k < PAR_TOKCAP)
-#endif
 					if (PAR_CHECK(k < PAR_TOKCAP, 13))
 					tok[k] = t.lit;
 					k++;
 					opos++;
 				}
 			}
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
-			if (k > tbase + 1000)
-				run = false;
-#endif
 		}
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 6
-		{
-			u32 *dbg = (u32 *)outp;
-			if (lane == 0) {
-				dbg[0] = K; dbg[1] = total_tok; dbg[2] = (u32)total_bytes;
-				dbg[3] = (u32)(end_bits - bpos0); dbg[4] = has_eob; dbg[5] = cb;
-			}
-			dbg[16 + 4 * lane] = ntok; dbg[17 + 4 * lane] = k - tbase;
-			dbg[18 + 4 * lane] = tbase; dbg[19 + 4 * lane] = (u32)(PB_POS(b) - bpos0);
-			return 77;
-		}
-#endif
 		if (__ballot(bad))
 			return PAR_STOP;
 #ifdef LDA_PAR_DEBUG
@@ -952,17 +906,9 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			return 77;
 		}
 #endif
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 5
-		if (k == 0xFFFFFFFFu)
-			tok[0] = (u32)opos;
-		return PAR_STOP;
-#endif
 	}
 	wave_sync();
-
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 3
-	return PAR_STOP;
-#endif
+	PROF_SEC(1);
 	/* ---- execute the tokens, 64 at a time ---- */
 	u64 gbase = out0;
 	for (u32 g = 0; g < total_tok; g += 64) {
@@ -985,20 +931,48 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			outp[o] = (u8)t;
 			win[(u32)o & (PAR_RW - 1)] = (u8)t;
 		}
-		/* bytes of other tokens this match reads end here */
+		/* Which earlier tokens of this group does the match read?  Token
+		 * offsets are sorted, so they are the lanes [dep_a, dep_b):
+		 * dep_a = tokens that end at or before the first source byte,
+		 * dep_b = tokens that start before the last byte taken from
+		 * others (binary searches in the offsets, kept in LDS). */
 		const u64 src_end = o - dist + len;
 		const u64 need_end = src_end < o ? src_end : o;
+		u64 depmask = 0;
+		{
+			u32 *po = (u32 *)stage;	/* the staged input is done with */
+			po[lane] = incl - len;
+			if (lane == 63)
+				po[64] = gtot;
+			wave_sync();
+			const bool dep = ism && need_end > gbase;
+			if (__ballot(dep)) {
+				const u32 ne = (u32)(need_end - gbase);
+				const bool sneg = o - dist < gbase;
+				const u32 sr = sneg ? 0 : (u32)(o - dist - gbase);
+				u32 a = 0, b = 0;
+#pragma unroll
+				for (u32 step = 32; step; step >>= 1) {
+					if (po[a + step] <= sr)	/* end of token a+step-1 */
+						a += step;
+					if (po[b + step - 1] < ne)
+						b += step;
+				}
+				if (sneg)
+					a = 0;
+				if (dep && b > a)
+					depmask = ((b >= 64 ? 0 : 1ull << b) - 1) &
+						  ~((1ull << a) - 1);
+			}
+		}
 		/* the source is in the ring if the ring has held it since it was
 		 * written and this group's own bytes cannot have replaced it */
 		const bool in_ring = o - dist >= ring_lo &&
 				     gbase + gtot - (o - dist) <= PAR_RW;
 		u64 pending = __ballot(ism);
-		wave_sync();
 		bool mine = ism;
 		while (pending) {
-			const u32 f = (u32)__builtin_ctzll(pending);
-			const u64 wmark = readlane64(o, f);
-			const bool ready = mine && need_end <= wmark;
+			const bool ready = mine && !(pending & depmask);
 			if (ready) {
 				if (PAR_CHECK(o + len <= out_avail && dist <= o && dist >= 1, 16))
 					win_copy(win, outp, o, dist, len, in_ring);
@@ -1720,10 +1694,6 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_TOKCAP;
-#if defined(LDA_PAR_STAGE) && LDA_PAR_STAGE == 9
-	if (threadIdx.x == 0)
-		tok[0] = 123;
-#endif
 
 	for (u64 blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
 		inflate_block(blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
