@@ -532,6 +532,7 @@ static __device__ u32 g_par_fail;	/* first failed address check */
 /* 'inp' is the round's input span staged in LDS (8-byte aligned, PAR_SPAN
  * bytes); b->nb and all bit positions of a round are relative to it */
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
+#define PAR_STAGE_BYTES (132u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
 
 static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
 {
@@ -695,6 +696,8 @@ static __device__ __forceinline__ void par_copy(u8 *dst, u32 dist, u32 len)
  * path of the copy phase.
  */
 #define PAR_RW 8192u
+#define PAR_GBYTES 1024u	/* output bytes resolved per group */
+#define PAR_LONG 32u		/* matches at least this long are copied by the whole wave */
 
 static __device__ __forceinline__ u32 win_ld32(const u8 *win, u32 pos)
 {
@@ -741,6 +744,42 @@ win_copy(u8 *win, u8 *outp, u64 o, u32 dist, u32 len, bool in_ring)
 		u8 b = in_ring ? win[(u32)(s + k) & (PAR_RW - 1)] : outp[s + k];
 		outp[o + k] = b;
 		win[(u32)(o + k) & (PAR_RW - 1)] = b;
+	}
+}
+
+/*
+ * A long match copied by the whole wave: byte k of the match is byte
+ * k mod dist of its (complete) first period, so all 4-byte pieces are
+ * independent.  o, dist, len, in_ring are wave-uniform.
+ */
+static __device__ __forceinline__ void
+win_copy_wave(u8 *win, u8 *outp, u64 o, u32 dist, u32 len, bool in_ring, u32 lane)
+{
+	const u64 s = o - dist;
+
+	for (u32 k = 4 * lane; k < len; k += 256) {
+		u32 m = dist >= len ? k : k % dist;
+		u32 v;
+		if (m + 4 <= dist) {
+			if (in_ring)
+				v = win_ld32(win, (u32)(s + m));
+			else
+				__builtin_memcpy(&v, outp + s + m, 4);
+		} else {
+			v = 0;
+			for (u32 j = 0; j < 4; j++) {
+				u32 q = m + j;
+				while (q >= dist)
+					q -= dist;
+				u8 b = in_ring ? win[(u32)(s + q) & (PAR_RW - 1)] : outp[s + q];
+				v |= (u32)b << (8 * j);
+			}
+		}
+		u32 nbw = len - k < 4 ? len - k : 4;
+		for (u32 j = 0; j < nbw; j++) {
+			outp[o + k + j] = (u8)(v >> (8 * j));
+			win[(u32)(o + k + j) & (PAR_RW - 1)] = (u8)(v >> (8 * j));
+		}
 	}
 }
 
@@ -909,79 +948,102 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	}
 	wave_sync();
 	PROF_SEC(1);
-	/* ---- execute the tokens, 64 at a time ---- */
-	u64 gbase = out0;
-	for (u32 g = 0; g < total_tok; g += 64) {
-		const bool have = g + lane < total_tok;
-		const u32 t = have && PAR_CHECK(g + lane < PAR_TOKCAP, 14) ? tok[g + lane] : 0;
-		const bool ism = have && (t >> 31);
-		const u32 len = !have ? 0 : ism ? (t & 0x1FF) : 1;
-		const u32 dist = (t >> 9) & 0xFFFF;
-		const u32 incl = wave_scan_incl(len);
-		const u64 o = gbase + incl - len;
-
-#ifdef LDA_PAR_DEBUG
-		if (__ballot(have && (o + len > out0 + total_bytes || (ism && dist > o)))) {
-			*bpos_ret = 2;
-			return 77;
-		}
-#endif
-		const u32 gtot = bcast_lane(incl, 63);
-		if (have && !ism && PAR_CHECK(o < out_avail, 15)) {
-			outp[o] = (u8)t;
-			win[(u32)o & (PAR_RW - 1)] = (u8)t;
-		}
-		/* Which earlier tokens of this group does the match read?  Token
-		 * offsets are sorted, so they are the lanes [dep_a, dep_b):
-		 * dep_a = tokens that end at or before the first source byte,
-		 * dep_b = tokens that start before the last byte taken from
-		 * others (binary searches in the offsets, kept in LDS). */
-		const u64 src_end = o - dist + len;
-		const u64 need_end = src_end < o ? src_end : o;
-		u64 depmask = 0;
-		{
-			u32 *po = (u32 *)stage;	/* the staged input is done with */
-			po[lane] = incl - len;
-			if (lane == 63)
-				po[64] = gtot;
+	/* ---- execute the tokens: up to 64 tokens / PAR_GBYTES bytes a group ----
+	 * The copies of a group are resolved per output BYTE, not per token:
+	 * byte b of the group is a literal, or a copy of the byte dist before
+	 * it; that byte may again be a copy inside the group (every word of a
+	 * table of counters copies three bytes from the word before it).  Each
+	 * byte starts with a pointer to its source inside the group (itself for
+	 * literals and for copies from before the group, the "roots"), pointer
+	 * doubling takes every byte to its root in log2(chain) steps whatever
+	 * the shape of the dependencies, the roots fetch their values (the LDS
+	 * mirror of the recent output, or the output itself when it is further
+	 * back) and the rest read theirs from their root. */
+	{
+		u32 *po = (u32 *)stage;			/* [65] token byte offsets */
+		u32 *tk = (u32 *)stage + 66;		/* [64] the group's tokens */
+		u16 *R = (u16 *)((u32 *)stage + 132);	/* [PAR_GBYTES] byte -> source byte */
+		u64 gbase = out0;
+		u32 g = 0;
+		while (g < total_tok) {
+			const bool have0 = g + lane < total_tok;
+			const u32 t = have0 ? tok[g + lane] : 0;
+			const u32 len0 = !have0 ? 0 : (t >> 31) ? (t & 0x1FF) : 1;
+			const u32 incl0 = wave_scan_incl(len0);
+			/* the tokens that fit: a prefix (offsets are increasing) */
+			const bool fits = have0 && incl0 <= PAR_GBYTES;
+			const u32 cnt = __builtin_popcountll(__ballot(fits));
+			const u32 gtot = bcast_lane(incl0, cnt - 1);
+			po[lane] = incl0 - len0;
+			tk[lane] = t;
+			if (lane == 0)
+				po[64] = 0xFFFFFFFFu;
 			wave_sync();
-			const bool dep = ism && need_end > gbase;
-			if (__ballot(dep)) {
-				const u32 ne = (u32)(need_end - gbase);
-				const bool sneg = o - dist < gbase;
-				const u32 sr = sneg ? 0 : (u32)(o - dist - gbase);
-				u32 a = 0, b = 0;
+			if (lane == cnt)
+				po[cnt] = 0xFFFFFFFFu;	/* searches stop at the group's end */
+			wave_sync();
+			/* bytes -> tokens -> source pointers; roots take their value */
+			for (u32 b0 = 0; b0 < gtot; b0 += 64) {
+				const u32 bi = b0 + lane;
+				if (bi < gtot) {
+					u32 ti = 0;	/* last token with po[ti] <= bi */
 #pragma unroll
-				for (u32 step = 32; step; step >>= 1) {
-					if (po[a + step] <= sr)	/* end of token a+step-1 */
-						a += step;
-					if (po[b + step - 1] < ne)
-						b += step;
+					for (u32 step = 32; step; step >>= 1)
+						if (po[ti + step] <= bi)
+							ti += step;
+					const u32 tw = tk[ti];
+					const u32 dist = (tw >> 9) & 0xFFFF;
+					u32 src = bi;
+					u32 v = tw & 0xFF;
+					if (tw >> 31) {
+						if (dist <= bi) {
+							src = bi - dist;
+						} else {
+							const u64 sp = gbase + bi - dist;
+							v = sp >= ring_lo &&
+							    gbase + gtot - sp <= PAR_RW ?
+								win[(u32)sp & (PAR_RW - 1)] : outp[sp];
+						}
+					}
+					R[bi] = (u16)src;
+					if (src == bi) {
+						win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)v;
+						outp[gbase + bi] = (u8)v;
+					}
 				}
-				if (sneg)
-					a = 0;
-				if (dep && b > a)
-					depmask = ((b >= 64 ? 0 : 1ull << b) - 1) &
-						  ~((1ull << a) - 1);
 			}
-		}
-		/* the source is in the ring if the ring has held it since it was
-		 * written and this group's own bytes cannot have replaced it */
-		const bool in_ring = o - dist >= ring_lo &&
-				     gbase + gtot - (o - dist) <= PAR_RW;
-		u64 pending = __ballot(ism);
-		bool mine = ism;
-		while (pending) {
-			const bool ready = mine && !(pending & depmask);
-			if (ready) {
-				if (PAR_CHECK(o + len <= out_avail && dist <= o && dist >= 1, 16))
-					win_copy(win, outp, o, dist, len, in_ring);
-				mine = false;
-			}
-			pending &= ~__ballot(ready);
 			wave_sync();
+			/* pointer doubling to the roots */
+			for (;;) {
+				bool changed = false;
+				for (u32 b0 = 0; b0 < gtot; b0 += 64) {
+					const u32 bi = b0 + lane;
+					if (bi < gtot) {
+						u32 r = R[bi], rr = R[r];
+						changed |= rr != r;
+						R[bi] = (u16)rr;
+					}
+				}
+				wave_sync();
+				if (!__ballot(changed))
+					break;
+			}
+			/* everyone else copies its root's value */
+			for (u32 b0 = 0; b0 < gtot; b0 += 64) {
+				const u32 bi = b0 + lane;
+				if (bi < gtot) {
+					const u32 r = R[bi];
+					if (r != bi) {
+						const u8 v = win[(u32)(gbase + r) & (PAR_RW - 1)];
+						win[(u32)(gbase + bi) & (PAR_RW - 1)] = v;
+						outp[gbase + bi] = v;
+					}
+				}
+			}
+			wave_sync();
+			gbase += gtot;
+			g += cnt;
 		}
-		gbase += gtot;
 	}
 	PROF_SEC(2);
 	PROF_SEC_FLUSH(18);
@@ -1710,7 +1772,7 @@ extern "C" size_t lda_inflate_tokcap(void)
 
 extern "C" size_t lda_inflate_window_bytes(void)
 {
-	return PAR_RW + PAR_SPAN;	/* output mirror + staged input span */
+	return PAR_RW + PAR_STAGE_BYTES;	/* output mirror + staged input span */
 }
 
 /* host helper: LDS bytes per stream */
