@@ -191,10 +191,6 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 					grid * lda_inflate_tokcap() * 4);
 		if (!tok)
 			return LIBDEFLATE_AMD_OOM;
-		if (getenv("LDA_DEBUG_PTRS"))
-			fprintf(stderr, "tok %p (%zu B) in %p out %p results %p ain %p aout %p scratch %p\n",
-				(void *)tok, d->tokens.cap, d_in, d_out, (void *)d_results,
-				(void *)ain, (void *)aout, d->scratch.p);
 		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared() +
 			     lda_inflate_window_bytes();
 		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
@@ -213,10 +209,6 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 				   d_results, ain, aout);
 	}
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
-	if (getenv("LDA_DEBUG_SYNC")) {
-		hipError_t e = hipStreamSynchronize(st);
-		fprintf(stderr, "inflate kernel done: %s\n", hipGetErrorString(e));
-	}
 	if (format != LIBDEFLATE_AMD_DEFLATE) {
 		int rc = format == LIBDEFLATE_AMD_GZIP ?
 			libdeflate_amd_crc32_batch(n, d_out, d_out_offsets, aout,

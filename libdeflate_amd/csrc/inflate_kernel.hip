@@ -10,12 +10,22 @@
  * (footer verification runs in lda_inflate_finalize_kernel after the batched
  * checksum kernel.)
  *
- * Huffman decoding is a serial dependence chain per stream (the next symbol
- * starts where this one ends), so a stream can keep exactly one lane busy
- * with entropy decoding - measured: a wave that gives all 64 lanes to one
- * stream spends >90 % of its issue slots with 63 lanes masked off.  Mapping
- * used here: ONE LANE PER STREAM.  A wave carries `lpw` streams (lanes
- * 0..lpw-1); every wave instruction advances all of them:
+ * Two mappings share the sequential decoder in inflate_block():
+ *
+ * WAVE PER STREAM (lda_inflate_wave_kernel, the default).  Inside a Huffman
+ * block the 64 lanes parse 64 consecutive 256-bit pieces of the input at
+ * once: a parse started at an arbitrary bit falls in step with the true one
+ * within a few dozen bits, so a couple of passes in which every lane restarts
+ * where its left neighbour ended give the exact token boundaries; the tokens
+ * are then executed byte-parallel ("sub-block parallel token decoding"
+ * below).  Headers, stored blocks, the last bytes of a stream and every error
+ * path run on lane 0 through the sequential code, so result codes are the
+ * same in both mappings.
+ *
+ * LANE PER STREAM (lda_inflate_batch_kernel, LDA_INFLATE_PAR=0).  Huffman
+ * decoding is a serial dependence chain per stream, so here a stream keeps
+ * exactly one lane busy.  A wave carries `lpw` streams (lanes 0..lpw-1);
+ * every wave instruction advances all of them:
  *
  *   - per-stream state lives in registers (64-bit bit buffer, one 8-byte
  *     word of input prefetched ahead, output cursor) and 2112 bytes of LDS
@@ -498,13 +508,12 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
  *   emit   with exact starts and prefix sums of the counts, every lane
  *          parses once more and writes its tokens (literal byte, or length
  *          and distance) to the wave's token scratch in HBM;
- *   copy   the tokens are executed 64 at a time: output offsets by a wave
- *          scan, literals stored at once, matches copied by their lanes as
- *          soon as everything they read lies below the completed watermark
- *          (the first pending match is always ready, so each iteration makes
- *          progress).  A wave's vector memory operations reach its L1 in
- *          issue order, so a later load sees an earlier store of another
- *          lane without waiting for the write to be acknowledged; only the
+ *   copy   the tokens are executed in groups of up to 64 tokens / 1 KiB of
+ *          output, resolved per output byte by pointer doubling (see the
+ *          copy phase in par_round); sources come from an 8 KiB LDS mirror
+ *          of the recent output.  A wave's vector memory operations reach
+ *          its L1 in issue order, so loads see earlier stores of other
+ *          lanes without waiting for write acknowledgements; only the
  *          compiler has to be kept from reordering them (wave_sync).
  *
  * Nothing is written to the output before the round is known to be free of
@@ -523,12 +532,6 @@ struct par_bits {
 	u32 cnt;
 };
 
-#ifdef LDA_PAR_DEBUG
-static __device__ u32 g_par_fail;	/* first failed address check */
-#define PAR_CHECK(cond, code) ((cond) ? true : (atomicCAS(&g_par_fail, 0u, (u32)(code)), false))
-#else
-#define PAR_CHECK(cond, code) true
-#endif
 /* 'inp' is the round's input span staged in LDS (8-byte aligned, PAR_SPAN
  * bytes); b->nb and all bit positions of a round are relative to it */
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
@@ -646,49 +649,6 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH,
 	return t;
 }
 
-/* exact-length forward copy of one match inside the output */
-static __device__ __forceinline__ void par_copy(u8 *dst, u32 dist, u32 len)
-{
-	const u8 *src = dst - dist;
-	u32 k = 0;
-
-	if (dist >= 8) {
-		for (; k + 8 <= len; k += 8)
-			st8(dst + k, ld8(src + k));
-		if (k + 4 <= len) {
-			u32 v;
-			__builtin_memcpy(&v, src + k, 4);
-			__builtin_memcpy(dst + k, &v, 4);
-			k += 4;
-		}
-		if (k + 2 <= len) {
-			u16 v;
-			__builtin_memcpy(&v, src + k, 2);
-			__builtin_memcpy(dst + k, &v, 2);
-			k += 2;
-		}
-		if (k < len)
-			dst[k] = src[k];
-		return;
-	}
-	/* period 1..7: one load, the period expanded and rotated in registers */
-	u64 w = 0;
-	for (u32 j = 0; j < dist; j++)
-		w |= (u64)src[j] << (8 * j);
-	for (u32 sh = 8 * dist; sh < 64; sh *= 2)
-		w |= w << sh;
-	const u32 r = 8 % dist;
-	for (; k + 8 <= len; k += 8) {
-		st8(dst + k, w);
-		if (r)
-			w = (w >> (8 * r)) | (w << (8 * (dist - r)));
-	}
-	for (; k < len; k++) {
-		dst[k] = (u8)w;
-		w >>= 8;
-	}
-}
-
 /*
  * The wave's most recent PAR_RW output bytes are mirrored in an LDS ring
  * (byte at output offset p lives at win[p % PAR_RW]): nearly every match
@@ -697,91 +657,6 @@ static __device__ __forceinline__ void par_copy(u8 *dst, u32 dist, u32 len)
  */
 #define PAR_RW 8192u
 #define PAR_GBYTES 1024u	/* output bytes resolved per group */
-#define PAR_LONG 32u		/* matches at least this long are copied by the whole wave */
-
-static __device__ __forceinline__ u32 win_ld32(const u8 *win, u32 pos)
-{
-	const u32 *w = (const u32 *)win;
-	u32 i = (pos & (PAR_RW - 1)) >> 2;
-	return __builtin_amdgcn_alignbyte(w[(i + 1) & (PAR_RW / 4 - 1)], w[i], pos & 3);
-}
-
-/* copy one match: source from the ring (in_ring) or from the output itself;
- * destination to both.  s = o - dist. */
-static __device__ __forceinline__ void
-win_copy(u8 *win, u8 *outp, u64 o, u32 dist, u32 len, bool in_ring)
-{
-	const u64 s = o - dist;
-	u32 k = 0;
-
-	if (dist >= 4) {
-		for (; k + 4 <= len; k += 4) {
-			u32 v;
-			if (in_ring)
-				v = win_ld32(win, (u32)(s + k));
-			else
-				__builtin_memcpy(&v, outp + s + k, 4);
-			__builtin_memcpy(outp + o + k, &v, 4);
-#pragma unroll
-			for (u32 j = 0; j < 4; j++)
-				win[(u32)(o + k + j) & (PAR_RW - 1)] = (u8)(v >> (8 * j));
-		}
-		if (k < len) {
-			u32 v;	/* the 4 bytes at s + k exist: dist >= 4 */
-			if (in_ring)
-				v = win_ld32(win, (u32)(s + k));
-			else
-				__builtin_memcpy(&v, outp + s + k, 4);
-			for (; k < len; k++) {
-				outp[o + k] = (u8)v;
-				win[(u32)(o + k) & (PAR_RW - 1)] = (u8)v;
-				v >>= 8;
-			}
-		}
-		return;
-	}
-	for (; k < len; k++) {
-		u8 b = in_ring ? win[(u32)(s + k) & (PAR_RW - 1)] : outp[s + k];
-		outp[o + k] = b;
-		win[(u32)(o + k) & (PAR_RW - 1)] = b;
-	}
-}
-
-/*
- * A long match copied by the whole wave: byte k of the match is byte
- * k mod dist of its (complete) first period, so all 4-byte pieces are
- * independent.  o, dist, len, in_ring are wave-uniform.
- */
-static __device__ __forceinline__ void
-win_copy_wave(u8 *win, u8 *outp, u64 o, u32 dist, u32 len, bool in_ring, u32 lane)
-{
-	const u64 s = o - dist;
-
-	for (u32 k = 4 * lane; k < len; k += 256) {
-		u32 m = dist >= len ? k : k % dist;
-		u32 v;
-		if (m + 4 <= dist) {
-			if (in_ring)
-				v = win_ld32(win, (u32)(s + m));
-			else
-				__builtin_memcpy(&v, outp + s + m, 4);
-		} else {
-			v = 0;
-			for (u32 j = 0; j < 4; j++) {
-				u32 q = m + j;
-				while (q >= dist)
-					q -= dist;
-				u8 b = in_ring ? win[(u32)(s + q) & (PAR_RW - 1)] : outp[s + q];
-				v |= (u32)b << (8 * j);
-			}
-		}
-		u32 nbw = len - k < 4 ? len - k : 4;
-		for (u32 j = 0; j < nbw; j++) {
-			outp[o + k + j] = (u8)(v >> (8 * j));
-			win[(u32)(o + k + j) & (PAR_RW - 1)] = (u8)(v >> (8 * j));
-		}
-	}
-}
 
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
 {
@@ -925,12 +800,10 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				} else if (t.kind == K_LEN) {
 					if (t.dist > opos)
 						bad = true;
-					if (PAR_CHECK(k < PAR_TOKCAP, 12))
 					tok[k] = 0x80000000u | t.length | (t.dist << 9);
 					k++;
 					opos += t.length;
 				} else {
-					if (PAR_CHECK(k < PAR_TOKCAP, 13))
 					tok[k] = t.lit;
 					k++;
 					opos++;
@@ -939,12 +812,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		}
 		if (__ballot(bad))
 			return PAR_STOP;
-#ifdef LDA_PAR_DEBUG
-		if (__ballot(valid && (k - tbase != ntok || opos - (out0 + obase) != nbytes))) {
-			*bpos_ret = 1;
-			return 77;
-		}
-#endif
 	}
 	wave_sync();
 	PROF_SEC(1);
@@ -1392,19 +1259,6 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 						   (u8 *)(SH + 1), (u8 *)(SH + 1) + PAR_RW,
 						   ring_lo, lane, bpos0, o0,
 						   &nb, &no);
-#ifdef LDA_PAR_DEBUG
-				if (g_par_fail) {
-					pr = 77;
-					nb = g_par_fail;
-				}
-				if (pr == 77) {
-					if (lane == 0) {
-						result = 100 + (s32)nb;
-						state = ST_DONE;
-					}
-					break;
-				}
-#endif
 				PROF_COUNT(12 + pr, 1);
 				if (pr == PAR_STOP)
 					break;

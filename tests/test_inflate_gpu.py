@@ -190,3 +190,70 @@ def test_many_streams_all_formats(dec):
         assert torch.equal(d_out.view(n // distinct, distinct * size),
                            want.expand(n // distinct, distinct * size))
         del d_in, d_out
+
+
+def _big_stream_cases(ref, seed):
+    """Streams long enough for the sub-block parallel rounds, in the shapes
+    that exercise their hand-overs to the sequential decoder."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    datas = [("text", datagen.chunk(0, 65536, seed)),
+             ("binary", datagen.chunk(5, 65536, seed)),
+             ("lowent", datagen.chunk(6, 40000, seed)),
+             ("zeros", bytes(70000)),
+             ("runs", (b"ab" * 700 + bytes(3000) + b"xyz" * 900) * 8),
+             ("far", datagen.chunk(1, 33000, seed) * 3),      # distances ~32 KiB
+             ("multi", b"".join(datagen.chunk(k, 30000, seed + k) for k in (0, 7, 5, 6, 0)))]
+    for name, d in datas:
+        for lvl in (1, 6, 12):
+            for fmt in ("deflate", "gzip"):
+                s = ref.compress(fmt, lvl, d)
+                n = len(d)
+                cases.append((fmt, s, n, True, f"{name}/l{lvl}"))
+                cases.append((fmt, s, n, False, f"{name}/l{lvl}/exact"))
+                # output buffers that end inside / just before the data
+                for short in (1, 7, 300, n // 2):
+                    cases.append((fmt, s, n - short, True, f"{name}/l{lvl}/short{short}"))
+                cases.append((fmt, s, n + 100, False, f"{name}/l{lvl}/long"))
+                # truncated input and flipped bytes deep inside the stream
+                for cut in (len(s) // 2, len(s) - 9, len(s) - 40):
+                    cases.append((fmt, s[:cut], n, True, f"{name}/l{lvl}/cut{cut}"))
+                for _ in range(6):
+                    pos = int(rng.integers(20, len(s) - 10))
+                    bad = bytearray(s)
+                    bad[pos] ^= 1 << int(rng.integers(0, 8))
+                    cases.append((fmt, bytes(bad), n, True, f"{name}/l{lvl}/flip{pos}"))
+    return cases
+
+
+def test_parallel_rounds_vs_oracle(dec, oracle):
+    """Result codes, sizes and bytes of long streams - valid, truncated,
+    corrupted, with short and long output buffers - against the oracle."""
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    _run_cases(dec, oracle, _big_stream_cases(ref, 0x0E110021))
+
+
+def test_both_mappings_agree(dec, oracle, monkeypatch):
+    """wave-per-stream (parallel rounds) and lane-per-stream give the same
+    result codes and bytes on the same batch."""
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    cases = _big_stream_cases(ref, 0x0E110022)[::3]
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        got = []
+        for want in (True, False):
+            grp = [c for c in cases if c[3] == want]
+            got += dec.decompress_batch_host("gzip", [c[1] for c in grp if c[0] == "gzip"],
+                                             [c[2] for c in grp if c[0] == "gzip"], want)
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert a[0] == b[0]
+        if a[0] == 0:
+            assert a[1:] == b[1:]

@@ -1,3 +1,5 @@
+"""Decode N reference-compressed chunks on the GPU and compare every byte.
+Usage: python tools/check_inflate.py [N] [size]   (LDA_INFLATE_PAR=0 selects lane-per-stream)"""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import torch
@@ -31,10 +33,3 @@ for i in range(n):
         if first >= 0:
             print('  exp', exp[first-8:first+24]); print('  got', got[first-8:first+24])
 print('done', sum(1 for x in r if x == 0), '/', n)
-import numpy as np
-if os.environ.get('DBG'):
-    a = np.frombuffer(o[:16*4+64*16], dtype=np.uint32)
-    print('K,total_tok,total_bytes,endbits,has_eob,cb =', a[:6])
-    print('tok %x outp %x inp %x' % (int(a[6]) | int(a[7])<<32, int(a[8]) | int(a[9])<<32, int(a[10]) | int(a[11])<<32), 'out tensor %x in tensor %x' % (out.data_ptr(), d_in.data_ptr()))
-    for l in range(64):
-        print(l, a[16+4*l:20+4*l])
