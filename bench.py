@@ -241,6 +241,7 @@ def main():
                 "note": "HIP events on the launch stream around the compress "
                         "call (deflate kernel + the ~0.05 ms CRC-32 kernel)",
                 "inflate_kernel": {
+                    "kernel": "lda_inflate_wave_kernel",
                     "achieved": round((U + C) / t_dec / 1e9, 2),
                     "frac": round((U + C) / t_dec / 1e9 / HBM_PEAK_GBS, 5),
                     "avg_launch_ms": round(t_dec * 1e3, 3)},

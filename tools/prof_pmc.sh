@@ -14,13 +14,21 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
      python $R/tools/microbench.py $what --chunks 4096 --iters 2 > /dev/null 2>&1 || echo "pass failed: $grp"
 done
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+out = collections.defaultdict(dict)
 for f in sorted(glob.glob("$R/gpurun_out/pmc_$what/*/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:40]
+        k = r["Kernel_Name"].split("(")[0]
+        if not k.startswith("lda_"):
+            continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
     for k, d in agg.items():
-        if "lda_" in k:
-            print(k, {c: f"{v:.4g}" for c, v in d.items()})
+        for c, v in d.items():
+            out[k][c + "_per_launch"] = v / max(1, len(disp[k]))
+json.dump(out, open("$R/gpurun_out/pmc_$what.json", "w"), indent=1, sort_keys=True)
+for k, d in out.items():
+    print(k, {c: f"{v:.4g}" for c, v in d.items()})
 PY
