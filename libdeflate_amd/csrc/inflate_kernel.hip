@@ -510,7 +510,7 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
  *          and distance) to the wave's token scratch in HBM;
  *   copy   the tokens are executed in groups of up to 64 tokens / 1 KiB of
  *          output, resolved per output byte by pointer doubling (see the
- *          copy phase in par_round); sources come from an 8 KiB LDS mirror
+ *          copy phase in par_round); sources come from a 4 KiB LDS mirror
  *          of the recent output.  A wave's vector memory operations reach
  *          its L1 in issue order, so loads see earlier stores of other
  *          lanes without waiting for write acknowledgements; only the
@@ -655,7 +655,9 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH,
  * reads from there, an LDS round trip instead of an HBM one on the dependent
  * path of the copy phase.
  */
-#define PAR_RW 8192u
+#ifndef PAR_RW
+#define PAR_RW 4096u
+#endif
 #define PAR_GBYTES 1024u	/* output bytes resolved per group */
 
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
@@ -1596,7 +1598,10 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
  * (each wave owns PAR_TOKCAP words of the token scratch and walks the
  * streams blockIdx.x, blockIdx.x + gridDim.x, ...).
  */
-extern "C" __global__ void __launch_bounds__(64, 3)
+#ifndef PAR_WAVES_PER_SIMD
+#define PAR_WAVES_PER_SIMD 4	/* 16 streams in flight per CU: occupancy hides the LDS chains */
+#endif
+extern "C" __global__ void __launch_bounds__(64, PAR_WAVES_PER_SIMD)
 lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 			const u8 *__restrict__ in_base,
 			const u64 *__restrict__ in_offsets,
