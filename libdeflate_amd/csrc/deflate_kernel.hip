@@ -923,6 +923,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
 					const u32 min_len = L->vars[V_MINLEN];
+					const u32 drain = depth >> 3 > 8 ? depth >> 3 : 8;
 					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 					    cnt = 0, boff = 0, curb = 0;
@@ -942,6 +943,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (lane == 0)
 								cbase = atomicAdd(&L->vars[V_CTR], nf);
 							cbase = bcast_first(cbase);
+							/* every position is taken: the chains still
+							 * running are what the other 15 waves will wait
+							 * for, so their remaining depth is cut (about one
+							 * position in twenty; +0.1 % output at level 6
+							 * for -5 % time) */
+							if (cbase + nf >= TILE && dep > drain)
+								dep = drain;
 							if (fin) {
 								if (my_i < TILE)
 									L->M[4 + my_i] =
