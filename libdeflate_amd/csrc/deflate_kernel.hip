@@ -107,7 +107,7 @@ struct deflate_lds {
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1
+	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY
 };
 
 struct level_params {
@@ -392,7 +392,9 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		wave_sync();
 		if (lane == 0) {
 			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
-			 * creation order (ascending too); heads cached in registers */
+			 * creation order (ascending too); heads cached in registers
+			 * (a variant that also prefetched the following entries had
+			 * more instructions on this single-lane path and was slower) */
 			u32 leaf = 0, node = 0;
 			u32 wl = H->A[0], wn = 0xFFFFFFFFu;
 			for (u32 k = 0; k + 1 < m; k++) {
@@ -836,19 +838,26 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						(last ? M_LAST : 0) |
 						(isv ? M_VALID : 0);
 				}
+				if (tid == NT - 1) {
+					L->vars[V_CTR] = 0;
+					L->vars[V_READY] = 0;
+				}
 				__syncthreads();
 
 				PROF_MARK(2);
-				/* ---- S2: thread groups through head[] in order ---- */
-				if (tid == NT - 1)
-					L->vars[V_CTR] = 0;
+				/* ---- S2: thread groups through head[] in order ----
+				 * Only wave 0 (hash chains) and wave 1 (3-byte table) do
+				 * this; chains only ever look backwards, so the other waves
+				 * start searching at once and wave 0 publishes how far the
+				 * chains are complete (V_READY) after every batch of groups;
+				 * claims beyond that wait. */
 				/* A wave's LDS operations execute in issue order, so the
 				 * read-old-head / write-new-head pairs of all groups are
 				 * issued back to back (no wait in between); the values read
 				 * are stored to prev[] afterwards. */
 				if (wave == 0) {
 					const u32 ngroups = (tend - t + 63) / 64;
-					enum { GB = 16 };	/* groups in flight */
+					enum { GB = 8 };	/* groups in flight */
 					for (u32 g0 = 0; g0 < ngroups; g0 += GB) {
 						u32 v[GB];
 #pragma unroll
@@ -873,7 +882,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (v[k] != 0xFFFFFFFFu)
 								L->prev[(t + (g0 + k) * 64 + lane) & RMASK] =
 									(u16)v[k];
+						/* LDS writes of a wave land in issue order */
+						if (lane == 0)
+							*(volatile u32 *)&L->vars[V_READY] =
+								g0 + GB < ngroups ? (g0 + GB) * 64 : TILE;
 					}
+					if (lane == 0)
+						*(volatile u32 *)&L->vars[V_READY] = TILE;
 				} else if (wave == 1) {
 					/* 3-byte table, same order, on its own wave: candidate
 					 * = last position of an EARLIER group with this hash */
@@ -901,7 +916,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								L->nxtA[4 + (g0 + k) * 64 + lane] = (u16)v[k];
 					}
 				}
-				__syncthreads();
 
 				PROF_MARK(3);
 				/* ---- S3: all positions search their chain ----
@@ -943,6 +957,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (lane == 0)
 								cbase = atomicAdd(&L->vars[V_CTR], nf);
 							cbase = bcast_first(cbase);
+							{	/* chains complete up to the claimed ones? */
+								const u32 need = cbase + nf < TILE ? cbase + nf : TILE;
+								if (cbase < TILE)
+									while (*(volatile u32 *)&L->vars[V_READY] < need)
+										__builtin_amdgcn_s_sleep(4);
+							}
 							/* every position is taken: the chains still
 							 * running are what the other 15 waves will wait
 							 * for, so their remaining depth is cut (about one
