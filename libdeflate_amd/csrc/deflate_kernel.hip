@@ -57,9 +57,15 @@
 #define LOOKAHEAD 272u
 #define HASH_BITS 13
 #define HASH3_BITS 12
-#define SEQ_CAP 3072u
+/*
+ * The matches of the current block live in HBM (8 bytes each, one list per
+ * workgroup): nothing of a block has to stay in LDS until the block is
+ * written, so a block can be as long as the reference's (one block for a
+ * 64 KiB buffer; soft maximum as lib/deflate_compress.c:90).
+ */
+#define MAX_BLOCK_LEN 131072u
 #define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile (min match 3) */
-#define MAX_BLOCK_SOFT (RING - LOOKAHEAD - 2 * TILE - 300)
+#define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
 #define EWIN 2048u		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
@@ -81,8 +87,6 @@ struct deflate_lds {
 	u16 prev[RING];
 	u16 head[1u << HASH_BITS];
 	u16 head3[1u << HASH3_BITS];	/* last position per 3-byte hash (no chain) */
-	u32 seq_pl[SEQ_CAP];	/* block-relative position | length << 16 */
-	u16 seq_d[SEQ_CAP];	/* distance */
 	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
 	u8 mark[TILE + 8];	/* 1 = literal chosen at this position */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
@@ -663,11 +667,14 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			 const u64 *__restrict__ out_offsets,
 			 const u64 *__restrict__ out_avail_arr,
 			 u64 *__restrict__ out_nbytes,
-			 const u32 *__restrict__ sums)
+			 const u32 *__restrict__ sums,
+			 u64 *__restrict__ seq_scratch)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
 	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	/* block-relative position | length << 32 | distance << 41 */
+	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_GCAP;
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
@@ -1198,9 +1205,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								}
 								if (ism) {
 									u32 sl, xb, xv;
-									L->seq_pl[seq0 + npre] =
-										(pos - block_start) | (l0 << 16);
-									L->seq_d[seq0 + npre] = (u16)(mm >> 16);
+									seqg[seq0 + npre] = (pos - block_start) |
+										((u64)l0 << 32) | ((u64)(mm >> 16) << 41);
 									length_code(l0, &sl, &xb, &xv);
 									atomicAdd(&L->freq[257 + sl], 1u);
 									dist_code(mm >> 16, &sl, &xb, &xv);
@@ -1297,13 +1303,16 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							u32 idx = seg_lo + lane + 64 * k;
 							u32 at = base + (k ? c0 + __builtin_popcountll(bal1 & lt) :
 									 __builtin_popcountll(bal0 & lt));
-							L->seq_pl[at] = (t + idx - 4 - block_start) |
-									((m0[k] & 0xFFFF) << 16);
-							L->seq_d[at] = (u16)(m0[k] >> 16);
+							seqg[at] = (t + idx - 4 - block_start) |
+								   ((u64)(m0[k] & 0xFFFF) << 32) |
+								   ((u64)(m0[k] >> 16) << 41);
 						}
 					}
 					if (tid == 0)
 						L->vars[V_NSEQ] = seq0 + npre + tot;
+					/* the match list is read back by other waves at the
+					 * end of the block */
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				}
 				__syncthreads();
 				walkpos = L->vars[V_WALKPOS_LO];
@@ -1321,8 +1330,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			PROF_MARK(6);
 			/* ---- block end? ---- */
 			bool end_block = last_tile ||
-				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_CAP) ||
-				walkpos - block_start > MAX_BLOCK_SOFT;
+				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_GCAP) ||
+				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
 				continue;
 
@@ -1575,8 +1584,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						__syncthreads();
 						for (u32 j = tid; j < cnt; j += NT) {
 							u32 pos = bstart + done + w0 + j;
-							stg_put(L, &os, os.bits + 8ull * j,
-								L->in[pos & RMASK], 8);
+							stg_put(L, &os, os.bits + 8ull * j, inp[pos], 8);
 						}
 						os.bits += 8ull * cnt;
 						__syncthreads();
@@ -1668,23 +1676,32 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				}
 				__syncthreads();
 				u32 wpar = 0;
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				for (u32 w0 = bstart; w0 < bend; w0 += EWIN, wpar ^= 1) {
 					u32 wend = w0 + EWIN < bend ? w0 + EWIN : bend;
 					const u32 v_spill_next = wpar ? V_SPILL : V_SPILL1;
 					const u32 v_cnt = wpar ? V_SEQCNT1 : V_SEQCNT;
+					/* this thread's input bytes, from HBM (the block may be
+					 * longer than the LDS ring); in flight during the scatter */
+					u8 litb[(EWIN + NT - 1) / NT];
+#pragma unroll
+					for (u32 k = 0; k < (EWIN + NT - 1) / NT; k++) {
+						u32 pos = w0 + tid * ((EWIN + NT - 1) / NT) + k;
+						litb[k] = pos < wend ? inp[pos] : 0;
+					}
 					/* matches that start in this window (the list is
 					 * position-sorted and holds < NT of them per window) */
 					{
 						u32 sidx = seq_lo + tid;
 						bool mine = false;
 						if (sidx < nseq) {
-							u32 pl = L->seq_pl[sidx];
-							u32 pos = bstart + (pl & 0xFFFF);
+							u64 sq = seqg[sidx];
+							u32 pos = bstart + (u32)sq;
 							if (pos < wend) {
-								u32 len = pl >> 16;
+								u32 len = (u32)(sq >> 32) & 0x1FF;
 								u32 q = pos - w0;
 								mine = true;
-								KD[q] = len | ((u32)L->seq_d[sidx] << 16);
+								KD[q] = len | ((u32)(sq >> 41) << 16);
 								for (u32 j = 1; j < len && q + j < EWIN; j++)
 									KD[q + j] = 0xFFFFFFFFu;
 								if (pos + len > w0 + EWIN)
@@ -1716,7 +1733,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						if (kd == 0xFFFFFFFFu)
 							continue;
 						if (kd == 0) {
-							u32 b = L->in[pos & RMASK];
+							u32 b = litb[k];
 							code[k] = L->codes[b];
 							nb[k] = L->lens[b];
 						} else {
@@ -1827,6 +1844,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 extern "C" size_t lda_deflate_lds_bytes(void)
 {
 	return sizeof(struct deflate_lds);
+}
+
+extern "C" size_t lda_deflate_seq_words(void)
+{
+	return SEQ_GCAP;
 }
 
 LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate)

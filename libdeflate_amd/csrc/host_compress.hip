@@ -136,11 +136,15 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
 		set_error("compress_batch: bad argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
+	/* scratch: [match lists: u64 x words x grid][sums u32 x n] */
+	size_t grid = n < (size_t)ctx->num_cus ? n : (size_t)ctx->num_cus;
+	size_t seq_bytes = grid * lda_deflate_seq_words() * 8;
+	uint8_t *scr = (uint8_t *)c->scratch.reserve(seq_bytes + n * 4);
+	if (!scr)
+		return LIBDEFLATE_AMD_OOM;
 	uint32_t *sums = NULL;
 	if (format != LIBDEFLATE_AMD_DEFLATE) {
-		sums = (uint32_t *)c->scratch.reserve(n * 4);
-		if (!sums)
-			return LIBDEFLATE_AMD_OOM;
+		sums = (uint32_t *)(scr + seq_bytes);
 		int rc = format == LIBDEFLATE_AMD_GZIP ?
 			libdeflate_amd_crc32_batch(n, d_in, d_in_offsets,
 						   d_in_nbytes, NULL, sums, stream) :
@@ -159,12 +163,12 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
 		attr_set[ctx->device] = true;
 	}
 	const level_cfg &lv = k_levels[c->level];
-	size_t grid = n < (size_t)ctx->num_cus ? n : (size_t)ctx->num_cus;
 	hipLaunchKernelGGL(lda_deflate_batch_kernel, dim3((unsigned)grid),
 			   dim3(LDA_DEFLATE_THREADS), lds, st, (uint64_t)n, format, c->level,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
-			   d_out_offsets, d_out_avail, d_out_nbytes, sums);
+			   d_out_offsets, d_out_avail, d_out_nbytes, sums,
+			   (uint64_t *)scr);
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
 	return LIBDEFLATE_AMD_OK;
 }
