@@ -51,11 +51,13 @@
 
 #define NT LDA_DEFLATE_THREADS
 #define NWAVES (NT / 64)
-#define TILE 2048
+#define TILE 4096
 #define RING 32768u
 #define RMASK (RING - 1)
 #define LOOKAHEAD 272u
+#ifndef HASH_BITS
 #define HASH_BITS 13
+#endif
 #define HASH3_BITS 12
 /*
  * The matches of the current block live in HBM (8 bytes each, one list per
@@ -64,9 +66,9 @@
  * 64 KiB buffer; soft maximum as lib/deflate_compress.c:90).
  */
 #define MAX_BLOCK_LEN 131072u
-#define SEQ_TILE_MAX 700u	/* > TILE/3 new matches per tile (min match 3) */
+#define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
-#define EWIN 2048u		/* encode window (positions) */
+#define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
 #endif
@@ -76,7 +78,7 @@
 #ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
 #endif
-#define STG_WORDS 1020u		/* staging: STG_WORDS + 8 words = sizeof nxtA */
+#define STG_WORDS ((TILE + 8) / 2 - 8)	/* staging: STG_WORDS + 8 words = sizeof nxtA */
 
 #define M_FIRST 0x10000u
 #define M_LAST 0x20000u
@@ -108,6 +110,8 @@ struct deflate_lds {
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 vars[16];
 };
+
+static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
@@ -1149,15 +1153,16 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					const s32 limit = last_tile ? (s32)(tend - t) :
 							  (s32)TILE - 2;
 					const u32 lim_idx = (u32)(limit + 4);
-					enum { SEG = TILE / NWAVES, JR = 7 };
+					enum { SEG = TILE / NWAVES, SL = SEG / 64,
+					       JR = SEG == 128 ? 7 : 8 };	/* 2^JR >= SEG */
 					/* wave w owns idx [4 + SEG w, 4 + SEG (w + 1)); the
 					 * carried-in idx 2, 3 can only be the entry itself */
 					const u32 seg_lo = 4 + SEG * wave, seg_hi = seg_lo + SEG;
 					u16 *J = L->nxtA, *Jn = L->nxtB;
-					u32 jh[JR][2], jc[2];	/* J^(2^r) of the own idx */
-					u32 m0[2];		/* M of the own idx */
+					u32 jh[JR][SL], jc[SL];	/* J^(2^r) of the own idx */
+					u32 m0[SL];		/* M of the own idx */
 #pragma unroll
-					for (u32 k = 0; k < 2; k++) {
+					for (u32 k = 0; k < SL; k++) {
 						u32 idx = seg_lo + lane + 64 * k;
 						u32 p = idx - 4;
 						u32 nx = p;
@@ -1172,7 +1177,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 #pragma unroll
 					for (u32 r = 0; r < JR; r++) {
 #pragma unroll
-						for (u32 k = 0; k < 2; k++) {
+						for (u32 k = 0; k < SL; k++) {
 							u32 idx = seg_lo + lane + 64 * k;
 							u32 q = jc[k];
 							jh[r][k] = q;
@@ -1183,7 +1188,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						wave_sync();
 						u16 *tmp = J; J = Jn; Jn = tmp;
 					}
-					/* JR is odd: the segment exits are in nxtB */
 					__syncthreads();
 					PROF_MARK(12);
 					u32 e = (u32)(entry + 4);
@@ -1224,23 +1228,23 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					for (u32 sgm = 0; sgm < wave; sgm++)
 						if (e < 4 + SEG * (sgm + 1) && e < lim_idx)
 							e = J[e];
-					bool mk[2];
+					bool mk[SL];
 #pragma unroll
-					for (u32 k = 0; k < 2; k++) {
+					for (u32 k = 0; k < SL; k++) {
 						u32 idx = seg_lo + lane + 64 * k;
 						mk[k] = idx == e && e < lim_idx;
 					}
 #pragma unroll
 					for (s32 r = JR - 1; r >= 0; r--) {
 #pragma unroll
-						for (u32 k = 0; k < 2; k++) {
+						for (u32 k = 0; k < SL; k++) {
 							u32 q = jh[r][k];
 							if (mk[k] && q < seg_hi && q < lim_idx)
 								L->mark[q] = 1;
 						}
 						wave_sync();
 #pragma unroll
-						for (u32 k = 0; k < 2; k++) {
+						for (u32 k = 0; k < SL; k++) {
 							u32 idx = seg_lo + lane + 64 * k;
 							mk[k] = mk[k] || L->mark[idx];
 						}
@@ -1250,9 +1254,9 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					 * count it for the block's Huffman codes and append
 					 * the matches to seq[] in position order (ballot ranks
 					 * inside the wave, one workgroup scan across waves) */
-					bool ism[2];
+					bool ism[SL];
 #pragma unroll
-					for (u32 k = 0; k < 2; k++) {
+					for (u32 k = 0; k < SL; k++) {
 						u32 idx = seg_lo + lane + 64 * k;
 						u32 st = jh[0][k] - idx, l0 = m0[k] & 0xFFFF;
 						ism[k] = mk[k] && st == l0 && l0;
@@ -1280,9 +1284,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_WALKPOS_LO] = (u32)((s32)t + entry);
 						L->vars[V_ENTRY] = (u32)(entry - (s32)TILE);
 					}
-					const u64 bal0 = __ballot(ism[0]), bal1 = __ballot(ism[1]);
-					const u32 c0 = __builtin_popcountll(bal0);
-					const u32 cw = c0 + __builtin_popcountll(bal1);
+					u64 bal[SL];
+					u32 cw = 0;
+#pragma unroll
+					for (u32 k = 0; k < SL; k++) {
+						bal[k] = __ballot(ism[k]);
+						cw += __builtin_popcountll(bal[k]);
+					}
 					u32 *sc = L->scan[tog];
 					tog ^= 1;
 					if (lane == 0)
@@ -1298,15 +1306,15 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					}
 					const u64 lt = (1ull << lane) - 1;
 #pragma unroll
-					for (u32 k = 0; k < 2; k++) {
+					for (u32 k = 0; k < SL; k++) {
 						if (ism[k]) {
 							u32 idx = seg_lo + lane + 64 * k;
-							u32 at = base + (k ? c0 + __builtin_popcountll(bal1 & lt) :
-									 __builtin_popcountll(bal0 & lt));
+							u32 at = base + __builtin_popcountll(bal[k] & lt);
 							seqg[at] = (t + idx - 4 - block_start) |
 								   ((u64)(m0[k] & 0xFFFF) << 32) |
 								   ((u64)(m0[k] >> 16) << 41);
 						}
+						base += __builtin_popcountll(bal[k]);
 					}
 					if (tid == 0)
 						L->vars[V_NSEQ] = seq0 + npre + tot;
@@ -1692,24 +1700,29 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					/* matches that start in this window (the list is
 					 * position-sorted and holds < NT of them per window) */
 					{
-						u32 sidx = seq_lo + tid;
-						bool mine = false;
-						if (sidx < nseq) {
-							u64 sq = seqg[sidx];
-							u32 pos = bstart + (u32)sq;
-							if (pos < wend) {
-								u32 len = (u32)(sq >> 32) & 0x1FF;
-								u32 q = pos - w0;
-								mine = true;
-								KD[q] = len | ((u32)(sq >> 41) << 16);
-								for (u32 j = 1; j < len && q + j < EWIN; j++)
-									KD[q + j] = 0xFFFFFFFFu;
-								if (pos + len > w0 + EWIN)
-									atomicMax(&L->vars[v_spill_next],
-										  pos + len - (w0 + EWIN));
+						u32 cw = 0;
+						for (u32 sidx = seq_lo + tid; ; sidx += NT) {
+							bool mine = false;
+							if (sidx < nseq) {
+								u64 sq = seqg[sidx];
+								u32 pos = bstart + (u32)sq;
+								if (pos < wend) {
+									u32 len = (u32)(sq >> 32) & 0x1FF;
+									u32 q = pos - w0;
+									mine = true;
+									KD[q] = len | ((u32)(sq >> 41) << 16);
+									for (u32 j = 1; j < len && q + j < EWIN; j++)
+										KD[q + j] = 0xFFFFFFFFu;
+									if (pos + len > w0 + EWIN)
+										atomicMax(&L->vars[v_spill_next],
+											  pos + len - (w0 + EWIN));
+								}
 							}
+							const u64 mm = __ballot(mine);
+							cw += __builtin_popcountll(mm);
+							if (mm != ~0ull)	/* the list is position-sorted */
+								break;
 						}
-						u32 cw = __builtin_popcountll(__ballot(mine));
 						if (lane == 0 && cw)
 							atomicAdd(&L->vars[v_cnt], cw);
 					}
