@@ -62,10 +62,13 @@
 /*
  * The matches of the current block live in HBM (8 bytes each, one list per
  * workgroup): nothing of a block has to stay in LDS until the block is
- * written, so a block can be as long as the reference's (one block for a
- * 64 KiB buffer; soft maximum as lib/deflate_compress.c:90).
+ * written, so a block can be as long as a whole 64 KiB buffer, like the
+ * reference's for homogeneous data.  There is no adaptive block splitting
+ * (lib/deflate_compress.c:2092-2218) yet: blocks end at tile boundaries once
+ * they reach MAX_BLOCK_LEN, which bounds the cost of content that changes
+ * inside a buffer.
  */
-#define MAX_BLOCK_LEN 131072u
+#define MAX_BLOCK_LEN 65536u
 #define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
 #define EWIN TILE		/* encode window (positions) */
@@ -74,6 +77,9 @@
 #endif
 #ifndef S3_EVMIN
 #define S3_EVMIN 1u		/* lanes with a queued hit that trigger an evaluate round */
+#endif
+#ifndef S3_TAIL
+#define S3_TAIL 256u		/* positions at the end of a tile searched with reduced depth */
 #endif
 #ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
@@ -672,7 +678,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			 const u64 *__restrict__ out_avail_arr,
 			 u64 *__restrict__ out_nbytes,
 			 const u32 *__restrict__ sums,
-			 u64 *__restrict__ seq_scratch)
+			 u64 *__restrict__ seq_scratch,
+			 const u32 *__restrict__ seg_info)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
@@ -746,15 +753,25 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 		__syncthreads();
 		stg_save(L, &os);
 
+		/* Segment mode (one large buffer cut into sub-ranges that are
+		 * compressed side by side): the first dict_len bytes (whole tiles)
+		 * of this "chunk" are the tail of the previous sub-range; they only
+		 * prime the hash chains.  Every segment but the last ends with a
+		 * non-final block and an empty stored block, so the segments'
+		 * outputs are byte aligned and concatenate into one stream
+		 * (lib/deflate_compress.c:1839-1847 is the same alignment rule). */
+		const u32 sinfo = seg_info ? seg_info[c] : 0x80000000u;
+		const u32 dict_len = sinfo & 0x7FFFFFFFu;
+		const bool seg_last = sinfo >> 31;
 		u32 loaded = 0;		/* input bytes present in the ring */
-		u32 block_start = 0;
-		u32 walkpos = 0;	/* absolute position the parse has reached */
+		u32 block_start = dict_len;
+		u32 walkpos = dict_len;	/* absolute position the parse has reached */
 		const bool aligned_in = ((uintptr_t)inp & 15) == 0;
 
 		/* level 0 and tiny inputs: stored blocks only
 		 * (deflate_compress.c:3925-3931, 2392-2443) */
 		const bool stored_only = level == 0 ||
-			n <= (u32)(55 - 4 * (level > 12 ? 12 : level));
+			n - dict_len <= (u32)(55 - 4 * (level > 12 ? 12 : level));
 		u32 num_tiles = (n + TILE - 1) / TILE;
 		if (num_tiles == 0)
 			num_tiles = 1;
@@ -763,6 +780,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			const u32 t = tile * TILE;
 			const u32 tend = t + TILE < n ? t + TILE : n;
 			const bool last_tile = tile + 1 == num_tiles;
+			const bool prime = t < dict_len;	/* dictionary tile (whole tiles) */
 
 			PROF_MARK(0);
 			/* ---- S0: stage input up to tend + LOOKAHEAD ---- */
@@ -789,22 +807,29 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			if (tid < 4)
 				L->M[TILE + 4 + tid] = 0;
 			__syncthreads();
-			if (tile == 0 && !stored_only) {
-				/* first estimate from the bytes at hand
-				 * (calculate_min_match_len, deflate_compress.c:2329-2353) */
+			if (!prime && !stored_only) {
+				/* minimum match length from the distinct bytes of this
+				 * tile's input (calculate_min_match_len,
+				 * deflate_compress.c:2329-2353, which the reference applies
+				 * to the first 4096 bytes and then refreshes per block from
+				 * the literals used; with blocks as long as a buffer the
+				 * per-tile estimate is what follows content changes) */
 				u32 *seen = L->M + 16;
 				for (u32 i = tid; i < 256; i += NT)
 					seen[i] = 0;
 				__syncthreads();
-				u32 lim = want < 4096 ? want : 4096;
+				u32 lim = want - t < 4096 ? want - t : 4096;
 				for (u32 i = tid; i < lim; i += NT)
-					seen[L->in[i]] = 1;
+					seen[L->in[(t + i) & RMASK]] = 1;
 				__syncthreads();
 				u32 c1 = tid < 256 ? seen[tid] : 0, tot1;
 				(void)block_scan(L, c1, &tot1);
 				if (tid == 0)
-					L->vars[V_MINLEN] = n < 512 ? 3 : choose_min_len(tot1, depth);
+					L->vars[V_MINLEN] = n - dict_len < 512 ? 3 :
+							    choose_min_len(tot1, depth);
 				__syncthreads();
+			} else if (tile == 0 && tid == 0) {
+				L->vars[V_MINLEN] = 3;	/* dictionary tiles: not used */
 			}
 
 			PROF_MARK(1);
@@ -927,6 +952,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								L->nxtA[4 + (g0 + k) * 64 + lane] = (u16)v[k];
 					}
 				}
+				if (prime) {	/* chains primed; nothing to search or emit */
+					__syncthreads();
+					continue;
+				}
 
 				PROF_MARK(3);
 				/* ---- S3: all positions search their chain ----
@@ -948,7 +977,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
 					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
 					const u32 min_len = L->vars[V_MINLEN];
-					const u32 drain = depth >> 3 > 8 ? depth >> 3 : 8;
+					const u32 drain = depth < 8 ? depth : depth >> 3 > 8 ? depth >> 3 : 8;
 					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 					    cnt = 0, boff = 0, curb = 0;
@@ -974,13 +1003,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									while (*(volatile u32 *)&L->vars[V_READY] < need)
 										__builtin_amdgcn_s_sleep(4);
 							}
-							/* every position is taken: the chains still
-							 * running are what the other 15 waves will wait
-							 * for, so their remaining depth is cut (about one
-							 * position in twenty; +0.1 % output at level 6
-							 * for -5 % time) */
-							if (cbase + nf >= TILE && dep > drain)
-								dep = drain;
 							if (fin) {
 								if (my_i < TILE)
 									L->M[4 + my_i] =
@@ -999,7 +1021,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										c16 = L->prev[p & RMASK];
 										maxlen = n - p < 258 ? n - p : 258;
 										dmaxp = p - lo_pos;
-										dep = depth;
+										/* the last positions of a tile are claimed when
+										 * the other waves are about to run dry: they
+										 * search less deep (by position, so the output
+										 * does not depend on timing) */
+										dep = my_i >= TILE - S3_TAIL ? drain : depth;
 										bestd = 0;
 										dprev = 0;
 										cnt = 0;
@@ -1331,6 +1357,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				if (tid < 4)
 					L->M[tid] = L->M[TILE + tid];
 			} else {
+				if (prime)
+					continue;
 				walkpos = tend;
 			}
 			__syncthreads();
@@ -1346,7 +1374,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			const u32 bstart = block_start, bend = last_tile ? n : walkpos;
 			const u32 blen = bend - bstart;
 			const u32 nseq = stored_only ? 0 : L->vars[V_NSEQ];
-			const u32 is_final = last_tile ? 1 : 0;
+			const u32 is_final = last_tile && seg_last ? 1 : 0;
 
 			/* ---- S5: codes, costs, block type ---- */
 			u32 btype = 0;	/* 0 stored, 1 static, 2 dynamic */
@@ -1826,8 +1854,19 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 
 		/* ---- finish the stream ---- */
 		__syncthreads();
+		if (!overflow && !seg_last &&
+		    (os.bits + 3 + 7) / 8 + 4 > os.avail)
+			overflow = true;
 		if (!overflow) {
 			stg_restore(L);
+			if (!seg_last) {
+				/* empty stored block: BFINAL 0, BTYPE 00, pad, LEN 0, NLEN ~0 */
+				u64 fb = 8 * ((os.bits + 3 + 7) / 8);
+				if (tid == 0)
+					stg_put(L, &os, fb, 0xFFFF0000ull, 32);
+				os.bits = fb + 32;
+				__syncthreads();
+			}
 			if (ftr_bytes) {
 				/* gzip_compress.c:73-79 / zlib_compress.c:66-72 */
 				u32 sum = sums ? sums[c] : 0;
@@ -1857,6 +1896,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 extern "C" size_t lda_deflate_lds_bytes(void)
 {
 	return sizeof(struct deflate_lds);
+}
+
+extern "C" size_t lda_deflate_tile(void)
+{
+	return TILE;
 }
 
 extern "C" size_t lda_deflate_seq_words(void)

@@ -8,6 +8,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <new>
 #include <vector>
 
@@ -114,14 +115,13 @@ libdeflate_gzip_compress_bound(struct libdeflate_compressor *c, size_t n)
 	return 18 + libdeflate_deflate_compress_bound(c, n);
 }
 
-extern "C" LIBDEFLATEAPI int
-libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
-			      size_t n, const void *d_in,
-			      const uint64_t *d_in_offsets,
-			      const uint64_t *d_in_nbytes, void *d_out,
-			      const uint64_t *d_out_offsets,
-			      const uint64_t *d_out_avail,
-			      uint64_t *d_out_nbytes, void *stream)
+static int
+compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
+		    const void *d_in, const uint64_t *d_in_offsets,
+		    const uint64_t *d_in_nbytes, void *d_out,
+		    const uint64_t *d_out_offsets, const uint64_t *d_out_avail,
+		    uint64_t *d_out_nbytes, void *stream,
+		    const uint32_t *d_seg_info)
 {
 	DeviceCtx *ctx = device_ctx();
 	hipStream_t st = (hipStream_t)stream;
@@ -168,9 +168,23 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
 			   d_out_offsets, d_out_avail, d_out_nbytes, sums,
-			   (uint64_t *)scr);
+			   (uint64_t *)scr, d_seg_info);
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
 	return LIBDEFLATE_AMD_OK;
+}
+
+extern "C" LIBDEFLATEAPI int
+libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
+			      size_t n, const void *d_in,
+			      const uint64_t *d_in_offsets,
+			      const uint64_t *d_in_nbytes, void *d_out,
+			      const uint64_t *d_out_offsets,
+			      const uint64_t *d_out_avail,
+			      uint64_t *d_out_nbytes, void *stream)
+{
+	return compress_batch_impl(c, format, n, d_in, d_in_offsets, d_in_nbytes,
+				   d_out, d_out_offsets, d_out_avail,
+				   d_out_nbytes, stream, NULL);
 }
 
 extern "C" LIBDEFLATEAPI int
@@ -232,10 +246,184 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 	return LIBDEFLATE_AMD_OK;
 }
 
+
+/*
+ * One LARGE buffer: the input is cut into sub-ranges
+ * of LDA_SEG_BYTES that are compressed side by side, one workgroup each.
+ * Every sub-range but the first is given the tail of its predecessor as a
+ * dictionary (whole tiles that only prime the hash chains), every one but
+ * the last ends byte aligned (non-final block + empty stored block), so the
+ * pieces concatenate into ONE raw DEFLATE stream; the container header /
+ * footer are written on the host, the checksum is combined from the
+ * per-piece checksums:
+ *   crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)
+ * (programs/gzip.c:149-185 hands the whole file to one compress call; this
+ * is what makes that call use the whole GPU.)
+ */
+#define LDA_SEG_BYTES 65536u
+#define LDA_LARGE_MIN (2 * LDA_SEG_BYTES)
+
+/* multiply two reflected polynomials mod the CRC-32 polynomial (bit 31 = x^0) */
+static uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+	uint32_t p = 0;
+	for (uint32_t m = 0x80000000u; m; m >>= 1) {
+		if (a & m)
+			p ^= b;
+		b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+	}
+	return p;
+}
+
+static uint32_t crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+{
+	uint32_t xp = 0x80000000u;	/* 1 */
+	uint32_t base = 0x00800000u;	/* x^8 */
+	for (uint64_t k = len_b; k; k >>= 1) {
+		if (k & 1)
+			xp = crc_mulmod(xp, base);
+		base = crc_mulmod(base, base);
+	}
+	return crc_mulmod(crc_a, xp) ^ crc_b;
+}
+
+static uint32_t adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b)
+{
+	const uint32_t M = 65521;
+	uint32_t a1 = ad_a & 0xFFFF, b1 = ad_a >> 16;
+	uint32_t a2 = ad_b & 0xFFFF, b2 = ad_b >> 16;
+	uint32_t rem = (uint32_t)(len_b % M);
+	uint32_t a = (a1 + a2 + M - 1) % M;
+	uint32_t b = (uint32_t)(((uint64_t)rem * a1 + b1 + b2 + M - rem) % M);
+	return (b << 16) | a;
+}
+
+static size_t compress_large(struct libdeflate_compressor *c, int format,
+			     const uint8_t *in, size_t n, uint8_t *out,
+			     size_t out_avail)
+{
+	const size_t S = LDA_SEG_BYTES;
+	const size_t tile = lda_deflate_tile();
+	/* usable window is 32 KiB minus a tile and the lookahead; whole tiles */
+	const size_t D = (32768 - tile - 272) / tile * tile;
+	const size_t nseg = (n + S - 1) / S;
+	const size_t slot = align_up(libdeflate_deflate_compress_bound(c, S) + 32, 16);
+	const uint32_t hdr = format == LIBDEFLATE_AMD_GZIP ? 10 :
+			     format == LIBDEFLATE_AMD_ZLIB ? 2 : 0;
+	const uint32_t ftr = format == LIBDEFLATE_AMD_GZIP ? 8 :
+			     format == LIBDEFLATE_AMD_ZLIB ? 4 : 0;
+
+	if (out_avail <= hdr + ftr)
+		return 0;
+	/* device layout: [5 u64 arrays + u32 seg_info + u32 sums][input][slots] */
+	size_t desc_bytes = align_up(nseg * (5 * 8 + 4 + 4), 64);
+	size_t in_at = desc_bytes, out_at = align_up(in_at + n + 64, 64);
+	uint8_t *st = (uint8_t *)c->stage.reserve(out_at + nseg * slot + 64);
+	if (!st)
+		die_no_device("libdeflate_*_compress (device memory)");
+	std::vector<uint64_t> d64(5 * nseg);
+	std::vector<uint32_t> d32(2 * nseg);
+	uint64_t *in_off = &d64[0], *in_n = &d64[nseg], *out_off = &d64[2 * nseg],
+		 *out_av = &d64[3 * nseg];
+	for (size_t i = 0; i < nseg; i++) {
+		size_t dict = i ? D : 0, len = i + 1 < nseg ? S : n - i * S;
+		in_off[i] = in_at + i * S - dict;
+		in_n[i] = dict + len;
+		out_off[i] = out_at + i * slot;
+		out_av[i] = slot;
+		d32[i] = (uint32_t)dict | (i + 1 == nseg ? 0x80000000u : 0);
+	}
+	uint64_t *d_desc = (uint64_t *)st;
+	uint32_t *d_seg = (uint32_t *)(st + 5 * 8 * nseg);
+	uint32_t *d_sums = d_seg + nseg;
+	if (hipMemcpy(d_desc, d64.data(), 4 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(st + in_at, in, n, hipMemcpyHostToDevice) != hipSuccess)
+		die_no_device("libdeflate_*_compress (copy in)");
+	int rc = compress_batch_impl(c, LIBDEFLATE_AMD_DEFLATE, nseg, st, d_desc,
+				     d_desc + nseg, st, d_desc + 2 * nseg,
+				     d_desc + 3 * nseg, d_desc + 4 * nseg, NULL, d_seg);
+	if (rc != LIBDEFLATE_AMD_OK)
+		die_no_device("libdeflate_*_compress");
+	if (ftr) {
+		/* per-piece checksums of the pieces themselves (no dictionary) */
+		std::vector<uint64_t> po(2 * nseg);
+		for (size_t i = 0; i < nseg; i++) {
+			po[i] = in_at + i * S;
+			po[nseg + i] = i + 1 < nseg ? S : n - i * S;
+		}
+		/* reuse the in_off / in_n rows after the kernel has consumed them */
+		if (hipDeviceSynchronize() != hipSuccess ||
+		    hipMemcpy(d_desc, po.data(), 2 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess)
+			die_no_device("libdeflate_*_compress (checksum setup)");
+		rc = format == LIBDEFLATE_AMD_GZIP ?
+			libdeflate_amd_crc32_batch(nseg, st, d_desc, d_desc + nseg,
+						   NULL, d_sums, NULL) :
+			libdeflate_amd_adler32_batch(nseg, st, d_desc, d_desc + nseg,
+						     NULL, d_sums, NULL);
+		if (rc != LIBDEFLATE_AMD_OK)
+			die_no_device("libdeflate_*_compress (checksum)");
+	}
+	if (hipDeviceSynchronize() != hipSuccess ||
+	    hipMemcpy(&d64[4 * nseg], d_desc + 4 * nseg, 8 * nseg, hipMemcpyDeviceToHost) != hipSuccess ||
+	    (ftr && hipMemcpy(&d32[nseg], d_sums, 4 * nseg, hipMemcpyDeviceToHost) != hipSuccess))
+		die_no_device("libdeflate_*_compress (copy out)");
+	size_t total = hdr + ftr;
+	for (size_t i = 0; i < nseg; i++) {
+		if (d64[4 * nseg + i] == 0)
+			return 0;
+		total += d64[4 * nseg + i];
+	}
+	if (total > out_avail)
+		return 0;
+	size_t at = hdr;
+	for (size_t i = 0; i < nseg; i++) {
+		size_t sz = d64[4 * nseg + i];
+		if (hipMemcpy(out + at, st + out_off[i], sz, hipMemcpyDeviceToHost) != hipSuccess)
+			die_no_device("libdeflate_*_compress (copy out)");
+		at += sz;
+	}
+	if (format == LIBDEFLATE_AMD_GZIP) {
+		/* lib/gzip_compress.c:44-79 */
+		uint32_t crc = 0;
+		for (size_t i = 0; i < nseg; i++) {
+			size_t len = i + 1 < nseg ? S : n - i * S;
+			crc = i ? crc32_concat(crc, d32[nseg + i], len) : d32[nseg];
+		}
+		const uint8_t xfl = c->level < 2 ? 4 : c->level >= 8 ? 2 : 0;
+		const uint8_t h[10] = { 0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 0xFF };
+		memcpy(out, h, 10);
+		uint32_t isize = (uint32_t)n;
+		for (int k = 0; k < 4; k++) {
+			out[at + k] = (uint8_t)(crc >> (8 * k));
+			out[at + 4 + k] = (uint8_t)(isize >> (8 * k));
+		}
+	} else if (format == LIBDEFLATE_AMD_ZLIB) {
+		/* lib/zlib_compress.c:45-72 */
+		uint32_t ad = 1;
+		for (size_t i = 0; i < nseg; i++) {
+			size_t len = i + 1 < nseg ? S : n - i * S;
+			ad = i ? adler32_concat(ad, d32[nseg + i], len) : d32[nseg];
+		}
+		uint32_t fl = c->level < 2 ? 0 : c->level < 6 ? 1 : c->level < 8 ? 2 : 3;
+		uint32_t hw = (0x78u << 8) | (fl << 6);
+		hw |= 31 - (hw % 31);
+		out[0] = (uint8_t)(hw >> 8);
+		out[1] = (uint8_t)hw;
+		for (int k = 0; k < 4; k++)
+			out[at + k] = (uint8_t)(ad >> (8 * (3 - k)));
+	}
+	return total;
+}
+
 static size_t compress_one(struct libdeflate_compressor *c, int format,
 			   const void *in, size_t in_nbytes, void *out,
 			   size_t out_avail)
 {
+	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 && in_nbytes < 0xFFFF0000u &&
+	    !getenv("LDA_NO_SEGMENTS"))
+		return compress_large(c, format, (const uint8_t *)in, in_nbytes,
+				      (uint8_t *)out, out_avail);
 	const void *ins[1] = { in };
 	void *outs[1] = { out };
 	size_t got = 0;

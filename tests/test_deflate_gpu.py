@@ -176,3 +176,39 @@ def test_small_blocks_zlib_level9(oracle):
         z = cb[i * bound:i * bound + sizes[i]].tobytes()
         _check_roundtrip(oracle, "zlib", chunks[i], z, ("4k", i))
     print("4 KiB zlib L9 ratio", sizes.sum() / (n * size))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_large_single_buffer_is_segmented(level, oracle):
+    """one large buffer through the single-buffer API is
+    compressed as side-by-side sub-ranges; the result is one valid stream
+    (round trip, container bytes, checksum combined from the pieces), within
+    compress_bound, close to the reference's size, and 0 when it cannot fit."""
+    from libdeflate_amd import api
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    c = api.Compressor(level)
+    sizes = [131072, 131073, 200000, 1 << 20, 3 * (1 << 20) + 12345]
+    for i, n in enumerate(sizes):
+        kinds = [0, 5, 6, 7, 1]
+        d = b"".join(datagen.chunk(kinds[(i + k) % 5], 65536, 0x0E110040 + k)
+                     for k in range((n + 65535) // 65536))[:n]
+        for fmt in ("deflate", "zlib", "gzip"):
+            z = c.compress(fmt, d)
+            _check_roundtrip(oracle, fmt, d, z, ("large", level, fmt, n))
+            assert len(z) <= c.bound(fmt, n)
+            if ref is not None:
+                zr = ref.compress(fmt, level, d)
+                assert len(z) <= 1.03 * len(zr) + 64, (level, fmt, n, len(z), len(zr))
+            if fmt == "gzip":
+                assert z[:4] == b"\x1f\x8b\x08\x00"
+                assert int.from_bytes(z[-4:], "little") == n
+                assert int.from_bytes(z[-8:-4], "little") == zlib.crc32(d)
+            if fmt == "zlib":
+                assert int.from_bytes(z[-4:], "big") == zlib.adler32(d)
+        # does not fit -> 0 (api returns None)
+        assert c.compress("gzip", d, out_avail=len(z) - 1) is None
+    # a long run across many segments: distances and lengths at their limits
+    d = bytes(5 * 65536 + 17)
+    z = c.compress("gzip", d)
+    _check_roundtrip(oracle, "gzip", d, z, ("zeros", level))
