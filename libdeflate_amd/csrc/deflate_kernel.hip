@@ -73,7 +73,7 @@
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
 #define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
-#define S3_WALK 4		/* chain steps per walk pass (<= 4: hit queue) */
+#define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
 #endif
 #ifndef S3_EVMIN
 #define S3_EVMIN 1u		/* lanes with a queued hit that trigger an evaluate round */
@@ -983,14 +983,15 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					    cnt = 0, boff = 0, curb = 0;
 					u64 nxt8 = 0, q = 0;
 					bool have = false, fin = true, ended = false;
+					PROF_SEC_DECL;
 
 					for (;;) {
+						PROF_SEC(3);
 						u64 mh = __ballot(have);
 						u32 nf = __builtin_popcountll(__ballot(fin));
 						if (!mh && !nf)
 							break;
 						if (nf && (nf >= S3_CLAIM || !mh)) {
-							PROF_COUNT(20, 1);
 							/* one counter update per wave; ranks by ballot */
 							const u64 fm = __ballot(fin);
 							u32 cbase = 0;
@@ -1036,11 +1037,10 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									}
 								}
 							}
+							PROF_SEC(0);
 							continue;
 						}
 						/* walk */
-						PROF_COUNT(14, 1);
-						PROF_COUNT(15, __builtin_popcountll(__ballot(have && !ended)));
 #pragma unroll
 						for (int s = 0; s < S3_WALK; s++) {
 							u32 d = (p - c16) & 0xFFFF;
@@ -1060,6 +1060,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						}
 						if (!have)
 							cnt = 0;
+						PROF_SEC(1);
 						/* evaluate: a round when enough lanes hold a hit, or
 						 * when no lane can walk any further */
 						bool done = false;
@@ -1067,8 +1068,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						u32 nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
 						while (nev && (nev >= S3_EVMIN || !nwalk)) {
 							bool ev = cnt > 0;
-							PROF_COUNT(17, 1);
-							PROF_COUNT(19, __builtin_popcountll(__ballot(ev)));
 							u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
 							cnt -= ev ? 1 : 0;
 							u32 cp = p - d;
@@ -1094,7 +1093,6 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							}
 							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
 								u32 src = (u32)__builtin_ctzll(mm);
-								PROF_COUNT(18, 1);
 								u32 bp = bcast_lane(p, src);
 								u32 bc = bcast_lane(cp, src);
 								u32 bmax = bcast_lane(maxlen, src);
@@ -1141,7 +1139,9 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							have = false;
 							fin = true;
 						}
+						PROF_SEC(2);
 					}
+					PROF_SEC_FLUSH(17);
 				}
 				__syncthreads();
 				PROF_MARK(16);

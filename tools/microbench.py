@@ -66,8 +66,8 @@ def main():
 PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
                   "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
                   "S4 doubling", "S4 chain+mark", "#walk passes (w0)", "#lanes walking at pass start",
-                  "S3 total (w0)", "#eval rounds", "#coop passes", "#lanes evaluating",
-                  "#claim passes", "S5 precode RLE (t0)", "S5 precode tree"]
+                  "S3 total (w0)", "S3 claim (w0)", "S3 walk (w0)", "S3 evaluate (w0)",
+                  "S3 loop (w0)", "S5 precode RLE (t0)", "S5 precode tree"]
 
 
 def read_profile(name, labels):
