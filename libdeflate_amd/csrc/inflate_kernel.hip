@@ -683,20 +683,25 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	  u32 *__restrict__ tok, u8 *win, u8 *stage, u64 ring_lo, u32 lane,
 	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret)
 {
-	/* lanes in this round: as many PAR_CB-bit chunks as fit in front of the
-	 * last 80 input bytes (the sequential decoder finishes the stream) */
+	/* lanes in this round: one PAR_CB-bit chunk each, up to the end of the
+	 * input.  Bytes past the end are staged as zeros, exactly the implicit
+	 * padding of the sequential decoder; a round whose exact parse ends
+	 * beyond the input is abandoned below and left to that decoder (it is
+	 * the one that knows the overread rules). */
 	const u32 cb = PAR_CB;
 	const u64 byte0 = bpos_abs >> 3;
-	if (byte0 + 80 + 4 * (cb / 8) > in_n)
+	if (byte0 + 64 > in_n)
 		return PAR_STOP;
-	const u64 room = (in_n - 80 - byte0) / (cb / 8);
+	const u64 room = (in_n - byte0 + cb / 8 - 1) / (cb / 8);
 	const u32 NL = room < 64 ? (u32)room : 64;
 	/* stage the span: 8-byte words, unaligned in HBM, aligned in LDS */
 	{
-		const u8 *src = inp + byte0;
 		const u32 nw = (NL * (cb / 8) + 80) / 8;
-		for (u32 w = lane; w < nw; w += 64)
-			*(u64 *)(stage + 8 * w) = ld8(src + 8 * w);
+		for (u32 w = lane; w < nw; w += 64) {
+			const u64 pos = byte0 + 8 * w;
+			*(u64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
+						  load_in(inp, in_n, pos);
+		}
 		wave_sync();
 	}
 	inp = stage;
@@ -782,6 +787,8 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	if (total_bytes > out_avail - out0)
 		return PAR_STOP;
 	const u64 end_bits = readlane64(end, K) - bpos0 + bpos_abs;
+	if (end_bits > 8 * in_n)
+		return PAR_STOP;
 
 	/* ---- emit the tokens ---- */
 	{
