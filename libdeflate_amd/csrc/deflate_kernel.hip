@@ -114,6 +114,7 @@ struct deflate_lds {
 	u16 nxtA[TILE + 8] __attribute__((aligned(16)));	/* S6: bit staging */
 	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
+	u32 obs[1][10];		/* block-split observations of the block before this tile */
 	u32 vars[16];
 };
 
@@ -121,7 +122,8 @@ static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY
+	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY,
+	V_SPLIT
 };
 
 struct level_params {
@@ -718,6 +720,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			((u32 *)L->head3)[i] = 0x80008000u;
 		for (u32 i = tid; i < 320; i += NT)
 			L->freq[i] = 0;
+		if (tid < 10)
+			L->obs[0][tid] = 0;
 		for (u32 i = tid; i < STG_WORDS + 8; i += NT)
 			stg_of(L)[i] = 0;
 		if (tid < 8)
@@ -1356,6 +1360,48 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				 * positions the walk deferred */
 				if (tid < 4)
 					L->M[tid] = L->M[TILE + tid];
+				/* block split observations (see "block end?" below), by the
+				 * last wave while the others wait at the barrier */
+				if (wave == NWAVES - 1) {
+					/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
+					 * matches: length slots 0..5 (3..8) / 6..28 */
+					u32 onow[10];
+#pragma unroll
+					for (u32 j = 0; j < 4; j++) {
+						u32 f = L->freq[lane + 64 * j];
+						onow[2 * j] = wave_sum(lane & 1 ? 0 : f);
+						onow[2 * j + 1] = wave_sum(lane & 1 ? f : 0);
+					}
+					{
+						u32 f = lane < 29 ? L->freq[257 + lane] : 0;
+						onow[8] = wave_sum(lane < 6 ? f : 0);
+						onow[9] = wave_sum(lane < 6 ? 0 : f);
+					}
+					u32 nprev = 0, nnew = 0;
+					u64 delta = 0;
+#pragma unroll
+					for (u32 i = 0; i < 10; i++) {
+						nprev += L->obs[0][i];
+						nnew += onow[i] - L->obs[0][i];
+					}
+#pragma unroll
+					for (u32 i = 0; i < 10; i++) {
+						u64 a = (u64)(onow[i] - L->obs[0][i]) * nprev;
+						u64 e = (u64)L->obs[0][i] * nnew;
+						delta += a > e ? a - e : e - a;
+					}
+					/* cutoff 200/512 of the mass as :2179-2193; blocks below
+					 * the minimum length of :2204 are never cut */
+					bool sp = nprev && walkpos - block_start >= 5000 &&
+						  delta >= (u64)nnew * 200 / 512 * nprev;
+					wave_sync();
+#pragma unroll
+					for (u32 i = 0; i < 10; i++)
+						if (lane == i)
+							L->obs[0][i] = sp ? 0 : onow[i];
+					if (lane == 0)
+						L->vars[V_SPLIT] = sp;
+				}
 			} else {
 				if (prime)
 					continue;
@@ -1364,12 +1410,25 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			__syncthreads();
 
 			PROF_MARK(6);
-			/* ---- block end? ---- */
-			bool end_block = last_tile ||
+			/* ---- block end? ----
+			 * The reference ends a block when the kind of symbols changes
+			 * (lib/deflate_compress.c:2092-2218): ten observation classes
+			 * (literals by their top two bits and low bit, matches shorter /
+			 * not shorter than 9), and a split when the distribution of the
+			 * new observations is far from the block's.  Here the classes
+			 * are sums over the block histogram, "new" is what this tile
+			 * added, and the decision is taken per tile: a tile that differs
+			 * ends the block AFTER itself (its state is gone once the block
+			 * is written), so one tile per change of content is coded with
+			 * the old block - the next block starts clean. */
+			const bool split = !stored_only && !last_tile && L->vars[V_SPLIT];
+			bool end_block = last_tile || split ||
 				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_GCAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
 				continue;
+			if (tid < 10)
+				L->obs[0][tid] = 0;
 
 			const u32 bstart = block_start, bend = last_tile ? n : walkpos;
 			const u32 blen = bend - bstart;

@@ -212,3 +212,27 @@ def test_large_single_buffer_is_segmented(level, oracle):
     d = bytes(5 * 65536 + 17)
     z = c.compress("gzip", d)
     _check_roundtrip(oracle, "gzip", d, z, ("zeros", level))
+
+
+def test_block_split_follows_content():
+    """lib/deflate_compress.c:2092-2218 (a10): a buffer whose content changes
+    is cut into blocks near the changes; homogeneous buffers stay one block.
+    Size within 5 % of the reference on the mixed buffers."""
+    import os
+    import sys
+    from libdeflate_amd import api
+    from tests import oracle_util
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import stream_stats
+    ref = oracle_util.load_ref()
+    c = api.Compressor(6)
+    for kinds, nblocks in (((0, 0), 1), ((5, 5), 1), ((0, 5), 2), ((0, 6, 5, 7), 4)):
+        d = b"".join(datagen.chunk(k, 32768, 0x0E110040 + i) for i, k in enumerate(kinds))
+        z = c.compress_batch_host("deflate", [d])[0]
+        out, blocks = stream_stats.stats(z)
+        assert out == d
+        assert len(blocks) == nblocks, (kinds, [b["len"] for b in blocks])
+        for b in blocks[:-1]:       # cut within two tiles after a change
+            assert b["start"] + b["len"] - 32768 * ((b["start"] + b["len"]) // 32768) <= 8192
+        if ref is not None:
+            assert len(z) <= 1.05 * len(ref.compress("deflate", 6, d))
