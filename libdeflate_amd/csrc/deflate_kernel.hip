@@ -851,20 +851,27 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					/* 3-byte hash rides along in M (bits 19..30) for S2;
 					 * written before the sort scatters the hash4 part */
 					u32 h3v = p + 3 <= n ? (hash3(w4) | 0x1000u) : 0;
-#pragma unroll
-					for (u32 k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-						for (u32 j = k >> 1; j > 0; j >>= 1) {
-							u32 other = __shfl_xor(key, j, 64);
-							bool up = (lane & k) == 0;
-							bool lower = (lane & j) == 0;
-							u32 mn = key < other ? key : other;
-							u32 mx = key < other ? other : key;
-							key = (lower == up) ? mn : mx;
-						}
-					}
-					u32 left = __shfl_up(key, 1, 64);
-					u32 right = __shfl_down(key, 1, 64);
+#define SORT_STEP(K, J)                                                        \
+	do {                                                                   \
+		u32 other = lane_xor<J>(key);                                  \
+		bool up = (lane & (K)) == 0, lower = (lane & (J)) == 0;        \
+		u32 mn = key < other ? key : other;                            \
+		u32 mx = key < other ? other : key;                            \
+		key = (lower == up) ? mn : mx;                                 \
+	} while (0)
+					SORT_STEP(2, 1);
+					SORT_STEP(4, 2); SORT_STEP(4, 1);
+					SORT_STEP(8, 4); SORT_STEP(8, 2); SORT_STEP(8, 1);
+					SORT_STEP(16, 8); SORT_STEP(16, 4); SORT_STEP(16, 2);
+					SORT_STEP(16, 1);
+					SORT_STEP(32, 16); SORT_STEP(32, 8); SORT_STEP(32, 4);
+					SORT_STEP(32, 2); SORT_STEP(32, 1);
+					SORT_STEP(64, 32); SORT_STEP(64, 16); SORT_STEP(64, 8);
+					SORT_STEP(64, 4); SORT_STEP(64, 2); SORT_STEP(64, 1);
+#undef SORT_STEP
+					/* neighbours: DPP wave shifts (lane 0 / 63 keep their own) */
+					u32 left = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xF, 0xF, false);
+					u32 right = __builtin_amdgcn_update_dpp(key, key, 0x130, 0xF, 0xF, false);
 					bool first = lane == 0 || (left >> 6) != (key >> 6);
 					bool last = lane == 63 || (right >> 6) != (key >> 6);
 					u32 orig = key & 63, hh = key >> 6;

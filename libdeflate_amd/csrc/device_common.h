@@ -52,6 +52,31 @@ static __device__ __forceinline__ u32 bcast_lane(u32 v, u32 lane)
 	return __builtin_amdgcn_readlane(v, lane);
 }
 
+/*
+ * v from lane (lane ^ J), J a power of two known at compile time.  Within a
+ * row of 16 lanes this is one or two DPP moves (quad_perm for 1 and 2;
+ * reversals of 8 and 16 lanes compose to 4 and 8), across rows of a 32-lane
+ * half a ds_swizzle; only J = 32 needs the LDS permute.
+ */
+template <u32 J> static __device__ __forceinline__ u32 lane_xor(u32 v)
+{
+	if (J == 1)
+		return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+	if (J == 2)
+		return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+	if (J == 4) {	/* reverse 8, then reverse 4: xor 7 ^ 3 */
+		u32 t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+		return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);
+	}
+	if (J == 8) {	/* reverse 16, then reverse 8: xor 15 ^ 7 */
+		u32 t = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+		return __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);
+	}
+	if (J == 16)
+		return __builtin_amdgcn_ds_swizzle(v, 0x401F);
+	return __shfl_xor(v, 32, 64);
+}
+
 static __device__ __forceinline__ u32 wave_xor(u32 v)
 {
 #pragma unroll
