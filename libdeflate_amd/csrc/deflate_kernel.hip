@@ -1783,13 +1783,15 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					u32 wend = w0 + EWIN < bend ? w0 + EWIN : bend;
 					const u32 v_spill_next = wpar ? V_SPILL : V_SPILL1;
 					const u32 v_cnt = wpar ? V_SEQCNT1 : V_SEQCNT;
-					/* this thread's input bytes, from HBM (the block may be
-					 * longer than the LDS ring); in flight during the scatter */
+					/* this thread's input bytes: from the LDS ring while it
+					 * still holds them, else from HBM (a block may be longer
+					 * than the ring); in flight during the scatter */
 					u8 litb[(EWIN + NT - 1) / NT];
 #pragma unroll
 					for (u32 k = 0; k < (EWIN + NT - 1) / NT; k++) {
 						u32 pos = w0 + tid * ((EWIN + NT - 1) / NT) + k;
-						litb[k] = pos < wend ? inp[pos] : 0;
+						litb[k] = pos >= wend ? 0 :
+							  pos + RING >= loaded + 32 ? L->in[pos & RMASK] : inp[pos];
 					}
 					/* matches that start in this window (the list is
 					 * position-sorted and holds < NT of them per window) */
