@@ -236,3 +236,67 @@ def test_block_split_follows_content():
             assert b["start"] + b["len"] - 32768 * ((b["start"] + b["len"]) // 32768) <= 8192
         if ref is not None:
             assert len(z) <= 1.05 * len(ref.compress("deflate", 6, d))
+
+
+def test_device_batch_ragged_unaligned(oracle):
+    """Device batch with ragged sizes and byte-granular (unaligned) input and
+    output offsets, neighbours packed back to back: no slot may be touched
+    outside [offset, offset + size), and every chunk round-trips through both
+    our decoder (unaligned too) and the oracle."""
+    import torch
+    from libdeflate_amd import api
+    rng = np.random.default_rng(0x0E110050)
+    sizes = [0, 1, 17, 4095, 4096, 4097, 5000, 33333, 65536, 65537, 100001, 131071,
+             200000, 3, 70000, 12345]
+    chunks = [datagen.chunk(i, s, 0x0E110051) for i, s in enumerate(sizes)]
+    n = len(sizes)
+    for fmt, lvl in (("gzip", 6), ("deflate", 1), ("zlib", 9)):
+        c = api.Compressor(lvl)
+        d = api.Decompressor()
+        in_off, pos = [], 3
+        blob = bytearray(b"\xAA" * 3)
+        for ch in chunks:
+            in_off.append(pos)
+            blob += ch
+            pad = int(rng.integers(0, 3))
+            blob += b"\xAA" * pad
+            pos += len(ch) + pad
+        blob += b"\xAA" * 64
+        data = torch.frombuffer(blob, dtype=torch.uint8).cuda()
+        bounds = [c.bound(fmt, s) for s in sizes]
+        c_off, pos = [], 5
+        for b in bounds:
+            c_off.append(pos)
+            pos += b + int(rng.integers(0, 2))
+        comp = torch.full((pos + 64,), 0x55, dtype=torch.uint8, device="cuda")
+        t = lambda v: torch.tensor(v, dtype=torch.int64, device="cuda")
+        c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
+        c.compress_batch(fmt, data, t(in_off), t(sizes), comp, t(c_off), t(bounds), c_n)
+        torch.cuda.synchronize()
+        got = c_n.cpu().numpy()
+        cb = comp.cpu().numpy()
+        for i in range(n):
+            assert 0 < got[i] <= bounds[i], (fmt, i)
+            z = cb[c_off[i]:c_off[i] + got[i]].tobytes()
+            _check_roundtrip(oracle, fmt, chunks[i], z, (fmt, "ragged", i))
+            # bytes between this slot's data and the next slot are untouched
+            end = c_off[i + 1] if i + 1 < n else len(cb)
+            assert (cb[c_off[i] + got[i]:end] == 0x55).all(), (fmt, "slot overrun", i)
+        assert (cb[:5] == 0x55).all()
+        # decode from the unaligned compressed slots into unaligned outputs
+        o_off, pos = [], 7
+        for s in sizes:
+            o_off.append(pos)
+            pos += s + int(rng.integers(0, 3))
+        out = torch.full((pos + 64,), 0x33, dtype=torch.uint8, device="cuda")
+        res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        d.decompress_batch(fmt, comp, t(c_off), c_n, out, t(o_off), t(sizes), res)
+        torch.cuda.synchronize()
+        assert res.cpu().numpy().tolist() == [0] * n
+        ob = out.cpu().numpy()
+        for i in range(n):
+            assert ob[o_off[i]:o_off[i] + sizes[i]].tobytes() == chunks[i], (fmt, "decode", i)
+            end = o_off[i + 1] if i + 1 < n else len(ob)
+            assert (ob[o_off[i] + sizes[i]:end] == 0x33).all(), (fmt, "output overrun", i)
+        c.close()
+        d.close()
