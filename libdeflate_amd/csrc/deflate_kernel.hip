@@ -685,7 +685,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
-	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u32 tid = threadIdx.x;
 	/* block-relative position | length << 32 | distance << 41 */
 	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_GCAP;
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
@@ -785,6 +785,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			const u32 tend = t + TILE < n ? t + TILE : n;
 			const bool last_tile = tile + 1 == num_tiles;
 			const bool prime = t < dict_len;	/* dictionary tile (whole tiles) */
+			/* the thread index is made opaque once per tile: otherwise every
+			 * per-lane address in this loop body is computed before the loop
+			 * and kept alive (in scratch) across it */
+			u32 tid_opaque = threadIdx.x;
+			asm volatile("" : "+v"(tid_opaque));
+			const u32 tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
 
 			PROF_MARK(0);
 			/* ---- S0: stage input up to tend + LOOKAHEAD ---- */
