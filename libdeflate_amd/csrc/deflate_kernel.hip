@@ -606,7 +606,7 @@ stg_put(struct deflate_lds *L, const struct outstate *os, u64 bitpos, u64 code,
  * Write the completed bytes of the staging area to HBM and slide the rest to
  * the front.  Whole workgroup; 'final' also writes the last partial unit.
  */
-static __device__ void
+static __device__ __forceinline__ void
 stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
 {
 	u32 *stg = stg_of(L);
@@ -649,7 +649,7 @@ stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
 
 /* bring back the few unfinished bytes saved in carry[] (the staging area
  * shares LDS with the tile scratch and is clobbered between blocks) */
-static __device__ void stg_restore(struct deflate_lds *L)
+static __device__ __forceinline__ void stg_restore(struct deflate_lds *L)
 {
 	u32 *stg = stg_of(L);
 
@@ -659,7 +659,7 @@ static __device__ void stg_restore(struct deflate_lds *L)
 	__syncthreads();
 }
 
-static __device__ void stg_save(struct deflate_lds *L, struct outstate *os)
+static __device__ __forceinline__ void stg_save(struct deflate_lds *L, struct outstate *os)
 {
 	stg_flush(L, os, false);
 	if (threadIdx.x < 6)
