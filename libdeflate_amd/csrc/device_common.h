@@ -104,16 +104,16 @@ static __device__ __forceinline__ u64 wave_sum64(u64 v)
 	return v;
 }
 
-/* inclusive prefix sum across the 64 lanes */
+/* inclusive prefix sum across the 64 lanes: DPP row shifts inside the rows of
+ * 16, then row_bcast15 / row_bcast31 carry the row totals (no LDS permutes) */
 static __device__ __forceinline__ u32 wave_scan_incl(u32 v)
 {
-	u32 lane = lane_id();
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		u32 t = __shfl_up(v, off, 64);
-		if (lane >= (u32)off)
-			v += t;
-	}
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);	/* row_shr:1 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);	/* row_shr:2 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);	/* row_shr:4 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);	/* row_shr:8 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);	/* row_bcast15 -> rows 1, 3 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);	/* row_bcast31 -> rows 2, 3 */
 	return v;
 }
 
