@@ -535,7 +535,7 @@ struct par_bits {
 /* 'inp' is the round's input span staged in LDS (8-byte aligned, PAR_SPAN
  * bytes); b->nb and all bit positions of a round are relative to it */
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
-#define PAR_STAGE_BYTES (132u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
+#define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
 
 static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
 {
@@ -658,7 +658,7 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH,
 #ifndef PAR_RW
 #define PAR_RW 4096u
 #endif
-#define PAR_GBYTES 1024u	/* output bytes resolved per group */
+#define PAR_GBYTES 1088u	/* output bytes resolved per group (>= 4 x 258) */
 
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
 {
@@ -824,7 +824,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	}
 	wave_sync();
 	PROF_SEC(1);
-	/* ---- execute the tokens: up to 64 tokens / PAR_GBYTES bytes a group ----
+	/* ---- execute the tokens: up to 256 tokens / PAR_GBYTES bytes a group ----
 	 * The copies of a group are resolved per output BYTE, not per token:
 	 * byte b of the group is a literal, or a copy of the byte dist before
 	 * it; that byte may again be a copy inside the group (every word of a
@@ -836,38 +836,66 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * mirror of the recent output, or the output itself when it is further
 	 * back) and the rest read theirs from their root. */
 	{
-		u32 *po = (u32 *)stage;			/* [65] token byte offsets */
-		u32 *tk = (u32 *)stage + 66;		/* [64] the group's tokens */
-		u16 *R = (u16 *)((u32 *)stage + 132);	/* [PAR_GBYTES] byte -> source byte */
+		u32 *tk = (u32 *)stage;			/* [256] the group's tokens */
+		u16 *R = (u16 *)((u32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */
 		u64 gbase = out0;
-		u32 g = 0;
+		u32 g = 0;		/* a multiple of 4: 16-byte token loads */
 		while (g < total_tok) {
-			const bool have0 = g + lane < total_tok;
-			const u32 t = have0 ? tok[g + lane] : 0;
-			const u32 len0 = !have0 ? 0 : (t >> 31) ? (t & 0x1FF) : 1;
-			const u32 incl0 = wave_scan_incl(len0);
-			/* the tokens that fit: a prefix (offsets are increasing) */
-			const bool fits = have0 && incl0 <= PAR_GBYTES;
+			/* four consecutive tokens per lane */
+			const u32 ti0 = g + 4 * lane;
+			uint4 tq = make_uint4(0, 0, 0, 0);
+			if (ti0 < total_tok)
+				tq = *(const uint4 *)(tok + ti0);
+			const u32 tw4[4] = { tq.x, tq.y, tq.z, tq.w };
+			u32 len4[4], lsum = 0;
+#pragma unroll
+			for (u32 j = 0; j < 4; j++) {
+				len4[j] = ti0 + j >= total_tok ? 0 :
+					  (tw4[j] >> 31) ? (tw4[j] & 0x1FF) : 1;
+				lsum += len4[j];
+			}
+			const u32 incl0 = wave_scan_incl(lsum);
+			/* the lanes whose tokens fit: a prefix */
+			const bool fits = ti0 < total_tok && incl0 <= PAR_GBYTES;
 			const u32 cnt = __builtin_popcountll(__ballot(fits));
 			const u32 gtot = bcast_lane(incl0, cnt - 1);
-			po[lane] = incl0 - len0;
-			tk[lane] = t;
-			if (lane == 0)
-				po[64] = 0xFFFFFFFFu;
+			/* byte -> token: every token drops its number at its first
+			 * byte, a running maximum over the bytes spreads it */
+			for (u32 b0 = lane; b0 < gtot; b0 += 64)
+				R[b0] = 0;
 			wave_sync();
-			if (lane == cnt)
-				po[cnt] = 0xFFFFFFFFu;	/* searches stop at the group's end */
+			if (lane < cnt) {
+				u32 o = incl0 - lsum;
+#pragma unroll
+				for (u32 j = 0; j < 4; j++) {
+					tk[4 * lane + j] = tw4[j];
+					if (len4[j])
+						R[o] = (u16)(4 * lane + j + 1);
+					o += len4[j];
+				}
+			}
 			wave_sync();
-			/* bytes -> tokens -> source pointers; roots take their value */
+			u32 carry = 0;
 			for (u32 b0 = 0; b0 < gtot; b0 += 64) {
 				const u32 bi = b0 + lane;
+				u32 own = bi < gtot ? R[bi] : 0;
+				/* inclusive running maximum (DPP, as wave_scan_incl) */
+#define DPP_MAX(ctrl, rm, bc)                                                  \
+	do {                                                                   \
+		u32 t_ = __builtin_amdgcn_update_dpp(0, own, ctrl, rm, 0xF, bc); \
+		own = own > t_ ? own : t_;                                     \
+	} while (0)
+				DPP_MAX(0x111, 0xF, true);
+				DPP_MAX(0x112, 0xF, true);
+				DPP_MAX(0x114, 0xF, true);
+				DPP_MAX(0x118, 0xF, true);
+				DPP_MAX(0x142, 0xA, false);
+				DPP_MAX(0x143, 0xC, false);
+#undef DPP_MAX
+				own = own > carry ? own : carry;
+				carry = bcast_lane(own, 63);
 				if (bi < gtot) {
-					u32 ti = 0;	/* last token with po[ti] <= bi */
-#pragma unroll
-					for (u32 step = 32; step; step >>= 1)
-						if (po[ti + step] <= bi)
-							ti += step;
-					const u32 tw = tk[ti];
+					const u32 tw = tk[own - 1];
 					const u32 dist = (tw >> 9) & 0xFFFF;
 					u32 src = bi;
 					u32 v = tw & 0xFF;
@@ -918,7 +946,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			}
 			wave_sync();
 			gbase += gtot;
-			g += cnt;
+			g += 4 * cnt;
 		}
 	}
 	PROF_SEC(2);
