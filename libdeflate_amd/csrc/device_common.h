@@ -85,14 +85,6 @@ static __device__ __forceinline__ u32 wave_xor(u32 v)
 	return v;
 }
 
-static __device__ __forceinline__ u32 wave_sum(u32 v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-		v += __shfl_xor(v, off, 64);
-	return v;
-}
-
 static __device__ __forceinline__ u64 wave_sum64(u64 v)
 {
 #pragma unroll
@@ -115,6 +107,12 @@ static __device__ __forceinline__ u32 wave_scan_incl(u32 v)
 	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);	/* row_bcast15 -> rows 1, 3 */
 	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);	/* row_bcast31 -> rows 2, 3 */
 	return v;
+}
+
+/* sum over the wave, wave-uniform: the last lane of the DPP scan */
+static __device__ __forceinline__ u32 wave_sum(u32 v)
+{
+	return (u32)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
 }
 
 static __device__ __forceinline__ u32 wave_max(u32 v)
