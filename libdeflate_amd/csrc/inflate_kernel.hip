@@ -662,7 +662,9 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH,
 
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
 {
-	u32 lo = __shfl_up((u32)v, 1, 64), hi = __shfl_up((u32)(v >> 32), 1, 64);
+	/* DPP wave_shr:1 (lane 0 keeps its own value) */
+	u32 lo = __builtin_amdgcn_update_dpp((u32)v, (u32)v, 0x138, 0xF, 0xF, false);
+	u32 hi = __builtin_amdgcn_update_dpp((u32)(v >> 32), (u32)(v >> 32), 0x138, 0xF, 0xF, false);
 	return ((u64)hi << 32) | lo;
 }
 
