@@ -681,7 +681,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			 u64 *__restrict__ out_nbytes,
 			 const u32 *__restrict__ sums,
 			 u64 *__restrict__ seq_scratch,
-			 const u32 *__restrict__ seg_info)
+			 const u32 *__restrict__ seg_info,
+			 u32 *__restrict__ next_chunk)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
@@ -691,7 +692,17 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
-	for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+	/* Buffers are handed out dynamically (one global counter): their cost
+	 * depends on their content, and a fixed stride gives every workgroup
+	 * the same kind of buffer whenever the batch is periodic. */
+	for (;;) {
+		__syncthreads();
+		if (tid == 0)
+			L->vars[V_TMP0] = atomicAdd(next_chunk, 1u);
+		__syncthreads();
+		const u64 c = L->vars[V_TMP0];
+		if (c >= n_chunks)
+			break;
 		const u8 *inp = in_base + in_offsets[c];
 		const u64 n64 = in_nbytes[c];
 		struct outstate os;

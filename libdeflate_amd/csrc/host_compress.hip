@@ -136,15 +136,17 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		set_error("compress_batch: bad argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	/* scratch: [match lists: u64 x words x grid][sums u32 x n] */
+	/* scratch: [match lists: u64 x words x grid][chunk counter][sums u32 x n] */
 	size_t grid = n < (size_t)ctx->num_cus ? n : (size_t)ctx->num_cus;
 	size_t seq_bytes = grid * lda_deflate_seq_words() * 8;
-	uint8_t *scr = (uint8_t *)c->scratch.reserve(seq_bytes + n * 4);
+	uint8_t *scr = (uint8_t *)c->scratch.reserve(seq_bytes + 16 + n * 4);
 	if (!scr)
 		return LIBDEFLATE_AMD_OOM;
+	uint32_t *next_chunk = (uint32_t *)(scr + seq_bytes);
+	LDA_HIP_TRY(hipMemsetAsync(next_chunk, 0, 16, st), LIBDEFLATE_AMD_NO_DEVICE);
 	uint32_t *sums = NULL;
 	if (format != LIBDEFLATE_AMD_DEFLATE) {
-		sums = (uint32_t *)(scr + seq_bytes);
+		sums = (uint32_t *)(scr + seq_bytes + 16);
 		int rc = format == LIBDEFLATE_AMD_GZIP ?
 			libdeflate_amd_crc32_batch(n, d_in, d_in_offsets,
 						   d_in_nbytes, NULL, sums, stream) :
@@ -168,7 +170,7 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
 			   d_out_offsets, d_out_avail, d_out_nbytes, sums,
-			   (uint64_t *)scr, d_seg_info);
+			   (uint64_t *)scr, d_seg_info, next_chunk);
 	LDA_HIP_TRY(hipGetLastError(), LIBDEFLATE_AMD_NO_DEVICE);
 	return LIBDEFLATE_AMD_OK;
 }
