@@ -877,31 +877,50 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				}
 			}
 			wave_sync();
+			/* The slots (64 bytes each) are independent except for the
+			 * running maximum, so the steps below work on SB slots at a
+			 * time: the LDS / HBM reads of a batch are all issued before
+			 * the first is used (one memory latency per batch, not per
+			 * slot). */
+			enum { SB = 4 };
 			u32 carry = 0;
-			for (u32 b0 = 0; b0 < gtot; b0 += 64) {
-				const u32 bi = b0 + lane;
-				u32 own = bi < gtot ? R[bi] : 0;
-				/* inclusive running maximum (DPP, as wave_scan_incl) */
+			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
+				u32 own[SB], vv[SB];
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					own[k] = bi < gtot ? R[bi] : 0;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					u32 o = own[k];
 #define DPP_MAX(ctrl, rm, bc)                                                  \
 	do {                                                                   \
-		u32 t_ = __builtin_amdgcn_update_dpp(0, own, ctrl, rm, 0xF, bc); \
-		own = own > t_ ? own : t_;                                     \
+		u32 t_ = __builtin_amdgcn_update_dpp(0, o, ctrl, rm, 0xF, bc);  \
+		o = o > t_ ? o : t_;                                           \
 	} while (0)
-				DPP_MAX(0x111, 0xF, true);
-				DPP_MAX(0x112, 0xF, true);
-				DPP_MAX(0x114, 0xF, true);
-				DPP_MAX(0x118, 0xF, true);
-				DPP_MAX(0x142, 0xA, false);
-				DPP_MAX(0x143, 0xC, false);
+					DPP_MAX(0x111, 0xF, true);
+					DPP_MAX(0x112, 0xF, true);
+					DPP_MAX(0x114, 0xF, true);
+					DPP_MAX(0x118, 0xF, true);
+					DPP_MAX(0x142, 0xA, false);
+					DPP_MAX(0x143, 0xC, false);
 #undef DPP_MAX
-				own = own > carry ? own : carry;
-				carry = bcast_lane(own, 63);
-				if (bi < gtot) {
-					const u32 tw = tk[own - 1];
+					o = o > carry ? o : carry;
+					carry = bcast_lane(o, 63);
+					own[k] = o;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					own[k] = bi < gtot ? tk[own[k] - 1] : 0;	/* token word */
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane, tw = own[k];
 					const u32 dist = (tw >> 9) & 0xFFFF;
-					u32 src = bi;
-					u32 v = tw & 0xFF;
-					if (tw >> 31) {
+					u32 src = bi, v = tw & 0xFF;
+					if (bi < gtot && (tw >> 31)) {
 						if (dist <= bi) {
 							src = bi - dist;
 						} else {
@@ -911,10 +930,18 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 								win[(u32)sp & (PAR_RW - 1)] : outp[sp];
 						}
 					}
-					R[bi] = (u16)src;
-					if (src == bi) {
-						win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)v;
-						outp[gbase + bi] = (u8)v;
+					own[k] = src;
+					vv[k] = v;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					if (bi < gtot) {
+						R[bi] = (u16)own[k];
+						if (own[k] == bi) {
+							win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)vv[k];
+							outp[gbase + bi] = (u8)vv[k];
+						}
 					}
 				}
 			}
@@ -922,12 +949,23 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			/* pointer doubling to the roots */
 			for (;;) {
 				bool changed = false;
-				for (u32 b0 = 0; b0 < gtot; b0 += 64) {
-					const u32 bi = b0 + lane;
-					if (bi < gtot) {
-						u32 r = R[bi], rr = R[r];
-						changed |= rr != r;
-						R[bi] = (u16)rr;
+				for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
+					u32 r[SB], rr[SB];
+#pragma unroll
+					for (u32 k = 0; k < SB; k++) {
+						const u32 bi = s0 + 64 * k + lane;
+						r[k] = bi < gtot ? R[bi] : 0;
+					}
+#pragma unroll
+					for (u32 k = 0; k < SB; k++)
+						rr[k] = R[r[k]];
+#pragma unroll
+					for (u32 k = 0; k < SB; k++) {
+						const u32 bi = s0 + 64 * k + lane;
+						if (bi < gtot) {
+							changed |= rr[k] != r[k];
+							R[bi] = (u16)rr[k];
+						}
 					}
 				}
 				wave_sync();
@@ -935,14 +973,22 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					break;
 			}
 			/* everyone else copies its root's value */
-			for (u32 b0 = 0; b0 < gtot; b0 += 64) {
-				const u32 bi = b0 + lane;
-				if (bi < gtot) {
-					const u32 r = R[bi];
-					if (r != bi) {
-						const u8 v = win[(u32)(gbase + r) & (PAR_RW - 1)];
-						win[(u32)(gbase + bi) & (PAR_RW - 1)] = v;
-						outp[gbase + bi] = v;
+			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
+				u32 r[SB], vv[SB];
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					r[k] = bi < gtot ? R[bi] : bi;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					vv[k] = win[(u32)(gbase + r[k]) & (PAR_RW - 1)];
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					if (bi < gtot && r[k] != bi) {
+						win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)vv[k];
+						outp[gbase + bi] = (u8)vv[k];
 					}
 				}
 			}
