@@ -73,6 +73,26 @@ def pmc_traffic():
     return int(2 * k["FETCH_SIZE_per_launch"] * 1024 + k["WRITE_SIZE_per_launch"] * 1024)
 
 
+def pmc_issue(t_launch_s):
+    """Share of the machine's VALU issue slots the compress kernel used: a
+    wave64 VALU instruction occupies its SIMD for 4 cycles whatever the number
+    of active lanes (SQ_INSTS_VALU from the same PMC passes; 256 CUs x 4 SIMDs
+    at the 2.4 GHz maximum clock of MI355X_MICROARCH.md).  This, not HBM, is
+    what bounds the kernel; None if no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_deflate*.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("lda_deflate_batch_kernel", {})
+    if "SQ_INSTS_VALU_per_launch" not in k:
+        return None
+    valu = k["SQ_INSTS_VALU_per_launch"]
+    return {"valu_wave_insts_per_launch": int(valu),
+            "simd_issue_frac": round(valu * 4 / (1024 * 2.4e9 * t_launch_s), 3),
+            "note": "VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x "
+                    "launch time); the kernel is issue-bound, not HBM-bound"}
+
+
 def cpu_baseline(chunks, threads):
     """Reference libdeflate (oracle/_ref) on host cores: gzip level 6 compress
     then decompress of a bounded sample, best of 3 after a warm-up."""
@@ -236,6 +256,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((U + C) / t_comp / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic(),
+                "issue": pmc_issue(t_comp),
                 "algorithmic_bytes_per_launch": U + C,
                 "avg_launch_ms": round(t_comp * 1e3, 3),
                 "note": "HIP events on the launch stream around the compress "
