@@ -46,6 +46,7 @@
  * (libdeflate.h:76-83 leaves them unpinned); validity, round trip,
  * compress_bound and ratio-vs-reference are what the tests check.
  */
+#include <stddef.h>
 #include "device_common.h"
 #include "kernels.h"
 
@@ -119,6 +120,8 @@ struct deflate_lds {
 };
 
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
+static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at LDS offset 0");
+#define PREV_OFF ((u32)offsetof(struct deflate_lds, prev))
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
@@ -140,18 +143,28 @@ struct level_params {
  * measured ~10x slower than aligned ones.  The ring is mirrored for 32 bytes
  * past its end so idx+1/idx+2 never wrap.
  */
+/*
+ * The kernel has no static LDS, so the dynamic LDS block (struct deflate_lds)
+ * starts at LDS address 0 (checked once per workgroup): reads of the hot
+ * arrays go through address-space-3 pointers built from constant offsets, so
+ * the array base folds into the instruction's immediate offset instead of
+ * costing a VALU add of a link-time symbol per access.
+ */
+#define LDS32(byteoff) (*(const __attribute__((address_space(3))) u32 *)(uintptr_t)(byteoff))
+#define LDS16(byteoff) (*(const __attribute__((address_space(3))) u16 *)(uintptr_t)(byteoff))
+
 static __device__ __forceinline__ u32 ld32(const u8 *ring, u32 pos)
 {
-	const u32 *r32 = (const u32 *)ring;
-	u32 o = pos & RMASK, i = o >> 2;
-	return __builtin_amdgcn_alignbyte(r32[i + 1], r32[i], o & 3);
+	(void)ring;	/* in[] is the first member: byte offset 0 */
+	u32 o = pos & RMASK, i = o & ~3u;
+	return __builtin_amdgcn_alignbyte(LDS32(i + 4), LDS32(i), o & 3);
 }
 
 static __device__ __forceinline__ u64 ld64(const u8 *ring, u32 pos)
 {
-	const u32 *r32 = (const u32 *)ring;
-	u32 o = pos & RMASK, i = o >> 2;
-	u32 a = r32[i], b = r32[i + 1], c = r32[i + 2];
+	(void)ring;
+	u32 o = pos & RMASK, i = o & ~3u;
+	u32 a = LDS32(i), b = LDS32(i + 4), c = LDS32(i + 8);
 	u32 lo = __builtin_amdgcn_alignbyte(b, a, o & 3);
 	u32 hi = __builtin_amdgcn_alignbyte(c, b, o & 3);
 	return ((u64)hi << 32) | lo;
@@ -687,6 +700,8 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
 	const u32 tid = threadIdx.x;
+	if ((u32)(uintptr_t)(__attribute__((address_space(3))) u8 *)lds_raw != 0)
+		__builtin_trap();	/* see LDS32(): the dynamic LDS block must start at 0 */
 	/* block-relative position | length << 32 | distance << 41 */
 	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_GCAP;
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
@@ -1047,7 +1062,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 										curb = cur;
 										boff = 0;
 										nxt8 = ld64(L->in, p + 4);
-										c16 = L->prev[p & RMASK];
+										c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
 										maxlen = n - p < 258 ? n - p : 258;
 										dmaxp = p - lo_pos;
 										/* the last positions of a tile are claimed when
@@ -1077,7 +1092,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							bool ok = !stall && chain;
 							u32 cp = p - d;
 							u32 w = ld32(L->in, cp + boff);
-							u32 c16n = L->prev[cp & RMASK];
+							u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
 							bool hit = ok && w == curb;
 							c16 = ok ? c16n : c16;
 							dprev = ok ? d : dprev;
