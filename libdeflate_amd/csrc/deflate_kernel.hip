@@ -119,6 +119,16 @@ struct deflate_lds {
 	u32 vars[16];
 };
 
+/* LDS-resident: every pointer into the block carries the address space, and
+ * the block itself sits at LDS address 0 (no static LDS in this kernel), so
+ * member offsets become instruction immediates */
+#ifdef __HIP_DEVICE_COMPILE__
+#define AS3 __attribute__((address_space(3)))
+#else
+#define AS3	/* the host pass only parses the device code */
+#endif
+typedef AS3 struct deflate_lds lds_t;
+
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at LDS offset 0");
 #define PREV_OFF ((u32)offsetof(struct deflate_lds, prev))
@@ -153,14 +163,14 @@ struct level_params {
 #define LDS32(byteoff) (*(const __attribute__((address_space(3))) u32 *)(uintptr_t)(byteoff))
 #define LDS16(byteoff) (*(const __attribute__((address_space(3))) u16 *)(uintptr_t)(byteoff))
 
-static __device__ __forceinline__ u32 ld32(const u8 *ring, u32 pos)
+static __device__ __forceinline__ u32 ld32(const AS3 u8 *ring, u32 pos)
 {
 	(void)ring;	/* in[] is the first member: byte offset 0 */
 	u32 o = pos & RMASK, i = o & ~3u;
 	return __builtin_amdgcn_alignbyte(LDS32(i + 4), LDS32(i), o & 3);
 }
 
-static __device__ __forceinline__ u64 ld64(const u8 *ring, u32 pos)
+static __device__ __forceinline__ u64 ld64(const AS3 u8 *ring, u32 pos)
 {
 	(void)ring;
 	u32 o = pos & RMASK, i = o & ~3u;
@@ -190,12 +200,12 @@ static __device__ __forceinline__ u32 hash4(u32 w)
  */
 struct deflate_lds;
 static __device__ u32
-find_len3(const struct deflate_lds *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
+find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 	  u32 dlim, u32 *best);
 
 /* workgroup exclusive scan of one value per thread; returns the exclusive
  * prefix and writes the total to *total.  Two barriers. */
-static __device__ u32 block_scan(struct deflate_lds *L, u32 v, u32 *total)
+static __device__ u32 block_scan(lds_t *L, u32 v, u32 *total)
 {
 	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	u32 incl = wave_scan_incl(v);
@@ -220,7 +230,7 @@ static __device__ u32 block_scan(struct deflate_lds *L, u32 v, u32 *total)
  * (*tog flips per call, uniformly), so a fast thread's next call cannot
  * overwrite what a slow thread still reads.  Every second call reuses an
  * array, and the barrier of the call in between orders that. */
-static __device__ u32 block_scan1(struct deflate_lds *L, u32 v, u32 *total,
+static __device__ u32 block_scan1(lds_t *L, u32 v, u32 *total,
 				  u32 *tog)
 {
 	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -293,7 +303,7 @@ static __device__ u32 choose_min_len(u32 used_literals, u32 depth)
 }
 
 static __device__ u32
-find_len3(const struct deflate_lds *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
+find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 	  u32 dlim, u32 *best)
 {
 	if (dmax > dlim)
@@ -499,7 +509,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			for (u32 j = 0; j < 5; j++) {
 				u32 k = lane + 64 * j;
 				if (k <= root)
-					atomicAdd(&H->cntI[dd[j] < 39 ? dd[j] : 39], 1u);
+					atomicAdd((u32 *)&H->cntI[dd[j] < 39 ? dd[j] : 39], 1u);
 			}
 			wave_sync();
 			/* leaves at depth d = 2 * internal(d-1) - internal(d) */
@@ -592,14 +602,14 @@ struct outstate {
 	u64 bits;		/* bits produced so far, relative to out[0] */
 };
 
-static __device__ __forceinline__ u32 *stg_of(struct deflate_lds *L)
+static __device__ __forceinline__ u32 *stg_of(lds_t *L)
 {
 	return (u32 *)L->nxtA;
 }
 
 /* OR 'nbits' (<= 57) bits of 'code' at absolute bit position 'bitpos' */
 static __device__ __forceinline__ void
-stg_put(struct deflate_lds *L, const struct outstate *os, u64 bitpos, u64 code,
+stg_put(lds_t *L, const struct outstate *os, u64 bitpos, u64 code,
 	u32 nbits)
 {
 	if (!nbits)
@@ -608,11 +618,11 @@ stg_put(struct deflate_lds *L, const struct outstate *os, u64 bitpos, u64 code,
 	u32 w = (u32)(rel >> 5), s = (u32)rel & 31;
 	u32 *stg = stg_of(L);
 	u64 lo = code << s;
-	atomicOr(&stg[w], (u32)lo);
+	atomicOr((u32 *)&stg[w], (u32)lo);
 	if (s + nbits > 32)
-		atomicOr(&stg[w + 1], (u32)(lo >> 32));
+		atomicOr((u32 *)&stg[w + 1], (u32)(lo >> 32));
 	if (s + nbits > 64)
-		atomicOr(&stg[w + 2], (u32)(code >> (64 - s)));
+		atomicOr((u32 *)&stg[w + 2], (u32)(code >> (64 - s)));
 }
 
 /*
@@ -620,7 +630,7 @@ stg_put(struct deflate_lds *L, const struct outstate *os, u64 bitpos, u64 code,
  * the front.  Whole workgroup; 'final' also writes the last partial unit.
  */
 static __device__ __forceinline__ void
-stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
+stg_flush(lds_t *L, struct outstate *os, bool final)
 {
 	u32 *stg = stg_of(L);
 	u8 *stgb = (u8 *)stg;
@@ -662,7 +672,7 @@ stg_flush(struct deflate_lds *L, struct outstate *os, bool final)
 
 /* bring back the few unfinished bytes saved in carry[] (the staging area
  * shares LDS with the tile scratch and is clobbered between blocks) */
-static __device__ __forceinline__ void stg_restore(struct deflate_lds *L)
+static __device__ __forceinline__ void stg_restore(lds_t *L)
 {
 	u32 *stg = stg_of(L);
 
@@ -672,7 +682,7 @@ static __device__ __forceinline__ void stg_restore(struct deflate_lds *L)
 	__syncthreads();
 }
 
-static __device__ __forceinline__ void stg_save(struct deflate_lds *L, struct outstate *os)
+static __device__ __forceinline__ void stg_save(lds_t *L, struct outstate *os)
 {
 	stg_flush(L, os, false);
 	if (threadIdx.x < 6)
@@ -698,7 +708,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 			 u32 *__restrict__ next_chunk)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-	struct deflate_lds *L = (struct deflate_lds *)lds_raw;
+	lds_t *L = (lds_t *)(uintptr_t)0;
 	const u32 tid = threadIdx.x;
 	if ((u32)(uintptr_t)(__attribute__((address_space(3))) u8 *)lds_raw != 0)
 		__builtin_trap();	/* see LDS32(): the dynamic LDS block must start at 0 */
@@ -1039,7 +1049,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							const u64 fm = __ballot(fin);
 							u32 cbase = 0;
 							if (lane == 0)
-								cbase = atomicAdd(&L->vars[V_CTR], nf);
+								cbase = atomicAdd((u32 *)&L->vars[V_CTR], nf);
 							cbase = bcast_first(cbase);
 							{	/* chains complete up to the claimed ones? */
 								const u32 need = cbase + nf < TILE ? cbase + nf : TILE;
@@ -1281,13 +1291,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									seqg[seq0 + npre] = (pos - block_start) |
 										((u64)l0 << 32) | ((u64)(mm >> 16) << 41);
 									length_code(l0, &sl, &xb, &xv);
-									atomicAdd(&L->freq[257 + sl], 1u);
+									atomicAdd((u32 *)&L->freq[257 + sl], 1u);
 									dist_code(mm >> 16, &sl, &xb, &xv);
-									atomicAdd(&L->freq[288 + sl], 1u);
+									atomicAdd((u32 *)&L->freq[288 + sl], 1u);
 								} else {
-									atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
+									atomicAdd((u32 *)&L->freq[L->in[pos & RMASK]], 1u);
 									if (st == 2)
-										atomicAdd(&L->freq[L->in[(pos + 1) & RMASK]], 1u);
+										atomicAdd((u32 *)&L->freq[L->in[(pos + 1) & RMASK]], 1u);
 								}
 							}
 							npre += ism ? 1 : 0;
@@ -1339,13 +1349,13 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							if (ism[k]) {
 								u32 sl, xb, xv;
 								length_code(l0, &sl, &xb, &xv);
-								atomicAdd(&L->freq[257 + sl], 1u);
+								atomicAdd((u32 *)&L->freq[257 + sl], 1u);
 								dist_code(m0[k] >> 16, &sl, &xb, &xv);
-								atomicAdd(&L->freq[288 + sl], 1u);
+								atomicAdd((u32 *)&L->freq[288 + sl], 1u);
 							} else {
-								atomicAdd(&L->freq[L->in[pos & RMASK]], 1u);
+								atomicAdd((u32 *)&L->freq[L->in[pos & RMASK]], 1u);
 								if (st == 2)
-									atomicAdd(&L->freq[L->in[(pos + 1) & RMASK]], 1u);
+									atomicAdd((u32 *)&L->freq[L->in[(pos + 1) & RMASK]], 1u);
 							}
 						}
 					}
@@ -1549,9 +1559,9 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						L->pre_freq[tid] = 0;
 					__syncthreads();
 					if (tid < 288 && tid >= 257 && L->lens[tid])
-						atomicMax(&L->vars[V_TMP1], tid + 1);
+						atomicMax((u32 *)&L->vars[V_TMP1], tid + 1);
 					if (tid >= 288 && tid < 320 && L->lens[tid])
-						atomicMax(&L->vars[V_TMP2], tid - 288 + 1);
+						atomicMax((u32 *)&L->vars[V_TMP2], tid - 288 + 1);
 					__syncthreads();
 					const u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
 					const u32 total = nlit + noff;
@@ -1595,12 +1605,12 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 							while (left >= 11) {
 								u32 r = left > 138 ? 138 : left;
 								L->pre_items[at++] = 18 | ((r - 11) << 5);
-								atomicAdd(&L->pre_freq[18], 1u);
+								atomicAdd((u32 *)&L->pre_freq[18], 1u);
 								left -= r;
 							}
 							if (left >= 3) {
 								L->pre_items[at++] = 17 | ((left - 3) << 5);
-								atomicAdd(&L->pre_freq[17], 1u);
+								atomicAdd((u32 *)&L->pre_freq[17], 1u);
 								left = 0;
 							}
 						} else if (left >= 4) {
@@ -1613,11 +1623,11 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								n16++;
 								left -= r;
 							}
-							atomicAdd(&L->pre_freq[16], n16);
-							atomicAdd(&L->pre_freq[rv], 1u);
+							atomicAdd((u32 *)&L->pre_freq[16], n16);
+							atomicAdd((u32 *)&L->pre_freq[rv], 1u);
 						}
 						if (left)
-							atomicAdd(&L->pre_freq[rv], left);
+							atomicAdd((u32 *)&L->pre_freq[rv], left);
 						while (left) {
 							L->pre_items[at++] = (u16)rv;
 							left--;
@@ -1842,7 +1852,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 									for (u32 j = 1; j < len && q + j < EWIN; j++)
 										KD[q + j] = 0xFFFFFFFFu;
 									if (pos + len > w0 + EWIN)
-										atomicMax(&L->vars[v_spill_next],
+										atomicMax((u32 *)&L->vars[v_spill_next],
 											  pos + len - (w0 + EWIN));
 								}
 							}
@@ -1852,7 +1862,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 								break;
 						}
 						if (lane == 0 && cw)
-							atomicAdd(&L->vars[v_cnt], cw);
+							atomicAdd((u32 *)&L->vars[v_cnt], cw);
 					}
 					__syncthreads();
 					seq_lo += L->vars[v_cnt];
