@@ -10,41 +10,48 @@
  *   gzip / zlib framing              lib/gzip_compress.c:31-82, lib/zlib_compress.c:31-74
  *
  * This is NOT the reference's algorithm transliterated: the reference walks
- * the buffer one position at a time.  Here ONE 512-thread workgroup (8 waves)
- * owns a buffer and keeps the whole 32 KiB LZ77 window state in the CU's
- * 160 KiB LDS:
+ * the buffer one position at a time.  Here ONE 1024-thread workgroup (16
+ * waves) owns a buffer and keeps the whole LZ77 window state in the CU's
+ * 160 KiB LDS (struct deflate_lds below):
  *
  *   in[]    32 KiB ring of input bytes           (coalesced 16 B loads)
  *   prev[]  32 Ki x u16 ring: previous position with the same 4-byte hash
- *   head[]  16 Ki x u16: most recent position per hash bucket
- *   seq[]   the current block's matches (position, length, distance)
+ *   head[]  most recent position per hash bucket; head3[] for 3-byte matches
+ *   M[]     per-position best (length, distance) of the current tile
  *
- * and advances in TILES of 2048 positions:
+ * and advances in TILES of 4096 positions:
  *
- *   S1  every lane hashes one position; each wave bitonic-sorts its 64
- *       (hash, lane) keys so equal hashes become neighbours: that yields the
- *       in-order "previous occurrence" links inside the group without any
- *       serial insertion;
- *   S2  one wave threads the groups through head[] in position order
- *       (first/last of each hash run only: no conflicts inside a group);
+ *   S1  every lane hashes its positions; each wave bitonic-sorts 64
+ *       (hash, position) keys with DPP exchanges so equal hashes become
+ *       neighbours: that yields the in-order "previous occurrence" links
+ *       inside the group without any serial insertion;
+ *   S2  wave 0 threads the groups through head[] in position order (first /
+ *       last of each hash run only), wave 1 does the same for head3[]; the
+ *       other waves already search the part of the tile published so far;
  *   S3  ALL positions of the tile search their chain in parallel (depth and
- *       nice length per level as lib/deflate_compress.c:3927-3979): quick
- *       4-byte reject, 8-byte-at-a-time extension, best (len, dist) per
- *       position;
- *   S4  the greedy / lazy / lazy2 choice is then a pure function of the
+ *       nice length per level as lib/deflate_compress.c:3927-3979), in
+ *       alternating "walk" passes (8 chain steps, filtered on the byte at the
+ *       best length so far) and "evaluate" passes (8-byte-at-a-time
+ *       extension of the queued hits); waves claim work dynamically;
+ *   S4  the greedy / lazy / lazy2 choice is a pure function of the
  *       per-position results (rules of deflate_compress.c:2573-2575,
- *       2712-2755); one lane walks the tile hopping from token to token;
- *   S5  at block end: symbol histogram -> length-limited canonical Huffman
- *       codes, exact cost of dynamic / static / stored, header;
- *   S6  tokens are encoded position-parallel: every lane looks up its
- *       codeword(s), a workgroup prefix sum of the bit lengths gives the bit
- *       offset, ds_or packs the bits into an LDS staging buffer that is
- *       written to HBM with coalesced 16-byte stores.
+ *       2712-2755): "next token start" is a forest over the positions, so
+ *       the parse is pointer doubling per wave segment plus a short chain
+ *       across segments; matches are appended to a per-workgroup list in HBM
+ *       and the symbol histogram is built in the same pass;
+ *   S5  at block end (content-driven split, deflate_compress.c:2143-2256, or
+ *       64 Ki positions): length-limited canonical Huffman codes, exact cost
+ *       of dynamic / static / stored, header;
+ *   S6  tokens are encoded position-parallel in windows of 4096 positions:
+ *       every lane looks up its codeword(s), a workgroup prefix sum of the
+ *       bit lengths gives the bit offset, ds_or packs the bits into an LDS
+ *       staging buffer that is written to HBM with coalesced stores.
  *
- * HBM traffic is the algorithmic minimum: the input is read once, the output
- * written once.  The compressed bytes differ from the reference's
- * (libdeflate.h:76-83 leaves them unpinned); validity, round trip,
- * compress_bound and ratio-vs-reference are what the tests check.
+ * HBM traffic beyond input-once / output-once: the match list (8 B per match,
+ * written in S4, read in S6) and literals of a block that have left the LDS
+ * ring by the time the block is flushed.  The compressed bytes differ from
+ * the reference's (libdeflate.h:76-83 leaves them unpinned); validity, round
+ * trip, compress_bound and ratio-vs-reference are what the tests check.
  */
 #include <stddef.h>
 #include "device_common.h"
