@@ -79,6 +79,7 @@
 #define MAX_BLOCK_LEN 65536u
 #define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
+#define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
 #define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
@@ -366,6 +367,211 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 		}
 	}
 	return l0;
+}
+
+/* ---------------- min-cost parse (levels 10-12) ---------------- */
+
+/*
+ * The reference's levels 10-12 (lib/deflate_compress.c:3327-3849) collect all
+ * matches per position with a binary-tree finder, run a backward min-cost DP
+ * over a whole block and re-cost it several times.  Restated for the tile
+ * pipeline:
+ *   - the candidates of a position are all the lengths 3..L of its best
+ *     (longest, then nearest) match from the chain search;
+ *   - symbol prices are -log2 of the frequencies of the block so far, in
+ *     1/16 bit.  The first tile of a block has no history: it is parsed
+ *     lazily into the histogram first (a dry run that is rolled back), and if
+ *     pure literals priced by the tile's own byte statistics would be
+ *     cheaper than that parse, literal prices come from the byte statistics
+ *     and match prices from flat defaults (the role of the reference's
+ *     default-cost tables, :2986-3102);
+ *   - the DP runs per wave over 256 positions plus 128 positions of warm-up
+ *     beyond them (a min-cost parse forgets its start within a few tokens,
+ *     like a Huffman parse re-synchronises), backwards, with the cost-to-go
+ *     of the next 320 positions held in five registers per lane that rotate
+ *     by one lane per step: no memory traffic inside the recurrence;
+ *   - the chosen lengths replace the match lengths in M[], and the ordinary
+ *     token walk (S4, greedy rule) follows them.
+ */
+#define OPT_SEG 256
+#define OPT_WARM 128
+#define OPT_BIG 0x40000000u
+/* price tables (u16, 1/16 bit) and the byte histogram live in the block-end
+ * scratch, which is dead until S4 uses nxtB */
+#define OPT_LIT(L) ((AS3 u16 *)(L)->sorted)	/* [256] by literal */
+#define OPT_LEN(L) ((AS3 u16 *)(L)->codes)	/* [259] by length, extra bits included */
+#define OPT_OFF(L) ((AS3 u16 *)(L)->pre_items)	/* [30] by offset slot, extra bits included */
+#define OPT_HIST(L) ((AS3 u32 *)(L)->hw)	/* [256] bytes of the tile */
+
+static __device__ __forceinline__ u32 opt_price(u32 f, float lg_total, float maxbits)
+{
+	float b = lg_total - __log2f((float)f + 0.4f);
+	b = fminf(fmaxf(b, 1.0f), maxbits);
+	return (u32)(b * 16.0f + 0.5f);
+}
+
+/* Prices from freq[]; with try_flat (freq[] = lazy parse of this tile alone)
+ * the literal-only estimate decides between them and the flat start.
+ * Whole workgroup; ends with a barrier. */
+static __device__ void
+opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
+{
+	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
+	AS3 u32 *o0 = OPT_HIST(L);
+	u32 tl, to;
+	(void)block_scan(L, tid < 286 ? L->freq[tid] : 0, &tl);
+	(void)block_scan(L, tid >= 288 && tid < 318 ? L->freq[tid] : 0, &to);
+	const float lgl = __log2f((float)tl + 1.0f), lgo = __log2f((float)to + 1.0f);
+	u32 est = 0, lsl = 0, lxb = 0, lxv = 0;
+	if (tid < 256) {
+		u32 f = L->freq[tid], c = opt_price(f, lgl, 14.0f);
+		lit[tid] = (u16)c;
+		est = f * c;
+	} else if (tid < 512) {
+		u32 l = tid - 253;	/* 3..258 */
+		length_code(l, &lsl, &lxb, &lxv);
+		u32 f = L->freq[257 + lsl], c = opt_price(f, lgl, 14.0f) + 16 * lxb;
+		len[l] = (u16)c;
+		if (lxv == 0)
+			est = f * c;
+	} else if (tid < 542) {
+		u32 sl = tid - 512, xb = sl < 4 ? 0 : (sl >> 1) - 1;
+		u32 f = L->freq[288 + sl], c = opt_price(f, lgo, 12.0f) + 16 * xb;
+		off[sl] = (u16)c;
+		est = f * c;
+	}
+	if (try_flat) {
+		u32 el, e0;
+		(void)block_scan(L, est, &el);
+		for (u32 i = tid; i < 256; i += NT)
+			o0[i] = 0;
+		__syncthreads();
+		for (u32 i = tid; i < tn; i += NT)
+			atomicAdd((u32 *)&o0[L->in[(t + i) & RMASK]], 1u);
+		__syncthreads();
+		u32 cf = 0, e = 0;
+		if (tid < 256) {
+			u32 f = o0[tid];
+			cf = opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
+			e = f * cf;
+		}
+		(void)block_scan(L, e, &e0);
+		if (e0 < el) {
+			if (tid < 256)
+				lit[tid] = (u16)cf;
+			else if (tid < 512)
+				len[tid - 253] = (u16)(16 * (7 + lxb));
+			else if (tid < 542) {
+				u32 sl = tid - 512;
+				off[sl] = (u16)(16 * (5 + (sl < 4 ? 0 : (sl >> 1) - 1)));
+			}
+		}
+	}
+	__syncthreads();
+}
+
+/* minimum over the wave, wave-uniform */
+static __device__ __forceinline__ u32 wave_min_u32(u32 v)
+{
+	u32 o;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x111, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x112, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x114, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x118, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x142, 0xA, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x143, 0xC, 0xF, false);
+	v = o < v ? o : v;
+	return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+/*
+ * One wave's part of the min-cost parse: chosen length (1 = literal) for the
+ * tile-relative positions [lo, hi) into ch16[position + 4]; positions up to
+ * 'e' are parsed as warm-up.  The cost-to-go lives in w[k] (lane j of w[k] =
+ * position + 1 + j + 64 k), packed as cost << 9 so that adding the packed
+ * length price (price << 9 | length) and taking the minimum yields the cost
+ * and the length together.
+ */
+static __device__ void
+opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo, s32 hi, s32 e, u32 lane)
+{
+	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
+	u32 lcp[5], w[5];
+#pragma unroll
+	for (u32 k = 0; k < 5; k++) {
+		u32 l = 1 + lane + 64 * k;
+		lcp[k] = l >= 3 && l <= 258 ? ((u32)len[l] << 9) | l : OPT_BIG;
+		w[k] = 0;
+	}
+	const u32 nsteps = (u32)(e - lo);
+	u32 pk = 0, ch = 0;
+	for (u32 step = 0; step < nsteps; step++) {
+		const u32 sl = step & 63;
+		const s32 p = e - 1 - (s32)step;
+		if (sl == 0) {
+			if (step) {	/* choices of the 64 positions above p */
+				s32 pj = p + 64 - (s32)lane;
+				if (pj >= lo && pj < hi)
+					ch16[pj + 4] = (u16)ch;
+			}
+			s32 pj = p - (s32)lane;
+			pk = 0;
+			if (pj >= lo) {
+				u32 m = L->M[pj + 4], lm = m & 0xFFFF, oc = 0;
+				if (lm >= 3) {
+					u32 ds, xb, xv;
+					dist_code(m >> 16, &ds, &xb, &xv);
+					oc = off[ds];
+				} else {
+					lm = 0;
+				}
+				u32 lc = lit[L->in[(t + (u32)pj) & RMASK]];
+				pk = lm | (oc << 9) | (lc << 18);
+			}
+		}
+		const u32 q = (u32)__builtin_amdgcn_readlane((int)pk, sl);
+		const u32 lm = q & 511, oc = (q >> 9) & 511, lc = q >> 18;
+		u32 best = (u32)__builtin_amdgcn_readfirstlane((int)w[0]) + (lc << 9) + 1;
+		if (lm >= 3) {
+			u32 cand = lane < lm ? w[0] + lcp[0] : OPT_BIG;
+			if (lm > 64) {
+				/* rare; the asm statement keeps this a branch instead of
+				 * 30 predicated instructions on every step */
+				asm volatile("; long match");
+#pragma unroll
+				for (u32 k = 1; k < 5; k++) {
+					u32 c = lane + 64 * k < lm ? w[k] + lcp[k] : OPT_BIG;
+					cand = c < cand ? c : cand;
+				}
+			}
+			u32 mn = wave_min_u32(cand) + (oc << 9);
+			best = mn < best ? mn : best;
+		}
+		ch = lane == sl ? best & 511 : ch;
+		/* slide: every cost moves one lane up, lane 63 of w[k] into lane 0
+		 * of w[k + 1], the new cost into lane 0 of w[0] */
+		const u32 nc = best & ~511u;
+		u32 r[5];
+#pragma unroll
+		for (u32 k = 0; k < 5; k++)	/* wave_ror:1; every lane has a source, 'old' is unused */
+			r[k] = __builtin_amdgcn_update_dpp(w[k], w[k], 0x13C, 0xF, 0xF, false);
+#pragma unroll
+		for (u32 k = 4; k >= 1; k--)
+			w[k] = lane == 0 ? r[k - 1] : r[k];
+		w[0] = lane == 0 ? nc : r[0];
+	}
+	if (nsteps) {	/* the last, possibly partial, group of 64 */
+		const u32 done = ((nsteps - 1) & 63) + 1;	/* steps in it */
+		s32 pbase = lo + (s32)done - 1;			/* its first (highest) position */
+		s32 pj = pbase - (s32)lane;
+		if (lane < done && pj >= lo && pj < hi)
+			ch16[pj + 4] = (u16)ch;
+	}
 }
 
 /* ---------------- Huffman code construction (wave 0) ---------------- */
@@ -699,28 +905,35 @@ static __device__ __forceinline__ void stg_save(lds_t *L, struct outstate *os)
 
 /* ---------------- the kernel ---------------- */
 
-extern "C" __global__ void __launch_bounds__(NT)
-lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
-			 u32 nice, u32 mode,
-			 const u8 *__restrict__ in_base,
-			 const u64 *__restrict__ in_offsets,
-			 const u64 *__restrict__ in_nbytes,
-			 u8 *__restrict__ out_base,
-			 const u64 *__restrict__ out_offsets,
-			 const u64 *__restrict__ out_avail_arr,
-			 u64 *__restrict__ out_nbytes,
-			 const u32 *__restrict__ sums,
-			 u64 *__restrict__ seq_scratch,
-			 const u32 *__restrict__ seg_info,
-			 u32 *__restrict__ next_chunk)
+/*
+ * The body is compiled twice: OPT = false for levels 0-9 (the min-cost parse
+ * and its re-parse loop compile away, so the lazy levels keep their register
+ * allocation), OPT = true for levels 10-12.
+ */
+template <bool OPT> static __device__ __forceinline__ void
+deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
+		   u32 nice, u32 mode,
+		   const u8 *__restrict__ in_base,
+		   const u64 *__restrict__ in_offsets,
+		   const u64 *__restrict__ in_nbytes,
+		   u8 *__restrict__ out_base,
+		   const u64 *__restrict__ out_offsets,
+		   const u64 *__restrict__ out_avail_arr,
+		   u64 *__restrict__ out_nbytes,
+		   const u32 *__restrict__ sums,
+		   u64 *__restrict__ seq_scratch,
+		   const u32 *__restrict__ seg_info,
+		   u32 *__restrict__ next_chunk)
 {
-	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	lds_t *L = (lds_t *)(uintptr_t)0;
 	const u32 tid = threadIdx.x;
 	if ((u32)(uintptr_t)(__attribute__((address_space(3))) u8 *)lds_raw != 0)
 		__builtin_trap();	/* see LDS32(): the dynamic LDS block must start at 0 */
 	/* block-relative position | length << 32 | distance << 41 */
-	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_GCAP;
+	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_STRIDE;
+	/* levels 10-12: the search results of a block's first tile, kept while
+	 * that tile is parsed more than once */
+	u32 *__restrict__ msave = (u32 *)(seqg + SEQ_GCAP);
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
@@ -1224,6 +1437,49 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 				__syncthreads();
 
 				PROF_MARK(4);
+				/* levels 10-12 (mode 3): min-cost parse, see opt_parse_wave().
+				 * A block's first tile is parsed lazily as a dry run (stage 0),
+				 * rolled back, and parsed again with prices from that run
+				 * (stage 1; level 11 and up once more with the prices of stage
+				 * 1); later tiles take their prices from the block so far. */
+				const bool opt = OPT && mode == 3;
+				const bool opt_first = opt && walkpos == block_start;
+				const u32 opt_last = level >= 11 ? 2 : 1;
+				u32 opt_stage = opt && !opt_first ? 1 : 0;
+				const u32 ent0 = L->vars[V_ENTRY], nseq0 = L->vars[V_NSEQ];
+				if (opt_first) {
+					for (u32 i = tid; i < TILE + 8; i += NT)
+						msave[i] = L->M[i];
+				} else if (opt) {
+					opt_build_costs(L, tid, false, t, tend - t);
+				}
+				for (;;) {
+				/* opaque again: see the top of the tile loop */
+				u32 tid_opaque2 = threadIdx.x;
+				asm volatile("" : "+v"(tid_opaque2));
+				const u32 tid = tid_opaque2, lane = tid & 63, wave = tid >> 6;
+				const u32 s4mode = opt ? (opt_stage ? 0 : 2) : mode;
+				if (opt && opt_stage) {
+					const s32 ent = (s32)ent0;
+					const s32 lim = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
+					const s32 pend = (s32)(tend - t);
+					s32 lo = (s32)(OPT_SEG * wave), hi = lo + OPT_SEG;
+					if (wave == 0 && ent < 0)
+						lo = ent;
+					if (hi > lim)
+						hi = lim;
+					s32 e = hi + OPT_WARM;
+					if (e > pend)
+						e = pend;
+					if (lo < hi)
+						opt_parse_wave(L, L->nxtA, t, lo, hi, e, lane);
+					__syncthreads();
+					for (s32 i = (s32)tid + (ent < 0 ? ent : 0); i < lim; i += NT) {
+						u32 c = L->nxtA[i + 4], m = L->M[i + 4];
+						L->M[i + 4] = c >= 3 ? c | (m & 0xFFFF0000u) : 0;
+					}
+					__syncthreads();
+				}
 				/* ---- S4: token choice by pointer jumping ----
 				 * step(p) is a pure function of M[p..p+2]; the chosen
 				 * tokens are the positions reachable from the entry point
@@ -1255,7 +1511,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						m0[k] = L->M[idx];
 						if ((s32)p < limit)
 							nx = p + token_step(m0[k], L->M[idx + 1],
-									    L->M[idx + 2], mode, nice);
+									    L->M[idx + 2], s4mode, nice);
 						jc[k] = nx + 4;	/* stored as idx */
 						J[idx] = (u16)jc[k];
 					}
@@ -1283,7 +1539,7 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 						if (e < 4 && e < lim_idx) {
 							u32 mm = L->M[e];
 							u32 st = token_step(mm, L->M[e + 1], L->M[e + 2],
-									    mode, nice);
+									    s4mode, nice);
 							u32 l0 = mm & 0xFFFF;
 							bool ism = st == l0 && l0;
 							if (tid == 0) {
@@ -1409,6 +1665,23 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				}
 				__syncthreads();
+				if (!opt_first || opt_stage == opt_last)
+					break;
+				/* prices from this parse, then undo it */
+				opt_build_costs(L, tid, opt_stage == 0, t, tend - t);
+				for (u32 i = tid; i < 320; i += NT)
+					L->freq[i] = 0;
+				for (u32 i = tid; i < TILE + 8; i += NT) {
+					L->mark[i] = 0;
+					L->M[i] = msave[i];
+				}
+				if (tid == 0) {
+					L->vars[V_ENTRY] = ent0;
+					L->vars[V_NSEQ] = nseq0;
+				}
+				__syncthreads();
+				opt_stage++;
+				}
 				walkpos = L->vars[V_WALKPOS_LO];
 				PROF_MARK(5);
 
@@ -2010,6 +2283,34 @@ lda_deflate_batch_kernel(u64 n_chunks, int format, int level, u32 depth,
 }
 
 /* host helper: dynamic LDS size the kernel needs */
+#define DEFLATE_KERNEL_PARAMS                                                  \
+	u64 n_chunks, int format, int level, u32 depth, u32 nice, u32 mode,    \
+	const u8 *__restrict__ in_base, const u64 *__restrict__ in_offsets,    \
+	const u64 *__restrict__ in_nbytes, u8 *__restrict__ out_base,          \
+	const u64 *__restrict__ out_offsets,                                   \
+	const u64 *__restrict__ out_avail_arr, u64 *__restrict__ out_nbytes,   \
+	const u32 *__restrict__ sums, u64 *__restrict__ seq_scratch,           \
+	const u32 *__restrict__ seg_info, u32 *__restrict__ next_chunk
+#define DEFLATE_KERNEL_ARGS                                                    \
+	lds_raw, n_chunks, format, level, depth, nice, mode, in_base,          \
+	in_offsets, in_nbytes, out_base, out_offsets, out_avail_arr,           \
+	out_nbytes, sums, seq_scratch, seg_info, next_chunk
+
+extern "C" __global__ void __launch_bounds__(NT)
+lda_deflate_batch_kernel(DEFLATE_KERNEL_PARAMS)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	deflate_batch_body<false>(DEFLATE_KERNEL_ARGS);
+}
+
+/* levels 10-12 */
+extern "C" __global__ void __launch_bounds__(NT)
+lda_deflate_opt_kernel(DEFLATE_KERNEL_PARAMS)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	deflate_batch_body<true>(DEFLATE_KERNEL_ARGS);
+}
+
 extern "C" size_t lda_deflate_lds_bytes(void)
 {
 	return sizeof(struct deflate_lds);
@@ -2022,7 +2323,7 @@ extern "C" size_t lda_deflate_tile(void)
 
 extern "C" size_t lda_deflate_seq_words(void)
 {
-	return SEQ_GCAP;
+	return SEQ_STRIDE;
 }
 
 LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate)

@@ -25,10 +25,12 @@ using namespace lda;
  * level -> (search depth, nice length, parse mode), the policy table of
  * lib/deflate_compress.c:3927-3979.  Level 1 maps onto the same hash-chain
  * kernel with a 2-deep search (the reference's level 1 probes a 2-way
- * bucket, lib/ht_matchfinder.h:50-55).  Levels 10-12 (near-optimal parsing,
- * SURVEY.md §8(f) "next") currently run the deepest lazy2 search.
+ * bucket, lib/ht_matchfinder.h:50-55).  Levels 10-12 (mode 3) choose the
+ * tokens by a min-cost parse over the chain search's results instead of the
+ * lazy rule (deflate_kernel.hip, "min-cost parse"); the reference's binary
+ * tree match finder (lib/bt_matchfinder.h) has no counterpart.
  */
-struct level_cfg { uint32_t depth, nice, mode; };
+struct level_cfg { uint32_t depth, nice, mode; };	/* mode: 0 greedy, 1 lazy, 2 lazy2, 3 min-cost */
 static const level_cfg k_levels[13] = {
 	{ 0, 0, 0 },		/* 0: stored */
 	{ 2, 32, 0 },		/* 1 */
@@ -40,9 +42,9 @@ static const level_cfg k_levels[13] = {
 	{ 100, 130, 1 },
 	{ 300, 258, 2 },	/* 8: lazy2 */
 	{ 600, 258, 2 },
-	{ 1000, 258, 2 },	/* 10-12: see above */
-	{ 1500, 258, 2 },
-	{ 2000, 258, 2 },
+	{ 600, 258, 3 },	/* 10-12: min-cost parse */
+	{ 1000, 258, 3 },
+	{ 2000, 258, 3 },
 };
 
 extern "C" LIBDEFLATEAPI struct libdeflate_compressor *
@@ -162,10 +164,15 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 				(const void *)lda_deflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)lds), LIBDEFLATE_AMD_NO_DEVICE);
+		LDA_HIP_TRY(hipFuncSetAttribute(
+				(const void *)lda_deflate_opt_kernel,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)lds), LIBDEFLATE_AMD_NO_DEVICE);
 		attr_set[ctx->device] = true;
 	}
 	const level_cfg &lv = k_levels[c->level];
-	hipLaunchKernelGGL(lda_deflate_batch_kernel, dim3((unsigned)grid),
+	hipLaunchKernelGGL(lv.mode == 3 ? lda_deflate_opt_kernel :
+					  lda_deflate_batch_kernel, dim3((unsigned)grid),
 			   dim3(LDA_DEFLATE_THREADS), lds, st, (uint64_t)n, format, c->level,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,

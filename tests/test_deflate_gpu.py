@@ -27,7 +27,7 @@ def _check_roundtrip(oracle, fmt, data, comp, tag):
     assert zlib.decompress(comp, WBITS[fmt]) == data, (tag, "zlib control")
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 4, 5, 6, 8, 9, 12])
+@pytest.mark.parametrize("level", [0, 1, 2, 4, 5, 6, 8, 9, 10, 11, 12])
 def test_roundtrip_sizes_formats(level, oracle):
     from libdeflate_amd import api
     c = api.Compressor(level)
@@ -92,10 +92,11 @@ def test_ratio_tracks_reference(oracle):
     from tests import oracle_util
     ref = oracle_util.load_ref()
     chunks = [datagen.chunk(i, 65536, 0x0E110003) for i in range(16)]
-    for lvl in (1, 6, 9):
+    sizes = {}
+    for lvl in (1, 6, 9, 10, 12):
         c = api.Compressor(lvl)
         comps = c.compress_batch_host("deflate", chunks)
-        ours = sum(len(z) for z in comps)
+        ours = sizes[lvl] = sum(len(z) for z in comps)
         for d, z in zip(chunks, comps):
             _check_roundtrip(oracle, "deflate", d, z, lvl)
         if ref:
@@ -105,6 +106,8 @@ def test_ratio_tracks_reference(oracle):
         print(f"level {lvl}: ours {ours} ref {theirs} ratio {ours/theirs:.4f}")
         assert ours <= theirs * 1.03
         c.close()
+    # the min-cost parse of levels 10-12 must pay for itself
+    assert sizes[10] < sizes[9] and sizes[12] <= sizes[10]
 
 
 def test_device_batch_roundtrip(oracle):
