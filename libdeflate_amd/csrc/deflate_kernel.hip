@@ -385,16 +385,16 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
  *     cheaper than that parse, literal prices come from the byte statistics
  *     and match prices from flat defaults (the role of the reference's
  *     default-cost tables, :2986-3102);
- *   - the DP runs per wave over 256 positions plus 128 positions of warm-up
- *     beyond them (a min-cost parse forgets its start within a few tokens,
- *     like a Huffman parse re-synchronises), backwards, with the cost-to-go
- *     of the next 320 positions held in five registers per lane that rotate
- *     by one lane per step: no memory traffic inside the recurrence;
+ *   - the DP runs backwards, per wave over 256 positions plus 64 positions
+ *     of warm-up beyond them (a min-cost parse forgets where it started
+ *     within a few tokens, like a Huffman parse re-synchronises), with the
+ *     cost-to-go of the positions ahead held in registers: no memory traffic
+ *     inside the recurrence (opt_parse_wave());
  *   - the chosen lengths replace the match lengths in M[], and the ordinary
  *     token walk (S4, greedy rule) follows them.
  */
 #define OPT_SEG 256
-#define OPT_WARM 128
+#define OPT_WARM 64
 #define OPT_BIG 0x40000000u
 /* price tables (u16, 1/16 bit) and the byte histogram live in the block-end
  * scratch, which is dead until S4 uses nxtB */
@@ -489,38 +489,63 @@ static __device__ __forceinline__ u32 wave_min_u32(u32 v)
 	return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+/* minimum over lanes 0..15, wave-uniform */
+static __device__ __forceinline__ u32 row0_min_u32(u32 v)
+{
+	u32 o;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x111, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x112, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x114, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x118, 0xF, 0xF, false);
+	v = o < v ? o : v;
+	return (u32)__builtin_amdgcn_readlane((int)v, 15);
+}
+
 /*
  * One wave's part of the min-cost parse: chosen length (1 = literal) for the
  * tile-relative positions [lo, hi) into ch16[position + 4]; positions up to
- * 'e' are parsed as warm-up.  The cost-to-go lives in w[k] (lane j of w[k] =
- * position + 1 + j + 64 k), packed as cost << 9 so that adding the packed
- * length price (price << 9 | length) and taking the minimum yields the cost
- * and the length together.
+ * 'e' are parsed as warm-up.  Backwards, one position p per step.  The stage
+ * is bound by VALU issue (16 waves x 4 cycles per instruction), so the step
+ * is built to need few vector instructions:
+ *   - c(p) = min(c(p+1) + literal, best match candidate) runs on the scalar
+ *     unit; the costs are packed as cost << 9 so that adding the packed
+ *     length price (price << 9 | length) and taking the minimum yields the
+ *     cost and the length together;
+ *   - the costs of the 64 positions p+3.. sit in w0 (lane j = position
+ *     p + 3 + j): the candidates of a match of up to 66 bytes are one add,
+ *     one select and a DPP reduction (over one row of 16 lanes when the
+ *     match is no longer than 18); w0 slides by one lane per step, and
+ *     c(p+2) enters at lane 0;
+ *   - longer matches are rare: the costs further ahead are kept as
+ *     snapshots of w0 taken every 64 steps (ws1..ws4; at step s of a group
+ *     lane j of ws_k is length s + 3 + j + 64 (k - 1)) and looked at only
+ *     then, with the length prices read from LDS.
  */
 static __device__ void
-opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo, s32 hi, s32 e, u32 lane)
+opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo_, s32 hi_, s32 e_, u32 lane)
 {
 	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
-	u32 lcp[5], w[5];
-#pragma unroll
-	for (u32 k = 0; k < 5; k++) {
-		u32 l = 1 + lane + 64 * k;
-		lcp[k] = l >= 3 && l <= 258 ? ((u32)len[l] << 9) | l : OPT_BIG;
-		w[k] = 0;
-	}
+	/* wave-uniform by construction; tell the compiler, or the step loop
+	 * is compiled as a divergent one */
+	const s32 lo = __builtin_amdgcn_readfirstlane(lo_);
+	const s32 hi = __builtin_amdgcn_readfirstlane(hi_);
+	const s32 e = __builtin_amdgcn_readfirstlane(e_);
+	const u32 lcp0 = ((u32)len[3 + lane] << 9) | (3 + lane);
+	const bool lane0 = lane == 0;
+	u32 w0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0;
 	const u32 nsteps = (u32)(e - lo);
-	u32 pk = 0, ch = 0;
-	for (u32 step = 0; step < nsteps; step++) {
-		const u32 sl = step & 63;
-		const s32 p = e - 1 - (s32)step;
-		if (sl == 0) {
-			if (step) {	/* choices of the 64 positions above p */
-				s32 pj = p + 64 - (s32)lane;
-				if (pj >= lo && pj < hi)
-					ch16[pj + 4] = (u16)ch;
-			}
-			s32 pj = p - (s32)lane;
-			pk = 0;
+	u32 ch = 0, c1 = 0, c2 = 0;	/* c1 = c(p+1), c2 = c(p+2) */
+	/* groups of 64 steps: position data in, snapshots rotated, choices out */
+	for (u32 g0 = 0; g0 < nsteps; g0 += 64) {
+		const u32 cnt = (u32)__builtin_amdgcn_readfirstlane(
+			(int)(nsteps - g0 < 64 ? nsteps - g0 : 64));
+		const s32 ptop = e - 1 - (s32)g0;	/* lane j = position ptop - j */
+		u32 pk = 0;
+		{
+			s32 pj = ptop - (s32)lane;
 			if (pj >= lo) {
 				u32 m = L->M[pj + 4], lm = m & 0xFFFF, oc = 0;
 				if (lm >= 3) {
@@ -534,43 +559,61 @@ opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo, s32 hi, s32 e, u32 lane)
 				pk = lm | (oc << 9) | (lc << 18);
 			}
 		}
-		const u32 q = (u32)__builtin_amdgcn_readlane((int)pk, sl);
-		const u32 lm = q & 511, oc = (q >> 9) & 511, lc = q >> 18;
-		u32 best = (u32)__builtin_amdgcn_readfirstlane((int)w[0]) + (lc << 9) + 1;
-		if (lm >= 3) {
-			u32 cand = lane < lm ? w[0] + lcp[0] : OPT_BIG;
-			if (lm > 64) {
-				/* rare; the asm statement keeps this a branch instead of
-				 * 30 predicated instructions on every step */
-				asm volatile("; long match");
-#pragma unroll
-				for (u32 k = 1; k < 5; k++) {
-					u32 c = lane + 64 * k < lm ? w[k] + lcp[k] : OPT_BIG;
-					cand = c < cand ? c : cand;
+		ws4 = ws3;
+		ws3 = ws2;
+		ws2 = ws1;
+		ws1 = w0;
+		for (u32 sl = 0; sl < cnt; sl++) {
+			const u32 q = (u32)__builtin_amdgcn_readlane((int)pk, sl);
+			const u32 lm = q & 511, oc = (q >> 9) & 511, lc = q >> 18;
+			u32 best = c1 + (lc << 9) + 1;
+			if (lm >= 3) {
+				u32 cand = lane + 3 <= lm ? w0 + lcp0 : OPT_BIG;
+				u32 mn;
+				if (lm <= 18) {
+					mn = row0_min_u32(cand);
+				} else {
+					if (lm > 66) {
+						/* the asm statement keeps this a branch instead
+						 * of predicated instructions on every step */
+						u32 ln = lane;	/* opaque: no address induction
+								 * variable in the common path */
+						asm volatile("; long match" : "+v"(ln));
+						const u32 l1 = sl + 3 + ln;
+						u32 x1 = l1 <= lm ? ws1 + (((u32)len[l1] << 9) | l1) : OPT_BIG;
+						u32 x2 = l1 + 64 <= lm ? ws2 + (((u32)len[l1 + 64] << 9) | (l1 + 64)) : OPT_BIG;
+						u32 x3 = l1 + 128 <= lm ? ws3 + (((u32)len[l1 + 128] << 9) | (l1 + 128)) : OPT_BIG;
+						u32 l4 = l1 + 192 <= 258 ? l1 + 192 : 258;
+						u32 x4 = l1 + 192 <= lm ? ws4 + (((u32)len[l4] << 9) | l4) : OPT_BIG;
+						x1 = x2 < x1 ? x2 : x1;
+						x3 = x4 < x3 ? x4 : x3;
+						cand = x1 < cand ? x1 : cand;
+						cand = x3 < cand ? x3 : cand;
+					}
+					mn = wave_min_u32(cand);
 				}
+				mn += oc << 9;
+				best = mn < best ? mn : best;
 			}
-			u32 mn = wave_min_u32(cand) + (oc << 9);
-			best = mn < best ? mn : best;
+			{	/* ch[lane sl] = chosen length (lane select through m0: one
+				 * SGPR operand per VALU instruction); the s_nop covers the
+				 * lane-select hazard the compiler cannot see in the asm */
+				const u32 cl = best & 511;
+				asm("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0"
+				    : "+v"(ch) : "s"(cl), "s"(sl) : "m0");
+			}
+			/* slide: every cost moves one lane up, c(p+2) enters at lane 0
+			 * (wave_ror:1; every lane has a source, 'old' is unused) */
+			const u32 r0 = __builtin_amdgcn_update_dpp(w0, w0, 0x13C, 0xF, 0xF, false);
+			w0 = lane0 ? c2 : r0;
+			c2 = c1;
+			c1 = best & ~511u;
 		}
-		ch = lane == sl ? best & 511 : ch;
-		/* slide: every cost moves one lane up, lane 63 of w[k] into lane 0
-		 * of w[k + 1], the new cost into lane 0 of w[0] */
-		const u32 nc = best & ~511u;
-		u32 r[5];
-#pragma unroll
-		for (u32 k = 0; k < 5; k++)	/* wave_ror:1; every lane has a source, 'old' is unused */
-			r[k] = __builtin_amdgcn_update_dpp(w[k], w[k], 0x13C, 0xF, 0xF, false);
-#pragma unroll
-		for (u32 k = 4; k >= 1; k--)
-			w[k] = lane == 0 ? r[k - 1] : r[k];
-		w[0] = lane == 0 ? nc : r[0];
-	}
-	if (nsteps) {	/* the last, possibly partial, group of 64 */
-		const u32 done = ((nsteps - 1) & 63) + 1;	/* steps in it */
-		s32 pbase = lo + (s32)done - 1;			/* its first (highest) position */
-		s32 pj = pbase - (s32)lane;
-		if (lane < done && pj >= lo && pj < hi)
-			ch16[pj + 4] = (u16)ch;
+		{
+			s32 pj = ptop - (s32)lane;
+			if (lane < cnt && pj < hi)	/* pj >= lo: lane < cnt */
+				ch16[pj + 4] = (u16)ch;
+		}
 	}
 }
 
