@@ -412,8 +412,12 @@ static __device__ __forceinline__ u32 opt_price(u32 f, float lg_total, float max
 
 /* Prices from freq[]; with try_flat (freq[] = lazy parse of this tile alone)
  * the literal-only estimate decides between them and the flat start.
+ * Without try_flat (freq[] = the block so far) the return value tells whether
+ * the block's literal statistics fit this tile's bytes at all: a tile of
+ * different content (it will end the block) is better parsed by the lazy
+ * rule than with prices that describe other data.
  * Whole workgroup; ends with a barrier. */
-static __device__ void
+static __device__ bool
 opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
 {
 	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
@@ -466,8 +470,29 @@ opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
 				off[sl] = (u16)(16 * (5 + (sl < 4 ? 0 : (sl >> 1) - 1)));
 			}
 		}
+		__syncthreads();
+		return true;
 	}
+	/* fit: the tile's bytes priced as literals of this block vs by their own
+	 * statistics (both without the share of the matches) */
+	u32 tlit, e_blk, e_own;
+	(void)block_scan(L, tid < 256 ? L->freq[tid] : 0, &tlit);
+	for (u32 i = tid; i < 256; i += NT)
+		o0[i] = 0;
 	__syncthreads();
+	for (u32 i = tid; i < tn; i += NT)
+		atomicAdd((u32 *)&o0[L->in[(t + i) & RMASK]], 1u);
+	__syncthreads();
+	u32 eb = 0, eo = 0;
+	if (tid < 256) {
+		u32 f = o0[tid];
+		eb = f * opt_price(L->freq[tid], __log2f((float)tlit + 1.0f), 14.0f);
+		eo = f * opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
+	}
+	(void)block_scan(L, eb, &e_blk);
+	(void)block_scan(L, eo, &e_own);
+	__syncthreads();
+	return 4 * e_blk <= 7 * e_own;
 }
 
 /* minimum over the wave, wave-uniform */
@@ -1488,13 +1513,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				const bool opt = OPT && mode == 3;
 				const bool opt_first = opt && walkpos == block_start;
 				const u32 opt_last = level >= 11 ? 2 : 1;
-				u32 opt_stage = opt && !opt_first ? 1 : 0;
+				u32 opt_stage = 0;
 				const u32 ent0 = L->vars[V_ENTRY], nseq0 = L->vars[V_NSEQ];
 				if (opt_first) {
 					for (u32 i = tid; i < TILE + 8; i += NT)
 						msave[i] = L->M[i];
 				} else if (opt) {
-					opt_build_costs(L, tid, false, t, tend - t);
+					/* a tile the block's statistics do not describe keeps
+					 * the lazy parse (stage 0, final) */
+					opt_stage = opt_build_costs(L, tid, false, t, tend - t) ? 1 : 0;
 				}
 				for (;;) {
 				/* opaque again: see the top of the tile loop */
