@@ -748,16 +748,17 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		/* depth of every internal node by pointer jumping (root = m-2) */
 		{
 			const u32 root = m - 2;
-			u32 dd[5], hh[5];
+			enum { NJ = (N + 63) / 64 };	/* internal nodes per lane */
+			u32 dd[NJ], hh[NJ];
 #pragma unroll
-			for (u32 j = 0; j < 5; j++) {
+			for (u32 j = 0; j < NJ; j++) {
 				u32 k = lane + 64 * j;
 				dd[j] = (k < root) ? 1 : 0;
 				hh[j] = (k < root) ? H->P[k] : root;
 			}
 			wave_sync();
 #pragma unroll
-			for (u32 j = 0; j < 5; j++) {
+			for (u32 j = 0; j < NJ; j++) {
 				u32 k = lane + 64 * j;
 				if (k <= root) {
 					H->NW[k] = dd[j];
@@ -767,7 +768,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			wave_sync();
 			for (u32 r = 0; r < 6; r++) {	/* depth < 64 */
 #pragma unroll
-				for (u32 j = 0; j < 5; j++) {
+				for (u32 j = 0; j < NJ; j++) {
 					u32 k = lane + 64 * j;
 					if (k <= root) {
 						u32 h = H->A[k];
@@ -777,7 +778,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 				}
 				wave_sync();
 #pragma unroll
-				for (u32 j = 0; j < 5; j++) {
+				for (u32 j = 0; j < NJ; j++) {
 					u32 k = lane + 64 * j;
 					if (k <= root) {
 						H->NW[k] = dd[j];
@@ -787,7 +788,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 				wave_sync();
 			}
 #pragma unroll
-			for (u32 j = 0; j < 5; j++) {
+			for (u32 j = 0; j < NJ; j++) {
 				u32 k = lane + 64 * j;
 				if (k <= root)
 					atomicAdd((u32 *)&H->cntI[dd[j] < 39 ? dd[j] : 39], 1u);

@@ -42,6 +42,54 @@ def test_roundtrip_sizes_formats(level, oracle):
     c.close()
 
 
+def _weird_chunk(rng, n):
+    """Inputs built to stress the parsers: periodic data with long matches,
+    matches that straddle tile (4096) and block ends, switches of content."""
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        return bytes(n)
+    if kind == 1:       # short period: every match 258 long at tiny distances
+        per = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+        return (per * (n // len(per) + 1))[:n]
+    if kind == 2:       # long period just inside / outside the window
+        per = bytes(rng.integers(0, 256, int(rng.choice([4090, 4096, 4100, 28000, 33000])), dtype=np.uint8))
+        return (per * (n // len(per) + 1))[:n]
+    if kind == 3:       # text with random bytes sprinkled in
+        d = bytearray(datagen.text_chunk(n, int(rng.integers(1 << 30))))
+        for i in rng.integers(0, max(n, 1), n // 50):
+            d[i] = int(rng.integers(0, 256))
+        return bytes(d)
+    if kind == 4:       # pieces of different content, cut at odd places
+        out = bytearray()
+        while len(out) < n:
+            k = int(rng.integers(0, 8))
+            out += datagen.chunk(k, int(rng.integers(1, 20000)), int(rng.integers(1 << 30)))
+        return bytes(out[:n])
+    if kind == 5:       # few symbols
+        return bytes(rng.integers(0, 3, n, dtype=np.uint8) + 65)
+    return datagen.chunk(int(rng.integers(0, 8)), n, int(rng.integers(1 << 30)))
+
+
+@pytest.mark.parametrize("level", list(range(13)))
+def test_random_sweep(level, oracle):
+    """Seeded sweep over sizes around the tile / block / segment limits and
+    contents that stress every parser (levels 10-12: the min-cost parse and
+    its re-parse of a block's first tile)."""
+    from libdeflate_amd import api
+    rng = np.random.default_rng(0x0E110060 + level)
+    edges = [4094, 4095, 4096, 4097, 4098, 8190, 8194, 12288, 65534, 65538, 69632, 131071]
+    sizes = [int(rng.choice(edges)) + int(rng.integers(-2, 3)) for _ in range(10)]
+    sizes += [int(rng.integers(0, 150000)) for _ in range(14)]
+    chunks = [_weird_chunk(rng, n) for n in sizes]
+    fmt = ("deflate", "zlib", "gzip")[level % 3]
+    c = api.Compressor(level)
+    comps = c.compress_batch_host(fmt, chunks)
+    for d, z in zip(chunks, comps):
+        _check_roundtrip(oracle, fmt, d, z, (level, fmt, len(d)))
+        assert len(z) <= c.bound(fmt, len(d))
+    c.close()
+
+
 def test_single_buffer_api_and_overflow(oracle):
     from libdeflate_amd import api
     c = api.Compressor(6)
