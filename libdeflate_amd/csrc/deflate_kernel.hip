@@ -79,7 +79,7 @@
 #define MAX_BLOCK_LEN 65536u
 #define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
-#define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
+#define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256)	/* u64 words of HBM scratch per workgroup */
 #define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
@@ -124,7 +124,7 @@ struct deflate_lds {
 	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 obs[1][10];		/* block-split observations of the block before this tile */
-	u32 vars[16];
+	u32 vars[20];
 };
 
 /* LDS-resident: every pointer into the block carries the address space, and
@@ -144,7 +144,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
 	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY,
-	V_SPLIT
+	V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT
 };
 
 struct level_params {
@@ -396,6 +396,10 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 #define OPT_SEG 256
 #define OPT_WARM 64
 #define OPT_BIG 0x40000000u
+#ifndef OPT_FIT_NUM
+#define OPT_FIT_NUM 7u	/* the block's literal statistics "fit" a tile up to 7/4 of */
+#define OPT_FIT_DEN 4u	/* the tile's own literal-only estimate */
+#endif
 /* price tables (u16, 1/16 bit) and the byte histogram live in the block-end
  * scratch, which is dead until S4 uses nxtB */
 #define OPT_LIT(L) ((AS3 u16 *)(L)->sorted)	/* [256] by literal */
@@ -413,13 +417,17 @@ static __device__ __forceinline__ u32 opt_price(u32 f, float lg_total, float max
 /* Prices from freq[]; with try_flat (freq[] = lazy parse of this tile alone)
  * the literal-only estimate decides between them and the flat start.
  * Without try_flat (freq[] = the block so far) the return value tells whether
- * the block's literal statistics fit this tile's bytes at all: a tile of
- * different content (it will end the block) is better parsed by the lazy
- * rule than with prices that describe other data.
+ * the block's literal statistics fit this tile's bytes at all: 0 = they do;
+ * 1 = poorly: the tile is better parsed by the lazy rule than with prices
+ * that describe other data; 2 = not at all: the content has changed, the
+ * block should end here whatever the observation classes of the split
+ * heuristic say (they cannot tell a 16-letter alphabet from text once both
+ * are mostly literals).
  * Whole workgroup; ends with a barrier. */
-static __device__ bool
-opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
+static __device__ u32
+opt_build_costs(lds_t *L, u32 tid, bool try_flat, bool check_fit, u32 t, u32 tn, u32 *bsave)
 {
+	u32 *osave = bsave + 256;
 	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
 	AS3 u32 *o0 = OPT_HIST(L);
 	u32 tl, to;
@@ -458,6 +466,8 @@ opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
 			u32 f = o0[tid];
 			cf = opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
 			e = f * cf;
+			bsave[tid] = 0;	/* the block's bytes start with this tile */
+			osave[tid] = f;
 		}
 		(void)block_scan(L, e, &e0);
 		if (e0 < el) {
@@ -471,7 +481,11 @@ opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
 			}
 		}
 		__syncthreads();
-		return true;
+		return 0;
+	}
+	if (!check_fit) {	/* prices only (second pass over a first tile) */
+		__syncthreads();
+		return 0;
 	}
 	/* fit: the tile's bytes priced as literals of this block vs by their own
 	 * statistics (both without the share of the matches) */
@@ -483,16 +497,36 @@ opt_build_costs(lds_t *L, u32 tid, bool try_flat, u32 t, u32 tn)
 	for (u32 i = tid; i < tn; i += NT)
 		atomicAdd((u32 *)&o0[L->in[(t + i) & RMASK]], 1u);
 	__syncthreads();
-	u32 eb = 0, eo = 0;
+	u32 eb = 0, eo = 0, bb = 0, tb, tv2;
 	if (tid < 256) {
 		u32 f = o0[tid];
 		eb = f * opt_price(L->freq[tid], __log2f((float)tlit + 1.0f), 14.0f);
 		eo = f * opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
+		/* bytes of the block so far (the previous tile joins them now) */
+		bb = bsave[tid] + osave[tid];
+		bsave[tid] = bb;
+		osave[tid] = f;
 	}
 	(void)block_scan(L, eb, &e_blk);
 	(void)block_scan(L, eo, &e_own);
+	/* total variation between the byte distributions of this tile and of
+	 * the block: homogeneous data stays below 0.5 (drifting binary counters
+	 * reach it), a change of content is 0.7 and up */
+	(void)block_scan(L, bb, &tb);
+	u32 dv = 0;
+	if (tid < 256 && tb) {
+		float d = (float)o0[tid] / (float)tn - (float)bb / (float)tb;
+		dv = (u32)(fabsf(d) * 65536.0f);
+	}
+	(void)block_scan(L, dv, &tv2);	/* 2 TV in 1/65536 */
 	__syncthreads();
-	return 4 * e_blk <= 7 * e_own;
+	if (tv2 > (u32)(2 * 0.6f * 65536.0f))
+		return 2;
+#ifdef LDA_DEBUG_SPLIT
+	if (tid == 0)
+		L->vars[V_TMP3] = 100 * e_blk / (e_own ? e_own : 1);
+#endif
+	return OPT_FIT_DEN * e_blk <= OPT_FIT_NUM * e_own ? 0 : 2 * e_blk <= 5 * e_own ? 1 : 2;
 }
 
 /* minimum over the wave, wave-uniform */
@@ -972,6 +1006,18 @@ static __device__ __forceinline__ void stg_save(lds_t *L, struct outstate *os)
 	__syncthreads();
 }
 
+#ifdef LDA_DEBUG_SPLIT	/* per-tile trace of the block-split inputs of buffer 0 (debug builds) */
+static __device__ u32 lda_dbg[2048];
+extern "C" __attribute__((visibility("default"))) void libdeflate_amd_debug_read(u32 *out)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lda_dbg), sizeof(lda_dbg));
+}
+#define DBG(tile, k, v) do { if ((tile) < 250) lda_dbg[8 * (tile) + (k)] = (v); } while (0)
+#else
+#define DBG(tile, k, v) do { } while (0)
+#endif
+
 /* ---------------- the kernel ---------------- */
 
 /*
@@ -1003,6 +1049,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	/* levels 10-12: the search results of a block's first tile, kept while
 	 * that tile is parsed more than once */
 	u32 *__restrict__ msave = (u32 *)(seqg + SEQ_GCAP);
+	/* the block histogram before the current tile [320] and the tile's own
+	 * share [320], for a block that ends in front of the tile */
+	u32 *__restrict__ fsave = msave + TILE + 8;
+	/* levels 10-12: byte histogram of the block before the previous tile
+	 * [256] and of the previous tile [256] */
+	u32 *__restrict__ bsave = fsave + 640;
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
@@ -1506,6 +1558,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				__syncthreads();
 
 				PROF_MARK(4);
+				/* the block as it is before this tile's tokens: if the tile
+				 * turns out to be of different content, the block ends in
+				 * front of it (see "block end?") */
+				if (tid < 320)
+					fsave[tid] = L->freq[tid];
+				if (tid == 0) {
+					L->vars[V_NSEQ_PRE] = L->vars[V_NSEQ];
+					L->vars[V_WPOS_PRE] = walkpos;
+				}
 				/* levels 10-12 (mode 3): min-cost parse, see opt_parse_wave().
 				 * A block's first tile is parsed lazily as a dry run (stage 0),
 				 * rolled back, and parsed again with prices from that run
@@ -1519,10 +1580,20 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (opt_first) {
 					for (u32 i = tid; i < TILE + 8; i += NT)
 						msave[i] = L->M[i];
+					if (tid == 0)
+						L->vars[V_FIT] = 0;
 				} else if (opt) {
 					/* a tile the block's statistics do not describe keeps
 					 * the lazy parse (stage 0, final) */
-					opt_stage = opt_build_costs(L, tid, false, t, tend - t) ? 1 : 0;
+					const u32 fit = opt_build_costs(L, tid, false, true, t, tend - t, bsave);
+					opt_stage = fit ? 0 : 1;
+					if (tid == 0) {
+						L->vars[V_FIT] = fit;
+						if (c == 0) {
+							DBG(tile, 6, 100 + fit);
+							DBG(tile, 7, L->vars[V_TMP3]);
+						}
+					}
 				}
 				for (;;) {
 				/* opaque again: see the top of the tile loop */
@@ -1739,7 +1810,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (!opt_first || opt_stage == opt_last)
 					break;
 				/* prices from this parse, then undo it */
-				opt_build_costs(L, tid, opt_stage == 0, t, tend - t);
+				opt_build_costs(L, tid, opt_stage == 0, false, t, tend - t, bsave);
 				for (u32 i = tid; i < 320; i += NT)
 					L->freq[i] = 0;
 				for (u32 i = tid; i < TILE + 8; i += NT) {
@@ -1794,13 +1865,27 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					 * the minimum length of :2204 are never cut */
 					bool sp = nprev && walkpos - block_start >= 5000 &&
 						  delta >= (u64)nnew * 200 / 512 * nprev;
+					if (OPT && mode == 3 && L->vars[V_FIT] == 2 &&
+					    walkpos - block_start >= 5000)
+						sp = true;	/* see opt_build_costs() */
 					wave_sync();
 #pragma unroll
 					for (u32 i = 0; i < 10; i++)
 						if (lane == i)
 							L->obs[0][i] = sp ? 0 : onow[i];
+					/* 2: the part before this tile is a block of its own
+					 * (>= the minimum block length of :2204) */
 					if (lane == 0)
-						L->vars[V_SPLIT] = sp;
+						L->vars[V_SPLIT] = !sp ? 0 :
+							L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
+					if (lane == 0 && c == 0) {
+						DBG(tile, 0, nprev);
+						DBG(tile, 1, nnew);
+						DBG(tile, 2, (u32)(delta / (nprev ? nprev : 1)));
+						DBG(tile, 3, sp);
+						DBG(tile, 4, walkpos - block_start);
+						DBG(tile, 5, onow[8] + onow[9]);
+					}
 				}
 			} else {
 				if (prime)
@@ -1817,12 +1902,14 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * not shorter than 9), and a split when the distribution of the
 			 * new observations is far from the block's.  Here the classes
 			 * are sums over the block histogram, "new" is what this tile
-			 * added, and the decision is taken per tile: a tile that differs
-			 * ends the block AFTER itself (its state is gone once the block
-			 * is written), so one tile per change of content is coded with
-			 * the old block - the next block starts clean. */
-			const bool split = !stored_only && !last_tile && L->vars[V_SPLIT];
-			bool end_block = last_tile || split ||
+			 * added, and the decision is taken per tile.  A tile that differs
+			 * ends the block IN FRONT of itself: the block is written from
+			 * the histogram and the match count saved before the tile, and
+			 * the tile's tokens (already in the match list) become the start
+			 * of the next block.  Only when that would leave a block shorter
+			 * than the minimum, the block ends after the tile. */
+			const u32 splitv = !stored_only && !last_tile ? L->vars[V_SPLIT] : 0;
+			bool end_block = last_tile || splitv ||
 				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_GCAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
@@ -1830,10 +1917,21 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			if (tid < 10)
 				L->obs[0][tid] = 0;
 
-			const u32 bstart = block_start, bend = last_tile ? n : walkpos;
+			const bool retro = splitv == 2;
+			const u32 bstart = block_start;
+			const u32 bend = last_tile ? n : retro ? L->vars[V_WPOS_PRE] : walkpos;
 			const u32 blen = bend - bstart;
-			const u32 nseq = stored_only ? 0 : L->vars[V_NSEQ];
+			const u32 nseq_all = stored_only ? 0 : L->vars[V_NSEQ];
+			const u32 nseq = retro ? L->vars[V_NSEQ_PRE] : nseq_all;
 			const u32 is_final = last_tile && seg_last ? 1 : 0;
+			if (retro) {
+				if (tid < 320) {
+					u32 f = L->freq[tid], fp = fsave[tid];
+					fsave[320 + tid] = f - fp;
+					L->freq[tid] = fp;
+				}
+				__syncthreads();
+			}
 
 			/* ---- S5: codes, costs, block type ---- */
 			u32 btype = 0;	/* 0 stored, 1 static, 2 dynamic */
@@ -2299,10 +2397,34 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					L->vars[V_MINLEN] = choose_min_len(nused, depth);
 				__syncthreads();
 			}
-			for (u32 i = tid; i < 320; i += NT)
-				L->freq[i] = 0;
-			if (tid == 0)
-				L->vars[V_NSEQ] = 0;
+			if (OPT && mode == 3 && tid < 256)
+				bsave[tid] = 0;	/* the previous tile's bytes are added by the next one */
+			if (retro) {
+				/* the last tile's tokens open the next block: its matches
+				 * move to the front of the list (positions are relative to
+				 * the block start), its histogram becomes the block's */
+				const u32 cnt = nseq_all - nseq;	/* <= SEQ_TILE_MAX < 2 NT */
+				u64 e0 = 0, e1 = 0;
+				if (tid < cnt)
+					e0 = seqg[nseq + tid];
+				if (tid + NT < cnt)
+					e1 = seqg[nseq + NT + tid];
+				__syncthreads();
+				if (tid < cnt)
+					seqg[tid] = e0 - blen;
+				if (tid + NT < cnt)
+					seqg[NT + tid] = e1 - blen;
+				if (tid < 320)
+					L->freq[tid] = fsave[320 + tid];
+				if (tid == 0)
+					L->vars[V_NSEQ] = cnt;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			} else {
+				for (u32 i = tid; i < 320; i += NT)
+					L->freq[i] = 0;
+				if (tid == 0)
+					L->vars[V_NSEQ] = 0;
+			}
 			/* restore what S1..S4 expect in M[0..3]: the deferred
 			 * entries were consumed only if the walk passed them; the
 			 * encode pass clobbered them, so re-derive from nothing:

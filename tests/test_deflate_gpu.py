@@ -267,8 +267,10 @@ def test_large_single_buffer_is_segmented(level, oracle):
 
 def test_block_split_follows_content():
     """lib/deflate_compress.c:2092-2218 (a10): a buffer whose content changes
-    is cut into blocks near the changes; homogeneous buffers stay one block.
-    Size within 5 % of the reference on the mixed buffers."""
+    is cut into blocks near the changes (the block ends in front of the first
+    tile of different content); homogeneous buffers stay one block.  Size
+    within 5 % of the reference on the mixed buffers, also when the changes
+    do not fall on tile boundaries."""
     import os
     import sys
     from libdeflate_amd import api
@@ -286,8 +288,9 @@ def test_block_split_follows_content():
             assert out == d
             if lvl == 6:
                 assert len(blocks) == nblocks, (kinds, [b["len"] for b in blocks])
-                for b in blocks[:-1]:       # cut within two tiles after a change
-                    assert b["start"] + b["len"] - 32768 * ((b["start"] + b["len"]) // 32768) <= 8192
+                for b in blocks[:-1]:       # cut within a tile of the change
+                    end = b["start"] + b["len"]
+                    assert abs(end - 32768 * round(end / 32768)) <= 4096 + 258, (kinds, end)
             else:
                 assert nblocks <= len(blocks) <= nblocks + 2, (kinds, len(blocks))
             if ref is not None:
@@ -298,6 +301,14 @@ def test_block_split_follows_content():
                 lazy_size[kinds] = len(z)
             else:       # a tile of foreign content must not make the min-cost parse lose
                 assert len(z) <= lazy_size[kinds], (kinds, len(z), lazy_size[kinds])
+        # changes of content at odd offsets
+        d = (datagen.chunk(0, 21000, 0x0E110048) + datagen.chunk(5, 30001, 0x0E110049) +
+             datagen.chunk(6, 17777, 0x0E11004A) + datagen.chunk(0, 40000, 0x0E11004B))
+        z = c.compress_batch_host("deflate", [d])[0]
+        out, blocks = stream_stats.stats(z)
+        assert out == d and 3 <= len(blocks) <= 6, len(blocks)
+        if ref is not None:
+            assert len(z) <= 1.05 * len(ref.compress("deflate", lvl, d)), (lvl, len(z))
         c.close()
 
 
