@@ -13,7 +13,7 @@
  * Two mappings share the sequential decoder in inflate_block():
  *
  * WAVE PER STREAM (lda_inflate_wave_kernel, the default).  Inside a Huffman
- * block the 64 lanes parse 64 consecutive 256-bit pieces of the input at
+ * block the 64 lanes parse 64 consecutive 384-bit pieces of the input at
  * once: a parse started at an arbitrary bit falls in step with the true one
  * within a few dozen bits, so a couple of passes in which every lane restarts
  * where its left neighbour ended give the exact token boundaries; the tokens
@@ -522,7 +522,9 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
  * buffer, and every distance inside the bytes already produced - otherwise
  * the round is abandoned and the sequential decoder takes the same bits.
  */
-#define PAR_CB 256u		/* input bits per lane and round */
+#ifndef PAR_CB
+#define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
+#endif
 #define PAR_TOKCAP 8192u	/* tokens per round held in the wave's scratch */
 enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
 
@@ -536,6 +538,7 @@ struct par_bits {
  * bytes); b->nb and all bit positions of a round are relative to it */
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
 #define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
+static_assert(PAR_SPAN <= 256u * 4 + 2 * 1088u, "the staged input span shares the copy phase's LDS");
 
 static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
 {
@@ -690,10 +693,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * padding of the sequential decoder; a round whose exact parse ends
 	 * beyond the input is abandoned below and left to that decoder (it is
 	 * the one that knows the overread rules). */
-	const u32 cb = PAR_CB;
 	const u64 byte0 = bpos_abs >> 3;
 	if (byte0 + 64 > in_n)
 		return PAR_STOP;
+	/* long pieces need fewer rounds and fewer passes per round (a parse
+	 * falls in step within ~50 bits); when the input left would not fill
+	 * the 64 lanes with them, shorter pieces keep more lanes busy */
+	const u32 cb = in_n - byte0 >= 64 * (PAR_CB / 8) ? PAR_CB : 256u;
 	const u64 room = (in_n - byte0 + cb / 8 - 1) / (cb / 8);
 	const u32 NL = room < 64 ? (u32)room : 64;
 	/* stage the span: 8-byte words, unaligned in HBM, aligned in LDS */
