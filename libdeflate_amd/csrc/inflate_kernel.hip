@@ -1685,7 +1685,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 /*
  * Wave per stream with sub-block parallel token decoding; persistent grid
  * (each wave owns PAR_TOKCAP words of the token scratch and walks the
- * streams blockIdx.x, blockIdx.x + gridDim.x, ...).
+ * streams first, first + gridDim.x, ...).
  */
 #ifndef PAR_WAVES_PER_SIMD
 #define PAR_WAVES_PER_SIMD 4	/* 16 streams in flight per CU: occupancy hides the LDS chains */
@@ -1705,7 +1705,21 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
 	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_TOKCAP;
 
-	for (u64 blk = blockIdx.x; blk < n_chunks; blk += gridDim.x) {
+	/* Which streams share a CU follows from the dispatch order (workgroup i
+	 * goes to XCD i mod 8, then CU by CU), so a batch whose content is
+	 * periodic in the stream index - every 8th buffer of the same kind, say -
+	 * would put all its slow streams on the same CUs.  The streams are taken
+	 * in a scrambled order instead: a bijection of the grid that folds the
+	 * high index bits into the low ones (an invertible xor-shift on the next
+	 * power of two, walked along its cycle until it lands inside the grid). */
+	u32 first = blockIdx.x;
+	if (gridDim.x > 1) {
+		const u32 m = (2u << (31 - __builtin_clz(gridDim.x - 1))) - 1;
+		do
+			first = (first ^ (first >> 3) ^ (first >> 6) ^ (first >> 9)) & m;
+		while (first >= gridDim.x);
+	}
+	for (u64 blk = first; blk < n_chunks; blk += gridDim.x) {
 		inflate_block(blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
 			      in_offsets, in_nbytes, out_base, out_offsets,
 			      out_avail_arr, results, actual_in, actual_out);
