@@ -187,14 +187,18 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		size_t grid = (size_t)c->num_cus * 16;
 		if (grid > n)
 			grid = n;
-		uint32_t *tok = (uint32_t *)d->tokens.reserve(
-					grid * lda_inflate_tokcap() * 4);
+		/* token scratch of every wave, then the counter the waves take
+		 * their second and later streams from */
+		const size_t tok_bytes = grid * lda_inflate_tokcap() * 4;
+		uint32_t *tok = (uint32_t *)d->tokens.reserve(tok_bytes + 16);
 		if (!tok)
 			return LIBDEFLATE_AMD_OOM;
+		uint32_t *next = (uint32_t *)((uint8_t *)tok + tok_bytes);
+		LDA_HIP_TRY(hipMemsetAsync(next, 0, 16, st), LIBDEFLATE_AMD_NO_DEVICE);
 		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared() +
 			     lda_inflate_window_bytes();
 		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
-				   dim3(64), lds, st, (uint64_t)n, format, tok,
+				   dim3(64), lds, st, (uint64_t)n, format, tok, next,
 				   (const uint8_t *)d_in, d_in_offsets, d_in_nbytes,
 				   (uint8_t *)d_out, d_out_offsets, d_out_avail,
 				   d_results, ain, aout);

@@ -1692,6 +1692,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 #endif
 extern "C" __global__ void __launch_bounds__(64, PAR_WAVES_PER_SIMD)
 lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
+			u32 *__restrict__ next_stream,
 			const u8 *__restrict__ in_base,
 			const u64 *__restrict__ in_offsets,
 			const u64 *__restrict__ in_nbytes,
@@ -1719,11 +1720,18 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 			first = (first ^ (first >> 3) ^ (first >> 6) ^ (first >> 9)) & m;
 		while (first >= gridDim.x);
 	}
-	for (u64 blk = first; blk < n_chunks; blk += gridDim.x) {
+	/* the first stream of a wave is fixed by that order; the streams beyond
+	 * the grid are handed out as the waves become free (their cost depends
+	 * on their content) */
+	for (u64 blk = first; blk < n_chunks;) {
 		inflate_block(blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
 			      in_offsets, in_nbytes, out_base, out_offsets,
 			      out_avail_arr, results, actual_in, actual_out);
 		wave_sync();
+		u32 nx = 0;
+		if (lane_id() == 0)
+			nx = atomicAdd(next_stream, 1u);
+		blk = (u64)gridDim.x + bcast_first(nx);
 	}
 }
 
