@@ -184,7 +184,10 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		attr_set[c->device] = true;
 	}
 	if (par) {
-		size_t grid = (size_t)c->num_cus * 16;
+		size_t per_cu = 16;
+		if (const char *e = getenv("LDA_INFLATE_WAVES_PER_CU"))	/* tuning */
+			per_cu = (size_t)atoi(e) >= 1 && atoi(e) <= 16 ? (size_t)atoi(e) : 16;
+		size_t grid = (size_t)c->num_cus * per_cu;
 		if (grid > n)
 			grid = n;
 		/* token scratch of every wave, then the counter the waves take
