@@ -1308,8 +1308,32 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 		}
 		PROF_MARK(1);
 
-		/* ------------ stored blocks: the lane copies its bytes ------------ */
-		if (state == ST_STORED) {
+		/* ------------ stored blocks ------------ */
+		if (par) {
+			/* wave per stream: lane 0 holds the stream, all 64 lanes copy
+			 * (8 bytes each, 512 per step; the odd tail byte by byte) */
+			if (bcast_first(state == ST_STORED ? 1u : 0u)) {
+				const u8 *src = (const u8 *)bcast64((u64)(uintptr_t)(inp + rpos));
+				u8 *dst = (u8 *)bcast64((u64)(uintptr_t)(outp + out_pos));
+				const u64 len = bcast64(stored_left);
+				for (u64 k = 8 * (u64)lane; k + 8 <= len; k += 512) {
+					u64 v;
+					__builtin_memcpy(&v, src + k, 8);
+					__builtin_memcpy(dst + k, &v, 8);
+				}
+				if ((len & ~7ull) + lane < len)
+					dst[(len & ~7ull) + lane] = src[(len & ~7ull) + lane];
+				wave_sync();	/* later matches read these bytes */
+				if (state == ST_STORED) {
+					out_pos += stored_left;
+					rpos += stored_left;
+					bitbuf = 0;
+					bitcnt = 0;
+					filled = rpos & ~(u64)63;	/* restart the input ring */
+					state = final_block ? ST_DONE : ST_HDR;
+				}
+			}
+		} else if (state == ST_STORED) {	/* lane per stream: the lane copies its bytes */
 			const u8 *src = inp + rpos;
 			u8 *dst = outp + out_pos;
 			u64 k = 0;
