@@ -525,7 +525,9 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
 #ifndef PAR_CB
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
 #endif
+#ifndef PAR_TOKCAP
 #define PAR_TOKCAP 8192u	/* tokens per round held in the wave's scratch */
+#endif
 enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
 
 struct par_bits {
