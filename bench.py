@@ -12,33 +12,40 @@ round-trip throughput: uncompressed batch bytes / step time, MB = 1e6 bytes
 (programs/test_util.c:197-200), aggregated over all ranks; the separate
 compress and decompress rates are reported alongside.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): chunks are
-independent, so every rank owns its own 4096-chunk shard (weak scaling, no
-data-path collective); the only exchange is the final gather of the
-per-chunk (size, status) verdicts to rank 0 over RCCL, inside the timed
-region.
+Multi-GPU: `python bench.py --gpus N` launches N ranks itself (it re-executes
+under torch.distributed.run when WORLD_SIZE is not set); under an external
+launcher it reads RANK/LOCAL_RANK/WORLD_SIZE.  Chunks are independent, so
+every rank owns its own shard (no data-path collective); the only exchange is
+the final gather of the per-chunk (size, status) verdicts to rank 0 over
+RCCL, inside the timed region.
 
 The JSON line also carries
   roofline      for the dominant kernel (the LZ77+Huffman compress kernel):
                 algorithmic bytes (U read + C written) per launch / its
                 average duration, HIP events on the launch stream, vs 8 TB/s.
   cpu_baseline  the real reference (oracle/_ref, built from /root/reference's
-                sources) timed on this box's host cores on a bounded sample of
-                the same batch - same round trip, one (de)compressor per
-                thread (libdeflate.h:56-57).
+                sources) timed by a C pthread harness (oracle/cpu_bench.c) on
+                this box's host cores, T = 1 and T = all, on a bounded sample
+                of the same batch.
+  configs       the other BASELINE.json configurations, each with its own
+                ms / MB/s / roofline fraction (see extra_*()): configs[1]
+                (level 1 raw), configs[3] (decompress-only, 65 536 streams
+                compressed by the reference, contiguous shard per rank,
+                every byte compared), configs[4] (1 Mi x 4 KiB zlib level 9).
+  end_to_end    the headline batch starting and ending in pinned host memory
+                (H2D + kernels + D2H); never `value`.
 """
 import argparse
-import concurrent.futures as cf
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 CHUNK = 65536
 CHUNKS_PER_GPU = 4096
@@ -47,101 +54,360 @@ FMT = "gzip"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_batch(rank, count, distinct=256):
-    """64 KiB chunk mix (5 text, binary, low-entropy,
-    random per 8), base seed 0x0E110003.  `distinct` different chunks are
-    generated and tiled to `count` (all chunks are independent streams either
-    way; this only bounds host-side generation time)."""
-    from tests import datagen
-    chunks = datagen.batch(count, CHUNK, 0x0E110003 + rank * 100003,
-                           distinct=distinct)
-    return chunks
+def relaunch(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks on this
+    node (one per GPU) the way the driver does for N > 1."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the compress kernel from the PMC passes
-    (tools/prof_pmc.sh -> profiles/*pmc_deflate*.json): FETCH_SIZE is doubled
-    per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read),
-    WRITE_SIZE taken as is; both are in KiB.  None if no profile is present."""
+def pmc_static():
+    """PMC figures of the compress kernel from a committed profile
+    (tools/prof_pmc.sh -> profiles/*pmc_deflate*.json): NOT measured in this
+    run, and labelled as such in the line.  FETCH_SIZE is doubled per
+    MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read),
+    WRITE_SIZE taken as is; both in KiB."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_deflate*.json")))
     if not files:
-        return None
+        return None, None, None
+    src = os.path.relpath(files[-1], ROOT)
     k = json.load(open(files[-1])).get("lda_deflate_batch_kernel", {})
-    if "FETCH_SIZE_per_launch" not in k or "WRITE_SIZE_per_launch" not in k:
+    traffic = None
+    if "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
+        traffic = int(2 * k["FETCH_SIZE_per_launch"] * 1024 +
+                      k["WRITE_SIZE_per_launch"] * 1024)
+    valu = k.get("SQ_INSTS_VALU_per_launch")
+    return traffic, valu, src
+
+
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask, cut by a
+    cgroup CPU quota if there is one (a container often shows the machine's
+    CPU count while being allowed a fraction of it)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
+def cpu_info():
+    model, cores = "unknown", usable_cores()
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, cores
+
+
+def cpu_baseline(chunks, fmt, level):
+    """Reference libdeflate (oracle/_ref) on this box's host cores through
+    oracle/cpu_bench.c (pthreads, one compressor + decompressor per thread,
+    clock_gettime, best of 3 after a warm-up): T = all cores, >= 0.5 s of
+    work per thread and pass, and T = 1."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cpu_bench")
+    if not os.path.exists(exe):
         return None
-    return int(2 * k["FETCH_SIZE_per_launch"] * 1024 + k["WRITE_SIZE_per_launch"] * 1024)
+    model, cores = cpu_info()
+    size = len(chunks[0])
+    out = {}
+    with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
+        # ~0.6 s of level-6 work per thread (reference: ~60 MB/s per core)
+        per_thread = max(8, int(36e6 // size)) if level >= 5 else max(16, int(80e6 // size))
+        count_all = per_thread * cores      # chunk i = file chunk i mod len(chunks)
+        for c in chunks:
+            f.write(c)
+        f.flush()
+        for key, t, cnt in (("all", cores, count_all), ("t1", 1, min(count_all, per_thread * 2))):
+            r = subprocess.run([exe, f.name, str(size), str(cnt), fmt, str(level),
+                                str(t), "3"], capture_output=True, text=True,
+                               timeout=300)
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-200:]}
+            out[key] = json.loads(r.stdout)
+    a, t1 = out["all"], out["t1"]
+    return {"value": a["MBps"], "unit": "MB/s", "cores": a["threads"],
+            "kind": "reference",
+            "sample": f"{a['chunks']} of the same {size}-byte chunks ({fmt} level "
+                      f"{level} compress+decompress round trip, statically "
+                      f"partitioned over {a['threads']} threads, best of 3 passes "
+                      f"after a warm-up, {a['wall_s']:.2f} s per pass)",
+            "compress_MBps": a["compress_MBps"],
+            "decompress_MBps": a["decompress_MBps"],
+            "t1": {"value": t1["MBps"], "compress_MBps": t1["compress_MBps"],
+                   "decompress_MBps": t1["decompress_MBps"], "chunks": t1["chunks"]},
+            "cpu_model": model, "host_cores": cores,
+            "host_cpus_online": os.cpu_count(),
+            "harness": "oracle/cpu_bench.c (pthreads, clock_gettime)"}
 
 
-def pmc_issue(t_launch_s):
-    """Share of the machine's VALU issue slots the compress kernel used: a
-    wave64 VALU instruction occupies its SIMD for 4 cycles whatever the number
-    of active lanes (SQ_INSTS_VALU from the same PMC passes; 256 CUs x 4 SIMDs
-    at the 2.4 GHz maximum clock of MI355X_MICROARCH.md).  This, not HBM, is
-    what bounds the kernel; None if no profile is present."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_deflate*.json")))
-    if not files:
-        return None
-    k = json.load(open(files[-1])).get("lda_deflate_batch_kernel", {})
-    if "SQ_INSTS_VALU_per_launch" not in k:
-        return None
-    valu = k["SQ_INSTS_VALU_per_launch"]
-    return {"valu_wave_insts_per_launch": int(valu),
-            "simd_issue_frac": round(valu * 4 / (1024 * 2.4e9 * t_launch_s), 3),
-            "note": "VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x "
-                    "launch time); the kernel is issue-bound, not HBM-bound"}
+class Timer:
+    """HIP events on the launch stream + wall clock bracketed by barriers."""
+
+    def __init__(self, torch, dist, dev, stream, steps, nmarks):
+        self.torch, self.dist, self.dev, self.stream = torch, dist, dev, stream
+        self.ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nmarks)]
+                   for _ in range(steps)]
+
+    def run(self, step, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            step(None)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = step(self.ev[i])
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, last
+
+    def span(self, a, b):
+        import numpy as np
+        return float(np.mean([e[a].elapsed_time(e[b]) for e in self.ev])) / 1e3
 
 
-def cpu_baseline(chunks, threads):
-    """Reference libdeflate (oracle/_ref) on host cores: gzip level 6 compress
-    then decompress of a bounded sample, best of 3 after a warm-up."""
-    from tests import oracle_util
-    import ctypes
+def all_sum(torch, dist, dev, *vals):
+    if not dist:
+        return vals
+    t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    return tuple(float(x) for x in t.tolist())
+
+
+def device_batch(torch, dev, chunks, count, first=0):
+    """`count` chunks on the device, chunk i = chunks[(first + i) % len]
+    (independent streams either way; tiling only bounds host-side generation
+    time).  Returns (data u8[count * size], offsets, nbytes)."""
+    size = len(chunks[0])
+    d = len(chunks)
+    base = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).to(dev)
+    idx = (torch.arange(count, device=dev) + first) % d
+    data = base.view(d, size)[idx].reshape(-1).contiguous()
+    offs = torch.arange(count, dtype=torch.int64, device=dev) * size
+    nb = torch.full((count,), size, dtype=torch.int64, device=dev)
+    return data, offs, nb
+
+
+def roundtrip_config(torch, dist, world, rank, dev, stream, api, shard, chunks,
+                     count, first, fmt, level, steps, warmup):
+    """compress then decompress `count` device-resident chunks; verifies the
+    round trip byte for byte after the timed region."""
+    size = len(chunks[0])
+    data, in_off, in_n = device_batch(torch, dev, chunks, count, first)
+    comp_c, dec = api.Compressor(level), api.Decompressor()
+    bound = (comp_c.bound(fmt, size) + 15) // 16 * 16
+    comp = torch.zeros(count * bound, dtype=torch.uint8, device=dev)
+    c_off = torch.arange(count, dtype=torch.int64, device=dev) * bound
+    c_av = torch.full((count,), bound, dtype=torch.int64, device=dev)
+    c_n = torch.zeros(count, dtype=torch.int64, device=dev)
+    out = torch.zeros(count * size, dtype=torch.uint8, device=dev)
+    res = torch.full((count,), -1, dtype=torch.int32, device=dev)
+    tm = Timer(torch, dist, dev, stream, steps, 3)
+
+    def step(ev):
+        if ev:
+            ev[0].record(stream)
+        comp_c.compress_batch(fmt, data, in_off, in_n, comp, c_off, c_av, c_n,
+                              stream=stream)
+        if ev:
+            ev[1].record(stream)
+        dec.decompress_batch(fmt, comp, c_off, c_n, out, in_off, in_n, res,
+                             stream=stream)
+        if ev:
+            ev[2].record(stream)
+        # final gather of the per-chunk verdicts (the only exchange step)
+        return shard.gather_verdicts(c_n, res, dist, world)
+
+    elapsed, verdict = tm.run(step, steps, warmup)
+    # correctness of what was timed (outside the timed region)
+    assert bool((res == 0).all()), "a chunk failed to decompress"
+    assert torch.equal(out, data), "round trip is not byte-exact"
+    assert bool((c_n > 0).all()) and bool((c_n <= comp_c.bound(fmt, size)).all())
+    U = count * size
+    C = int(c_n.sum().item())
+    r = {"elapsed": elapsed, "t_comp": tm.span(0, 1), "t_dec": tm.span(1, 2),
+         "U": U, "C": C, "verdict": verdict,
+         "tensors": (data, in_off, in_n, comp, c_off, c_av, c_n, out, res, comp_c, dec)}
+    return r
+
+
+def end_to_end(torch, dev, stream, api, tensors):
+    """The headline batch from pinned host memory and back: H2D of the input,
+    compress, D2H of the output slots; H2D of the slots, decompress, D2H of
+    the output (SURVEY.md 8(d) "(ii) end-to-end"; the reference times from
+    host buffers, programs/test_util.c:143-164)."""
+    data, in_off, in_n, comp, c_off, c_av, c_n, out, res, comp_c, dec = tensors
+    h_in = torch.empty(data.numel(), dtype=torch.uint8).pin_memory()
+    h_in.copy_(data)
+    h_comp = torch.empty(comp.numel(), dtype=torch.uint8).pin_memory()
+    h_out = torch.empty(out.numel(), dtype=torch.uint8).pin_memory()
+    best_c = best_d = None
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        data.copy_(h_in, non_blocking=True)
+        comp_c.compress_batch(FMT, data, in_off, in_n, comp, c_off, c_av, c_n,
+                              stream=stream)
+        h_comp.copy_(comp, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        comp.copy_(h_comp, non_blocking=True)
+        dec.decompress_batch(FMT, comp, c_off, c_n, out, in_off, in_n, res,
+                             stream=stream)
+        h_out.copy_(out, non_blocking=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it:
+            best_c = min(best_c or 1e9, t1 - t0)
+            best_d = min(best_d or 1e9, t2 - t1)
+    assert torch.equal(h_out, h_in)
+    U = data.numel()
+    return {"compress_MBps": round(U / best_c / 1e6, 1),
+            "decompress_MBps": round(U / best_d / 1e6, 1),
+            "roundtrip_MBps": round(U / (best_c + best_d) / 1e6, 1),
+            "note": "pinned host -> HBM -> pinned host, whole slot array copied "
+                    "back (H2D U + kernels + D2H slots; H2D slots + kernels + D2H U), "
+                    "best of 2 after a warm-up; one GPU"}
+
+
+def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
+                    shard, chunks, total, fmt, level, steps, scaling):
+    """A non-headline BASELINE config: compress + decompress of `total`
+    chunks (strong: partitioned over the ranks; weak: `total` per rank)."""
+    if scaling == "strong":
+        lo, hi = shard.partition(total, world, rank)
+    else:
+        lo, hi = rank * total, (rank + 1) * total
+    r = roundtrip_config(torch, dist, world, rank, dev, stream, api, shard,
+                         chunks, hi - lo, lo, fmt, level, steps, 1)
+    U, C, tc, td = all_sum(torch, dist, dev, r["U"], r["C"], r["t_comp"], r["t_dec"])
+    tc, td = tc / world, td / world     # mean launch time over ranks
+    ms = r["elapsed"] / steps * 1e3
+    del r["tensors"]
+    torch.cuda.empty_cache()
+    return {"workload": workload, "scaling": scaling, "n_gpus": world,
+            "steps": steps, "ms_per_step": round(ms, 3),
+            "roundtrip_MBps": round(U / (ms / 1e3) / 1e6, 1),
+            "compress_MBps": round(U / tc / 1e6, 1),
+            "decompress_MBps": round(U / td / 1e6, 1),
+            "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3),
+            "compressed_ratio": round(C / U, 4),
+            "verified": "round trip byte-exact on every rank",
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "compress": {"achieved": round((U + C) / world / tc / 1e9, 2),
+                                      "frac": round((U + C) / world / tc / 1e9 / HBM_PEAK_GBS, 5)},
+                         "decompress": {"achieved": round((U + C) / world / td / 1e9, 2),
+                                        "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5)}}}
+
+
+def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, steps):
+    """BASELINE configs[3]: `total` gzip streams pre-compressed by the
+    reference (oracle/_ref) at level 6 OUTSIDE the timed region, contiguous
+    shard per rank, decompress-only in exact-fill mode
+    (actual_out_nbytes_ret = NULL, out_avail = 65 536), every byte of the
+    output compared, verdicts gathered to rank 0."""
+    from tests import datagen, oracle_util
     ref = oracle_util.load_ref()
     if ref is None:
-        return None
-    lib = ref.lib
-    sample = chunks[:max(256, 32 * threads)]
-    per = [sample[i::threads] for i in range(threads)]
-    bound = lib.libdeflate_gzip_compress_bound(None, CHUNK)
+        return {"skipped": "oracle/_ref/libdeflate_ref.so not built"}
+    distinct = 256
+    chunks = datagen.batch(distinct, CHUNK, 0x0E110004, distinct=distinct)
+    streams = [ref.compress("gzip", 6, c) for c in chunks]
+    lo, hi = shard.partition(total, world, rank)
+    n = hi - lo
+    # one aligned blob of the distinct streams, repeated on the device
+    offs, blob = [], bytearray()
+    for s in streams:
+        offs.append(len(blob))
+        blob += s
+        blob += bytes((-len(blob)) % 16)
+    blen = len(blob)
+    reps = (n + distinct - 1) // distinct + 1
+    d_blob = torch.frombuffer(blob, dtype=torch.uint8).to(dev).repeat(reps)
+    d_in = torch.cat([d_blob, torch.zeros(64, dtype=torch.uint8, device=dev)])
+    gi = torch.arange(lo, hi, device=dev)
+    first_rep = lo // distinct
+    base_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    in_off = base_off[gi % distinct] + (gi // distinct - first_rep) * blen
+    in_n = torch.tensor([len(s) for s in streams], dtype=torch.int64,
+                        device=dev)[gi % distinct]
+    want_base = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).to(dev)
+    out = torch.zeros(n * CHUNK, dtype=torch.uint8, device=dev)
+    out_off = torch.arange(n, dtype=torch.int64, device=dev) * CHUNK
+    out_av = torch.full((n,), CHUNK, dtype=torch.int64, device=dev)
+    res = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    dec = api.Decompressor()
+    tm = Timer(torch, dist, dev, stream, steps, 2)
 
-    def work(part):
-        c = ctypes.c_void_p(lib.libdeflate_alloc_compressor(LEVEL))
-        d = ctypes.c_void_p(lib.libdeflate_alloc_decompressor())
-        out = ctypes.create_string_buffer(bound)
-        back = ctypes.create_string_buffer(CHUNK)
-        ai, ao = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        tc = td = 0.0
-        for data in part:
-            t0 = time.perf_counter()
-            n = lib.libdeflate_gzip_compress(c, data, len(data), out, bound)
-            t1 = time.perf_counter()
-            r = lib.libdeflate_gzip_decompress_ex(d, out, n, back, CHUNK,
-                                                  ctypes.byref(ai), ctypes.byref(ao))
-            t2 = time.perf_counter()
-            assert n > 0 and r == 0 and ao.value == len(data)
-            tc += t1 - t0
-            td += t2 - t1
-        lib.libdeflate_free_compressor(c)
-        lib.libdeflate_free_decompressor(d)
-        return tc, td
+    def step(ev):
+        if ev:
+            ev[0].record(stream)
+        dec.decompress_batch("gzip", d_in, in_off, in_n, out, out_off, out_av,
+                             res, stream=stream)   # actual_out = None: exact fill
+        if ev:
+            ev[1].record(stream)
+        return shard.gather_verdicts(in_n, res, dist, world)
 
-    best = None
-    with cf.ThreadPoolExecutor(threads) as ex:
-        for it in range(4):
-            t0 = time.perf_counter()
-            res = list(ex.map(work, per))
-            wall = time.perf_counter() - t0
-            if it and (best is None or wall < best[0]):
-                best = (wall, max(r[0] for r in res), max(r[1] for r in res))
-    nbytes = len(sample) * CHUNK
-    return {"value": round(nbytes / best[0] / 1e6, 1), "unit": "MB/s",
-            "cores": threads, "kind": "reference",
-            "sample": f"{len(sample)} of the same 64 KiB chunks, gzip level 6 "
-                      f"compress+decompress round trip, best of 3",
-            "compress_MBps": round(nbytes / best[1] / 1e6, 1),
-            "decompress_MBps": round(nbytes / best[2] / 1e6, 1)}
+    elapsed, verdict = tm.run(step, steps, 1)
+    assert bool((res == 0).all()), "a stream failed to decompress"
+    want = want_base.view(distinct, CHUNK)[gi % distinct].reshape(-1)
+    assert torch.equal(out, want), "decompressed bytes differ from the original"
+    U, C, td = all_sum(torch, dist, dev, n * CHUNK, int(in_n.sum().item()), tm.span(0, 1))
+    td /= world
+    ms = elapsed / steps * 1e3
+    r = {"workload": f"configs[3]: decompress-only, {total} gzip streams of 64 KiB "
+                     "chunks compressed by the reference at level 6, contiguous "
+                     "shard per rank",
+         "scaling": "strong", "n_gpus": world, "steps": steps,
+         "ms_per_step": round(ms, 3),
+         "decompress_MBps": round(U / (ms / 1e3) / 1e6, 1),
+         "kernel_ms": round(td * 1e3, 3),
+         "compressed_ratio": round(C / U, 4),
+         "verified": f"all {int(U)} output bytes equal the original; "
+                     f"{verdict[0]} verdicts gathered, {verdict[1]} failed",
+         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                      "achieved": round((U + C) / world / td / 1e9, 2),
+                      "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5)}}
+    del d_in, d_blob, out, want
+    torch.cuda.empty_cache()
+    return r
 
 
 def main():
@@ -151,8 +417,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_GPU)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--configs", default="all", choices=["all", "headline"],
+                    help="'headline' skips the other BASELINE configs")
+    ap.add_argument("--streams", type=int, default=65536,
+                    help="configs[3] stream count (total over all ranks)")
+    ap.add_argument("--blocks", type=int, default=1 << 20,
+                    help="configs[4] 4 KiB block count (total over all ranks)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(a))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,74 +440,47 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from libdeflate_amd import api, shard
-    n = a.chunks
-    chunks = build_batch(rank, n)
+    from tests import datagen
     dev = torch.device("cuda", local_rank)
-    data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).to(dev)
-    comp_c = api.Compressor(LEVEL)
-    dec = api.Decompressor()
-    bound = (comp_c.bound(FMT, CHUNK) + 15) // 16 * 16
-    in_off = torch.arange(n, dtype=torch.int64, device=dev) * CHUNK
-    in_n = torch.full((n,), CHUNK, dtype=torch.int64, device=dev)
-    comp = torch.zeros(n * bound, dtype=torch.uint8, device=dev)
-    c_off = torch.arange(n, dtype=torch.int64, device=dev) * bound
-    c_av = torch.full((n,), bound, dtype=torch.int64, device=dev)
-    c_n = torch.zeros(n, dtype=torch.int64, device=dev)
-    out = torch.zeros(n * CHUNK, dtype=torch.uint8, device=dev)
-    res = torch.full((n,), -1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
+    n = a.chunks
+    # 64 KiB chunk mix (5 text, binary, low-entropy,
+    # random per 8); 256 distinct chunks per rank are generated and tiled
+    chunks = datagen.batch(256, CHUNK, 0x0E110003 + rank * 100003, distinct=256)
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)]
-          for _ in range(a.steps)]
+    head = roundtrip_config(torch, dist, world, rank, dev, stream, api, shard,
+                            chunks, n, 0, FMT, LEVEL, a.steps, a.warmup)
+    elapsed, t_comp, t_dec = head["elapsed"], head["t_comp"], head["t_dec"]
+    U, C = head["U"], head["C"]
+    e2e = None
+    if rank == 0 and a.configs == "all":
+        e2e = end_to_end(torch, dev, stream, api, head["tensors"])
+    del head["tensors"]
+    torch.cuda.empty_cache()
 
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record(stream)
-        comp_c.compress_batch(FMT, data, in_off, in_n, comp, c_off, c_av, c_n,
-                              stream=stream)
-        if i is not None:
-            ev[i][1].record(stream)
-        dec.decompress_batch(FMT, comp, c_off, c_n, out, in_off, in_n, res,
-                             stream=stream)
-        if i is not None:
-            ev[i][2].record(stream)
-        # final gather of the per-chunk verdicts (the only exchange step)
-        return shard.gather_verdicts(c_n, res, dist, world)
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        verdict = step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness of what was timed (outside the timed region)
-    assert bool((res == 0).all()), "a chunk failed to decompress"
-    assert torch.equal(out, data), "round trip is not byte-exact"
-    sizes = c_n.cpu().numpy()
-    assert (sizes > 0).all() and (sizes <= comp_c.bound(FMT, CHUNK)).all()
-
-    t_comp = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) / 1e3
-    t_dec = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / 1e3
-    U = n * CHUNK
-    C = int(sizes.sum())
+    extras = {}
+    if a.configs == "all":
+        extras["configs[1]"] = extra_roundtrip(
+            "l1", "configs[1]: 4096 x 64 KiB raw DEFLATE buffers, level 1, "
+            "compress then decompress, per GPU", torch, dist, world, rank, dev,
+            stream, api, shard,
+            datagen.batch(256, CHUNK, 0x0E110002 + rank * 100003, distinct=256),
+            a.chunks, "deflate", 1, 3, "weak")
+        extras["configs[3]"] = extra_inflate(torch, dist, world, rank, dev, stream,
+                                             api, shard, a.streams, 3)
+        extras["configs[4]"] = extra_roundtrip(
+            "zlib4k", f"configs[4]: {a.blocks} x 4 KiB zlib buffers "
+            "(filesystem-block mix), level 9, compress then decompress, "
+            "partitioned over the GPUs", torch, dist, world, rank, dev, stream,
+            api, shard,
+            datagen.batch(2048, 4096, 0x0E110005, mix=datagen.MIX4K, distinct=2048),
+            a.blocks, "zlib", 9, 2, "strong")
 
     if rank == 0:
-        total_chunks, n_fail = verdict
+        total_chunks, n_fail = head["verdict"]
         ms = elapsed / a.steps * 1e3
         value = U * world / (elapsed / a.steps) / 1e6
+        traffic, valu, pmc_src = pmc_static()
         line = {
             "metric": "compress+decompress MB/s, 64 KiB chunks level 6",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world,
@@ -255,12 +504,20 @@ def main():
                 "achieved": round((U + C) / t_comp / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((U + C) / t_comp / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(),
-                "issue": pmc_issue(t_comp),
+                "traffic": traffic,
+                "traffic_source": f"{pmc_src} (static: PMC passes of "
+                                  "tools/prof_pmc.sh, not this run)" if pmc_src else None,
+                "issue": None if not valu else {
+                    "valu_wave_insts_per_launch": int(valu),
+                    "simd_issue_frac": round(valu * 4 / (1024 * 2.4e9 * t_comp), 3),
+                    "source": f"{pmc_src} (static) / this run's launch time",
+                    "note": "VALU wave-instructions x 4 cycles / (1024 SIMDs x "
+                            "2.4 GHz x launch time): the kernel is issue-bound, "
+                            "not HBM-bound"},
                 "algorithmic_bytes_per_launch": U + C,
                 "avg_launch_ms": round(t_comp * 1e3, 3),
                 "note": "HIP events on the launch stream around the compress "
-                        "call (deflate kernel + the ~0.05 ms CRC-32 kernel)",
+                        "call; U + C with the CRC-32 pass counted as part of it",
                 "inflate_kernel": {
                     "kernel": "lda_inflate_wave_kernel",
                     "achieved": round((U + C) / t_dec / 1e9, 2),
@@ -268,11 +525,11 @@ def main():
                     "avg_launch_ms": round(t_dec * 1e3, 3)},
             },
         }
-        if not a.no_cpu:
-            threads = min(os.cpu_count() or 1, 64)
-            line["cpu_baseline"] = cpu_baseline(chunks, threads)
-        else:
-            line["cpu_baseline"] = None
+        if e2e:
+            line["end_to_end"] = e2e
+        if extras:
+            line["configs"] = extras
+        line["cpu_baseline"] = None if a.no_cpu else cpu_baseline(chunks, FMT, LEVEL)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

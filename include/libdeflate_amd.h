@@ -263,9 +263,40 @@ libdeflate_amd_adler32_batch(size_t n_chunks, const void *d_in,
 			     void *stream);
 
 /*
+ * Compaction of a batch's ragged outputs (what a caller of the reference does
+ * with the sizes libdeflate_*_compress returns: write them back to back,
+ * programs/gzip.c:149-185).  Copies d_nbytes[i] bytes from d_in +
+ * d_in_offsets[i] to d_out + d_out_offsets[i], where d_out_offsets[0..n) is
+ * the exclusive prefix sum of d_nbytes (computed here) and d_out_offsets[n]
+ * the total.  d_out_offsets must have room for
+ * libdeflate_amd_compact_offsets_len(n) entries (the tail is scan scratch).
+ * d_out must not overlap the inputs.
+ */
+LIBDEFLATEAPI size_t
+libdeflate_amd_compact_offsets_len(size_t n_chunks);
+LIBDEFLATEAPI int
+libdeflate_amd_compact_batch(size_t n_chunks, const void *d_in,
+			     const uint64_t *d_in_offsets,
+			     const uint64_t *d_nbytes, void *d_out,
+			     uint64_t *d_out_offsets, void *stream);
+
+/*
+ * Objects and streams: the batch calls only ENQUEUE work on `stream`.  A
+ * compressor / decompressor owns device scratch (match lists, token scratch,
+ * per-chunk sums, work counters) that a batch uses until it completes, so an
+ * object may have batches in flight on ONE stream at a time (they are ordered
+ * by the stream); use one object per stream for concurrent batches, exactly
+ * as the reference asks for one object per thread (libdeflate.h:56-57,
+ * :178-179).  Inputs of 4 GiB and more per chunk are not supported by the
+ * batch kernels (positions are 32-bit): such a chunk reports 0 / BAD_DATA.
+ */
+
+/*
  * Convenience forms taking HOST arrays of per-chunk host pointers (what a
- * cgo/JNI/ctypes caller holding ordinary buffers has).  They stage the batch
- * through HBM, run the device batch above and copy results back; blocking.
+ * cgo/JNI/ctypes caller holding ordinary buffers has).  They pack the batch
+ * into pinned host memory, move it as a few large DMA transfers (not one copy
+ * per chunk), run the device batch above, compact the outputs on the device
+ * and bring them back the same way; blocking.
  * results/actual_* have the meaning above.
  */
 LIBDEFLATEAPI int

@@ -195,3 +195,22 @@ def checksum_batch(kind, data, offsets, nbytes, out, init=None, stream=None):
     check(fn(offsets.numel(), data.data_ptr(), offsets.data_ptr(),
              nbytes.data_ptr(), init.data_ptr() if init is not None else None,
              out.data_ptr(), _stream_ptr(stream)), kind + "_batch")
+
+
+def compact_batch(data, offsets, nbytes, stream=None):
+    """Device-side compaction (libdeflate_amd_compact_batch): the used part of
+    every slot back to back.  torch CUDA tensors in; returns (packed uint8
+    tensor sized for the worst case, int64 offsets[n + 1] - exclusive prefix
+    sums of nbytes, offsets[n] = total).  Only enqueues; slice `packed` with
+    int(offsets[n]) after synchronising."""
+    import torch
+    lib = binding.load()
+    n = offsets.numel()
+    cap = int(lib.libdeflate_amd_compact_offsets_len(n))
+    out_off = torch.zeros(cap, dtype=torch.int64, device=data.device)
+    packed = torch.empty(data.numel(), dtype=torch.uint8, device=data.device)
+    check(lib.libdeflate_amd_compact_batch(
+        n, data.data_ptr(), offsets.data_ptr(), nbytes.data_ptr(),
+        packed.data_ptr(), out_off.data_ptr(), _stream_ptr(stream)),
+        "compact_batch")
+    return packed, out_off[:n + 1]

@@ -42,6 +42,7 @@ BATCH_SYMBOLS = [
     "libdeflate_amd_crc32_batch", "libdeflate_amd_adler32_batch",
     "libdeflate_amd_compress_batch_host",
     "libdeflate_amd_decompress_batch_host",
+    "libdeflate_amd_compact_offsets_len", "libdeflate_amd_compact_batch",
 ]
 
 _lib = None
@@ -106,6 +107,8 @@ def load():
         P)
     sig("libdeflate_amd_decompress_batch_host", c_int, P, c_int, SZ, P, P, P,
         P, P, P, P)
+    sig("libdeflate_amd_compact_offsets_len", SZ, SZ)
+    sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib
     return lib
 

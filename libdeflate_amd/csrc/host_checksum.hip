@@ -72,18 +72,18 @@ static uint32_t checksum_host(bool crc, uint32_t init, const void *buf,
 	DeviceCtx *c = device_ctx();
 
 	if (!c)
-		die_no_device(crc ? "libdeflate_crc32" : "libdeflate_adler32");
+		die(crc ? "libdeflate_crc32" : "libdeflate_adler32");
 	std::lock_guard<std::mutex> lk(c->stage_mu);
 	/* layout: [offset u64][nbytes u64][init u32][out u32][pad][data] */
 	size_t hdr = 64;
 	uint8_t *st = (uint8_t *)stage_reserve(c, hdr + len + 16);
 	if (!st)
-		die_no_device("checksum staging");
+		die("checksum staging");
 	struct { uint64_t off, n; uint32_t init, out; } h = { hdr, len, init, 0 };
 	if (hipMemcpy(st, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
 	    (len && hipMemcpy(st + hdr, buf, len, hipMemcpyHostToDevice) !=
 			    hipSuccess))
-		die_no_device("checksum H2D copy");
+		die("checksum H2D copy");
 	int rc = crc ?
 		libdeflate_amd_crc32_batch(1, st, (uint64_t *)st,
 					   (uint64_t *)(st + 8),
@@ -96,7 +96,7 @@ static uint32_t checksum_host(bool crc, uint32_t init, const void *buf,
 	uint32_t out = 0;
 	if (rc != LIBDEFLATE_AMD_OK ||
 	    hipMemcpy(&out, st + 20, 4, hipMemcpyDeviceToHost) != hipSuccess)
-		die_no_device("checksum kernel");
+		die("checksum kernel");
 	return out;
 }
 

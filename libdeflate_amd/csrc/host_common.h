@@ -42,8 +42,38 @@ DeviceCtx *device_ctx();
 /* grow-only device staging; caller holds ctx->stage_mu */
 void *stage_reserve(DeviceCtx *ctx, size_t nbytes);
 
-/* abort with a message: used where the reference API has no error channel */
-[[noreturn]] void die_no_device(const char *what);
+/* abort with a message: ONLY where the reference API has no error channel
+ * (libdeflate_crc32 / libdeflate_adler32); prints the real HIP error */
+[[noreturn]] void die(const char *what);
+
+/* a failure inside a single-buffer libdeflate_* call that does have an error
+ * return: one line on stderr (the error is also in libdeflate_amd_last_error) */
+void complain(const char *what, int status);
+
+/*
+ * Two pinned host buffers the host-pointer batch entry points pack into /
+ * unpack from while the other one is in flight: a batch crosses PCIe as a few
+ * large DMA transfers instead of one blocking copy per chunk.
+ */
+struct PinnedPair {
+	uint8_t *buf[2] = { nullptr, nullptr };
+	hipEvent_t ev[2] = { nullptr, nullptr };
+	size_t cap = 0;
+	bool ensure();		/* false + error if pinned memory is unavailable */
+	void release();
+};
+#define LDA_PINNED_SLICE ((size_t)32 << 20)
+
+/* host chunks -> device, packed at d_base + off[i] (off ascending); blocking
+ * only on its own pinned buffers */
+int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
+		   const void *const *in, const size_t *in_nbytes,
+		   const uint64_t *off, hipStream_t st);
+/* device bytes at d_base + off[i] (off ascending) -> out[i], nbytes[i] each
+ * (0 = skip); the stream must already hold the work that produces them */
+int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
+		    void *const *out, const uint64_t *nbytes,
+		    const uint64_t *off, hipStream_t st);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

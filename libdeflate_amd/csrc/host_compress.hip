@@ -87,6 +87,7 @@ libdeflate_free_compressor(struct libdeflate_compressor *c)
 		return;
 	c->scratch.release();
 	c->stage.release();
+	c->pinned.release();
 	free_func_t f = c->free_func;
 	c->~libdeflate_compressor();
 	f(c);
@@ -210,51 +211,52 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 		set_error("compress_batch_host: NULL argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	std::vector<uint64_t> desc(5 * n);
+	/* device layout: [in_off in_n out_off out_av out_n cmp_off...] [inputs]
+	 * [output slots] [compacted outputs]; everything 16-byte aligned */
+	const size_t ncmp = libdeflate_amd_compact_offsets_len(n);
+	std::vector<uint64_t> desc(5 * n + ncmp);
 	uint64_t *in_off = &desc[0], *in_n = &desc[n], *out_off = &desc[2 * n],
-		 *out_av = &desc[3 * n];
-	size_t pos = align_up(5 * n * 8, 64);
+		 *out_av = &desc[3 * n], *out_n = &desc[4 * n], *cmp_off = &desc[5 * n];
+	size_t pos = align_up(desc.size() * 8, 64);
 	for (size_t i = 0; i < n; i++) {
 		in_off[i] = pos;
 		in_n[i] = in_nbytes[i];
 		pos = align_up(pos + in_nbytes[i] + 16, 16);
 	}
+	size_t total_avail = 0;
 	for (size_t i = 0; i < n; i++) {
 		out_off[i] = pos;
 		out_av[i] = out_avail[i];
 		pos = align_up(pos + out_avail[i] + 16, 16);
+		total_avail += out_avail[i];
 	}
-	uint8_t *st = (uint8_t *)c->stage.reserve(pos + 64);
+	const size_t cmp_at = pos;
+	uint8_t *st = (uint8_t *)c->stage.reserve(cmp_at + total_avail + 64);
 	if (!st)
 		return LIBDEFLATE_AMD_OOM;
-	LDA_HIP_TRY(hipMemcpy(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice),
-		    LIBDEFLATE_AMD_NO_DEVICE);
-	for (size_t i = 0; i < n; i++)
-		if (in_nbytes[i])
-			LDA_HIP_TRY(hipMemcpy(st + in_off[i], in[i], in_nbytes[i],
-					      hipMemcpyHostToDevice),
-				    LIBDEFLATE_AMD_NO_DEVICE);
-	uint64_t *d_desc = (uint64_t *)st;
-	int rc = libdeflate_amd_compress_batch(c, format, n, st, d_desc,
-					       d_desc + n, st, d_desc + 2 * n,
-					       d_desc + 3 * n, d_desc + 4 * n,
-					       NULL);
+	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
+				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
+	int rc = copy_in_packed(&c->pinned, st, n, in, in_nbytes, in_off, nullptr);
 	if (rc != LIBDEFLATE_AMD_OK)
 		return rc;
-	LDA_HIP_TRY(hipDeviceSynchronize(), LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipMemcpy(&desc[4 * n], d_desc + 4 * n, n * 8,
-			      hipMemcpyDeviceToHost), LIBDEFLATE_AMD_NO_DEVICE);
-	for (size_t i = 0; i < n; i++) {
-		out_nbytes[i] = desc[4 * n + i];
-		if (out_nbytes[i])
-			LDA_HIP_TRY(hipMemcpy(out[i], st + out_off[i],
-					      out_nbytes[i],
-					      hipMemcpyDeviceToHost),
-				    LIBDEFLATE_AMD_NO_DEVICE);
-	}
-	return LIBDEFLATE_AMD_OK;
+	uint64_t *d_desc = (uint64_t *)st;
+	rc = libdeflate_amd_compress_batch(c, format, n, st, d_desc, d_desc + n, st,
+					   d_desc + 2 * n, d_desc + 3 * n,
+					   d_desc + 4 * n, NULL);
+	if (rc != LIBDEFLATE_AMD_OK)
+		return rc;
+	rc = libdeflate_amd_compact_batch(n, st, d_desc + 2 * n, d_desc + 4 * n,
+					  st + cmp_at, d_desc + 5 * n, NULL);
+	if (rc != LIBDEFLATE_AMD_OK)
+		return rc;
+	LDA_HIP_TRY(hipMemcpyAsync(out_n, d_desc + 4 * n, (n + n + 1) * 8,
+				   hipMemcpyDeviceToHost, nullptr),
+		    LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipStreamSynchronize(nullptr), LIBDEFLATE_AMD_NO_DEVICE);
+	for (size_t i = 0; i < n; i++)
+		out_nbytes[i] = out_n[i];
+	return copy_out_packed(&c->pinned, st + cmp_at, n, out, out_n, cmp_off, nullptr);
 }
-
 
 /*
  * One LARGE buffer: the input is cut into sub-ranges
@@ -307,6 +309,18 @@ static uint32_t adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b)
 	return (b << 16) | a;
 }
 
+/* a device failure inside a single-buffer call: reported, and the call returns
+ * 0 like any other "could not produce the stream" (libdeflate.h:73-74); the
+ * reason is in libdeflate_amd_last_error() */
+static size_t large_fail(const char *what)
+{
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		set_error("%s: %s", what, hipGetErrorString(e));
+	complain("libdeflate_*_compress", LIBDEFLATE_AMD_NO_DEVICE);
+	return 0;
+}
+
 static size_t compress_large(struct libdeflate_compressor *c, int format,
 			     const uint8_t *in, size_t n, uint8_t *out,
 			     size_t out_avail)
@@ -328,8 +342,10 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	size_t desc_bytes = align_up(nseg * (5 * 8 + 4 + 4), 64);
 	size_t in_at = desc_bytes, out_at = align_up(in_at + n + 64, 64);
 	uint8_t *st = (uint8_t *)c->stage.reserve(out_at + nseg * slot + 64);
-	if (!st)
-		die_no_device("libdeflate_*_compress (device memory)");
+	if (!st) {
+		complain("libdeflate_*_compress (device memory)", LIBDEFLATE_AMD_OOM);
+		return 0;
+	}
 	std::vector<uint64_t> d64(5 * nseg);
 	std::vector<uint32_t> d32(2 * nseg);
 	uint64_t *in_off = &d64[0], *in_n = &d64[nseg], *out_off = &d64[2 * nseg],
@@ -348,12 +364,12 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	if (hipMemcpy(d_desc, d64.data(), 4 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(st + in_at, in, n, hipMemcpyHostToDevice) != hipSuccess)
-		die_no_device("libdeflate_*_compress (copy in)");
+		return large_fail("copy in");
 	int rc = compress_batch_impl(c, LIBDEFLATE_AMD_DEFLATE, nseg, st, d_desc,
 				     d_desc + nseg, st, d_desc + 2 * nseg,
 				     d_desc + 3 * nseg, d_desc + 4 * nseg, NULL, d_seg);
 	if (rc != LIBDEFLATE_AMD_OK)
-		die_no_device("libdeflate_*_compress");
+		return large_fail("kernel launch");
 	if (ftr) {
 		/* per-piece checksums of the pieces themselves (no dictionary) */
 		std::vector<uint64_t> po(2 * nseg);
@@ -364,19 +380,19 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 		/* reuse the in_off / in_n rows after the kernel has consumed them */
 		if (hipDeviceSynchronize() != hipSuccess ||
 		    hipMemcpy(d_desc, po.data(), 2 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess)
-			die_no_device("libdeflate_*_compress (checksum setup)");
+			return large_fail("checksum setup");
 		rc = format == LIBDEFLATE_AMD_GZIP ?
 			libdeflate_amd_crc32_batch(nseg, st, d_desc, d_desc + nseg,
 						   NULL, d_sums, NULL) :
 			libdeflate_amd_adler32_batch(nseg, st, d_desc, d_desc + nseg,
 						     NULL, d_sums, NULL);
 		if (rc != LIBDEFLATE_AMD_OK)
-			die_no_device("libdeflate_*_compress (checksum)");
+			return large_fail("checksum");
 	}
 	if (hipDeviceSynchronize() != hipSuccess ||
 	    hipMemcpy(&d64[4 * nseg], d_desc + 4 * nseg, 8 * nseg, hipMemcpyDeviceToHost) != hipSuccess ||
 	    (ftr && hipMemcpy(&d32[nseg], d_sums, 4 * nseg, hipMemcpyDeviceToHost) != hipSuccess))
-		die_no_device("libdeflate_*_compress (copy out)");
+		return large_fail("copy out");
 	size_t total = hdr + ftr;
 	for (size_t i = 0; i < nseg; i++) {
 		if (d64[4 * nseg + i] == 0)
@@ -389,7 +405,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	for (size_t i = 0; i < nseg; i++) {
 		size_t sz = d64[4 * nseg + i];
 		if (hipMemcpy(out + at, st + out_off[i], sz, hipMemcpyDeviceToHost) != hipSuccess)
-			die_no_device("libdeflate_*_compress (copy out)");
+			return large_fail("copy out");
 		at += sz;
 	}
 	if (format == LIBDEFLATE_AMD_GZIP) {
@@ -439,8 +455,10 @@ static size_t compress_one(struct libdeflate_compressor *c, int format,
 	int rc = libdeflate_amd_compress_batch_host(c, format, 1, ins, &in_nbytes,
 						    outs, &out_avail, &got);
 
-	if (rc != LIBDEFLATE_AMD_OK)
-		die_no_device("libdeflate_*_compress");
+	if (rc != LIBDEFLATE_AMD_OK) {
+		complain("libdeflate_*_compress", rc);
+		return 0;
+	}
 	return got;
 }
 

@@ -21,12 +21,154 @@ void set_error(const char *fmt, ...)
 	va_end(ap);
 }
 
-[[noreturn]] void die_no_device(const char *what)
+[[noreturn]] void die(const char *what)
 {
 	fprintf(stderr,
-		"libdeflate_amd: %s needs a gfx950 (MI355X) device and none is "
-		"usable (%s). This library has no CPU fallback.\n", what, g_err);
+		"libdeflate_amd: %s failed on the gfx950 device (%s) and this "
+		"call has no error return. This library has no CPU fallback.\n",
+		what, g_err);
 	abort();
+}
+
+void complain(const char *what, int status)
+{
+	fprintf(stderr, "libdeflate_amd: %s: status %d (%s)\n", what, status, g_err);
+}
+
+bool PinnedPair::ensure()
+{
+	if (cap)
+		return true;
+	for (int b = 0; b < 2; b++) {
+		hipError_t e = hipHostMalloc((void **)&buf[b], LDA_PINNED_SLICE,
+					     hipHostMallocDefault);
+		if (e == hipSuccess)
+			e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+		if (e != hipSuccess) {
+			set_error("pinned staging: %s", hipGetErrorString(e));
+			release();
+			return false;
+		}
+	}
+	cap = LDA_PINNED_SLICE;
+	return true;
+}
+
+void PinnedPair::release()
+{
+	for (int b = 0; b < 2; b++) {
+		if (buf[b])
+			(void)hipHostFree(buf[b]);
+		if (ev[b])
+			(void)hipEventDestroy(ev[b]);
+		buf[b] = nullptr;
+		ev[b] = nullptr;
+	}
+	cap = 0;
+}
+
+int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
+		   const void *const *in, const size_t *in_nbytes,
+		   const uint64_t *off, hipStream_t st)
+{
+	if (!pp->ensure())
+		return LIBDEFLATE_AMD_OOM;
+	int b = 0;
+	bool used[2] = { false, false };
+	for (size_t i = 0; i < n;) {
+		if (in_nbytes[i] > pp->cap) {	/* one huge chunk: straight from the caller */
+			LDA_HIP_TRY(hipMemcpyAsync(d_base + off[i], in[i], in_nbytes[i],
+						   hipMemcpyHostToDevice, st),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+			i++;
+			continue;
+		}
+		const uint64_t s0 = off[i];
+		size_t j = i;
+		while (j < n && off[j] + in_nbytes[j] - s0 <= pp->cap)
+			j++;
+		if (used[b])
+			LDA_HIP_TRY(hipEventSynchronize(pp->ev[b]), LIBDEFLATE_AMD_NO_DEVICE);
+		for (size_t k = i; k < j; k++)
+			if (in_nbytes[k])
+				memcpy(pp->buf[b] + (off[k] - s0), in[k], in_nbytes[k]);
+		const uint64_t span = off[j - 1] + in_nbytes[j - 1] - s0;
+		if (span)
+			LDA_HIP_TRY(hipMemcpyAsync(d_base + s0, pp->buf[b], span,
+						   hipMemcpyHostToDevice, st),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+		LDA_HIP_TRY(hipEventRecord(pp->ev[b], st), LIBDEFLATE_AMD_NO_DEVICE);
+		used[b] = true;
+		b ^= 1;
+		i = j;
+	}
+	/* the pinned buffers are reused by the caller's next step */
+	for (b = 0; b < 2; b++)
+		if (used[b])
+			LDA_HIP_TRY(hipEventSynchronize(pp->ev[b]), LIBDEFLATE_AMD_NO_DEVICE);
+	return LIBDEFLATE_AMD_OK;
+}
+
+int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
+		    void *const *out, const uint64_t *nbytes,
+		    const uint64_t *off, hipStream_t st)
+{
+	if (!pp->ensure())
+		return LIBDEFLATE_AMD_OOM;
+	struct slice { size_t i, j; uint64_t s0, span; int b; };
+	auto next_slice = [&](size_t i, int b, slice *s) {
+		while (i < n && nbytes[i] == 0)
+			i++;
+		s->i = s->j = i;
+		s->b = b;
+		s->span = 0;
+		if (i >= n)
+			return;
+		s->s0 = off[i];
+		size_t j = i;
+		if (nbytes[i] > pp->cap) {
+			s->j = i + 1;
+			s->span = nbytes[i];
+			return;
+		}
+		while (j < n && off[j] + nbytes[j] - s->s0 <= pp->cap) {
+			if (nbytes[j])
+				s->span = off[j] + nbytes[j] - s->s0;
+			j++;
+		}
+		s->j = j;
+	};
+	auto issue = [&](const slice &s) -> int {
+		if (s.i >= n)
+			return LIBDEFLATE_AMD_OK;
+		if (s.span > pp->cap)	/* one huge chunk: straight to the caller */
+			LDA_HIP_TRY(hipMemcpyAsync(out[s.i], d_base + s.s0, s.span,
+						   hipMemcpyDeviceToHost, st),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+		else
+			LDA_HIP_TRY(hipMemcpyAsync(pp->buf[s.b], d_base + s.s0, s.span,
+						   hipMemcpyDeviceToHost, st),
+				    LIBDEFLATE_AMD_NO_DEVICE);
+		LDA_HIP_TRY(hipEventRecord(pp->ev[s.b], st), LIBDEFLATE_AMD_NO_DEVICE);
+		return LIBDEFLATE_AMD_OK;
+	};
+	slice cur, nxt;
+	next_slice(0, 0, &cur);
+	int rc = issue(cur);
+	while (rc == LIBDEFLATE_AMD_OK && cur.i < n) {
+		next_slice(cur.j, cur.b ^ 1, &nxt);
+		rc = issue(nxt);	/* in flight while this one is unpacked */
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		LDA_HIP_TRY(hipEventSynchronize(pp->ev[cur.b]), LIBDEFLATE_AMD_NO_DEVICE);
+		if (cur.span <= pp->cap)
+			for (size_t k = cur.i; k < cur.j; k++)
+				if (nbytes[k])
+					memcpy(out[k], pp->buf[cur.b] + (off[k] - cur.s0),
+					       nbytes[k]);
+		cur = nxt;
+	}
+	return rc;
 }
 
 #define MAX_DEVICES 16

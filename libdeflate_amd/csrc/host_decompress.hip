@@ -112,6 +112,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->scratch.release();
 	d->stage.release();
 	d->tokens.release();
+	d->pinned.release();
 	free_func_t f = d->free_func;
 	d->~libdeflate_decompressor();
 	f(d);
@@ -272,41 +273,38 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 	uint8_t *st = (uint8_t *)d->stage.reserve(pos + 64);
 	if (!st)
 		return LIBDEFLATE_AMD_OOM;
-	LDA_HIP_TRY(hipMemcpy(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice),
-		    LIBDEFLATE_AMD_NO_DEVICE);
-	for (size_t i = 0; i < n; i++)
-		if (in_nbytes[i])
-			LDA_HIP_TRY(hipMemcpy(st + in_off[i], in[i], in_nbytes[i],
-					      hipMemcpyHostToDevice),
-				    LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
+				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
+	int rc = copy_in_packed(&d->pinned, st, n, in, in_nbytes, in_off, nullptr);
+	if (rc != LIBDEFLATE_AMD_OK)
+		return rc;
 	uint64_t *d_desc = (uint64_t *)st;
 	int32_t *d_res = (int32_t *)(st + 6 * n * 8);
-	int rc = libdeflate_amd_decompress_batch(
+	rc = libdeflate_amd_decompress_batch(
 		d, format, n, st, d_desc, d_desc + n, st, d_desc + 2 * n,
 		d_desc + 3 * n, d_res, d_desc + 4 * n,
 		actual_out ? d_desc + 5 * n : NULL, NULL);
 	if (rc != LIBDEFLATE_AMD_OK)
 		return rc;
-	LDA_HIP_TRY(hipDeviceSynchronize(), LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipMemcpy(&desc[4 * n], d_desc + 4 * n, 2 * n * 8,
-			      hipMemcpyDeviceToHost), LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipMemcpy(results, d_res, n * 4, hipMemcpyDeviceToHost),
+	LDA_HIP_TRY(hipMemcpyAsync(&desc[4 * n], d_desc + 4 * n, 2 * n * 8,
+				   hipMemcpyDeviceToHost, nullptr),
 		    LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipMemcpyAsync(results, d_res, n * 4, hipMemcpyDeviceToHost,
+				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
+	LDA_HIP_TRY(hipStreamSynchronize(nullptr), LIBDEFLATE_AMD_NO_DEVICE);
 	(void)out_begin;
+	/* bytes to bring back per chunk: the produced ones of successful chunks
+	 * (output is undefined on failure, libdeflate.h:216-217) */
+	std::vector<uint64_t> nout(n);
 	for (size_t i = 0; i < n; i++) {
+		const bool ok = results[i] == LIBDEFLATE_SUCCESS;
 		if (actual_in)
-			actual_in[i] = results[i] == 0 ? desc[4 * n + i] : 0;
+			actual_in[i] = ok ? desc[4 * n + i] : 0;
 		if (actual_out)
-			actual_out[i] = results[i] == 0 ? desc[5 * n + i] : 0;
-		if (results[i] != LIBDEFLATE_SUCCESS)
-			continue;	/* output undefined on failure */
-		size_t nout = actual_out ? desc[5 * n + i] : out_avail[i];
-		if (nout)
-			LDA_HIP_TRY(hipMemcpy(out[i], st + out_off[i], nout,
-					      hipMemcpyDeviceToHost),
-				    LIBDEFLATE_AMD_NO_DEVICE);
+			actual_out[i] = ok ? desc[5 * n + i] : 0;
+		nout[i] = !ok ? 0 : actual_out ? desc[5 * n + i] : out_avail[i];
 	}
-	return LIBDEFLATE_AMD_OK;
+	return copy_out_packed(&d->pinned, st, n, out, nout.data(), out_off, nullptr);
 }
 
 /* ---- the single-buffer calls: batches of one ---- */
@@ -324,8 +322,15 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 		d, format, 1, ins, &in_nbytes, outs, &out_avail, &res, &ain,
 		actual_out_ret ? &aout : NULL);
 
-	if (rc != LIBDEFLATE_AMD_OK)
-		die_no_device("libdeflate_*_decompress");
+	if (rc != LIBDEFLATE_AMD_OK) {
+		/* the reference never aborts: a library-side failure comes back
+		 * through the result (the reason is in libdeflate_amd_last_error):
+		 * no memory for the staged output -> INSUFFICIENT_SPACE, anything
+		 * else -> BAD_DATA */
+		complain("libdeflate_*_decompress", rc);
+		return rc == LIBDEFLATE_AMD_OOM ? LIBDEFLATE_INSUFFICIENT_SPACE :
+						  LIBDEFLATE_BAD_DATA;
+	}
 	if (res == LIBDEFLATE_SUCCESS) {
 		if (actual_in_ret)
 			*actual_in_ret = ain;

@@ -34,6 +34,7 @@ struct libdeflate_decompressor {
 	lda::DevBuf scratch;	/* per-chunk u32 sums + u64 actual_in/out */
 	lda::DevBuf stage;	/* host-pointer entry points */
 	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
+	lda::PinnedPair pinned;	/* host-pointer entry points */
 };
 
 struct libdeflate_compressor {
@@ -41,6 +42,7 @@ struct libdeflate_compressor {
 	int level;
 	lda::DevBuf scratch;	/* parse/encode workspace + per-chunk sums */
 	lda::DevBuf stage;
+	lda::PinnedPair pinned;	/* host-pointer entry points */
 };
 
 #endif /* LDA_HOST_OBJECTS_H */

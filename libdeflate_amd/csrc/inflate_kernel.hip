@@ -1327,6 +1327,11 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					dst[(len & ~7ull) + lane] = src[(len & ~7ull) + lane];
 				wave_sync();	/* later matches read these bytes */
 				if (state == ST_STORED) {
+					/* the register history describes the bytes before
+					 * the stored block: a short-distance match of the
+					 * next block must not be served from it */
+					if (stored_left)
+						hist_n = 0;
 					out_pos += stored_left;
 					rpos += stored_left;
 					bitbuf = 0;
@@ -1346,6 +1351,8 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 			}
 			for (; k < stored_left; k++)
 				dst[k] = src[k];
+			if (stored_left)
+				hist_n = 0;	/* see the wave mode above */
 			out_pos += stored_left;
 			rpos += stored_left;
 			bitbuf = 0;

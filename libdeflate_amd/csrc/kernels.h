@@ -1,6 +1,6 @@
 /*
  * kernels.h - device entry points shared between the .hip translation units
- * and the host side of the C-ABI (host_api.hip).
+ * and the host side of the C-ABI (host_*.hip).
  */
 #ifndef LDA_KERNELS_H
 #define LDA_KERNELS_H
@@ -71,7 +71,19 @@ extern "C" size_t lda_deflate_seq_words(void);	/* u64 match-list entries per wor
 extern "C" size_t lda_inflate_lds_per_stream(void);
 extern "C" size_t lda_inflate_lds_shared(void);
 
-/* CRC constant tables, generated on the host at first use (host_api.hip) */
+/* compact_kernels.hip */
+extern "C" __global__ void
+lda_scan_local_kernel(uint64_t n, const uint64_t *sizes, uint64_t *offsets,
+		      uint64_t *block_sums);
+extern "C" __global__ void
+lda_scan_blocks_kernel(uint64_t nblocks, uint64_t *block_sums);
+extern "C" __global__ void
+lda_compact_copy_kernel(uint64_t n, const uint8_t *in_base,
+			const uint64_t *in_offsets, const uint64_t *sizes,
+			uint8_t *out_base, uint64_t *offsets,
+			const uint64_t *block_sums);
+
+/* CRC constant tables, generated on the host at first use (host_context.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)
 #define LDA_CRC_XPOW_WORDS 1024
 

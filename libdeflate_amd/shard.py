@@ -47,8 +47,14 @@ def gather_verdicts(sizes, results, dist, world):
 
 
 def compact(payload, offsets, sizes):
-    """Concatenate the used part of each output slot (host-side helper for the
-    payload gather; returns a uint8 tensor on payload's device)."""
+    """Concatenate the used part of each output slot into one uint8 tensor on
+    payload's device.  On a GPU this is the device-side compaction of the
+    C-ABI (prefix sum of the sizes + one gather-copy kernel, no per-chunk host
+    work); CPU tensors (the gloo tests) are concatenated with torch."""
+    if payload.is_cuda:
+        from . import api
+        packed, off = api.compact_batch(payload, offsets, sizes)
+        return packed[:int(off[-1].item())]
     parts = [payload[int(o):int(o) + int(s)] for o, s in
              zip(offsets.tolist(), sizes.tolist())]
     return torch.cat(parts) if parts else payload[:0]

@@ -269,3 +269,97 @@ def garbage_cases(seed, count):
         avail = rng.choice([0, 10, 1000, 70000])
         cases.append((fmt, s, avail, True, f"garbage{it}"))
     return cases
+
+
+# ---- static-Huffman helpers (RFC 1951 3.2.6) ----
+
+def _static_lit(w, sym):
+    if sym < 144:
+        w.put_code(0x30 + sym, 8)
+    elif sym < 256:
+        w.put_code(0x190 + sym - 144, 9)
+    elif sym < 280:
+        w.put_code(sym - 256, 7)
+    else:
+        w.put_code(0xC0 + sym - 280, 8)
+
+
+_LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51,
+          59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LXB = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4,
+        5, 5, 5, 5, 0]
+
+
+def _static_match(w, length, dist):
+    s = max(i for i in range(29) if _LBASE[i] <= length)
+    _static_lit(w, 257 + s)
+    w.put(length - _LBASE[s], _LXB[s])
+    d = dist - 1
+    if d < 4:
+        slot, xb, xv = d, 0, 0
+    else:
+        hb = d.bit_length() - 1
+        slot, xb = 2 * hb + ((d >> (hb - 1)) & 1), hb - 1
+        xv = d & ((1 << xb) - 1)
+    w.put_code(slot, 5)
+    w.put(xv, xb)
+
+
+def stored_then_match_streams():
+    """[Huffman block][non-empty stored block][Huffman block that opens with a
+    short-distance match]: the decoder must take the match's source from the
+    stored bytes, not from what preceded them.  -> list of (stream, expected).
+    Sizes under and over 64 input bytes, stored lengths 1..300."""
+    out = []
+    for head, stored, (mlen, mdist), tail in [
+            (b"abcdefgh", b"XYZ", (3, 1), b""),
+            (b"abcdefgh", b"XYZ", (8, 3), b"!"),
+            (b"q", b"Z", (5, 1), b"end"),
+            (b"hello, hello", b"0123456789" * 30, (7, 2), b"tail" * 20),
+            (b"", b"AB", (6, 2), b""),
+            (b"12345678", bytes(range(65, 73)), (8, 8), b"zz"),
+            (b"12345678", bytes(range(65, 75)), (4, 7), b"")]:
+        w = BitWriter()
+        w.put(0, 1); w.put(1, 2)                 # static block, not final
+        for b in head:
+            _static_lit(w, b)
+        _static_lit(w, 256)
+        w.put(0, 1); w.put(0, 2)                 # stored block
+        if w.n:
+            w.put(0, 8 - w.n)
+        w.put(len(stored), 16); w.put(len(stored) ^ 0xFFFF, 16)
+        for b in stored:
+            w.put(b, 8)
+        w.put(1, 1); w.put(1, 2)                 # final static block
+        _static_match(w, mlen, mdist)
+        for b in tail:
+            _static_lit(w, b)
+        _static_lit(w, 256)
+        sofar = bytearray(head + stored)
+        for _ in range(mlen):
+            sofar.append(sofar[-mdist])
+        out.append((w.finish(), bytes(sofar) + tail))
+    return out
+
+
+def gzip_optional_field_streams():
+    """VALID gzip members that carry FEXTRA / FNAME / FCOMMENT / FHCRC in every
+    combination (lib/gzip_decompress.c:69-100 skips them) -> (stream, data)."""
+    import struct
+    out = []
+    for flg in range(0, 32, 2):        # FHCRC 2, FEXTRA 4, FNAME 8, FCOMMENT 16
+        data = datagen.text_chunk(300 + 37 * flg, 0x0E1100F0 + flg)
+        body = _zcompress("deflate", 6, data)
+        h = bytearray(b"\x1f\x8b\x08" + bytes([flg]) + b"\x12\x34\x56\x78\x02\x03")
+        if flg & 4:
+            extra = bytes(range(flg + 3))
+            h += struct.pack("<H", len(extra)) + extra
+        if flg & 8:
+            h += b"file-name.txt\x00"
+        if flg & 16:
+            h += b"a comment\x00"
+        if flg & 2:
+            h += struct.pack("<H", zlib.crc32(bytes(h)) & 0xFFFF)
+        s = bytes(h) + body + struct.pack("<II", zlib.crc32(data), len(data))
+        out.append((s, data))
+    return out

@@ -257,3 +257,77 @@ def test_both_mappings_agree(dec, oracle, monkeypatch):
         assert a[0] == b[0]
         if a[0] == 0:
             assert a[1:] == b[1:]
+
+
+def test_stored_block_then_short_match(dec, oracle, monkeypatch):
+    """[Huffman][non-empty stored][Huffman opening with a short-distance
+    match], in both mappings, raw and inside gzip/zlib (a stale register
+    history would give wrong bytes / a false checksum failure)."""
+    import struct
+    cases = []
+    for i, (s, want) in enumerate(streams.stored_then_match_streams()):
+        cases.append(("deflate", s, len(want), True, f"stored{i}"))
+        cases.append(("deflate", s, len(want), False, f"stored{i}/exact"))
+        g = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + s + \
+            struct.pack("<II", zlib.crc32(want), len(want))
+        cases.append(("gzip", g, len(want), True, f"stored{i}/gzip"))
+        z = b"\x78\x9c" + s + struct.pack(">I", zlib.adler32(want))
+        cases.append(("zlib", z, len(want), True, f"stored{i}/zlib"))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        _run_cases(dec, oracle, cases)
+        for i, (s, want) in enumerate(streams.stored_then_match_streams()):
+            assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
+
+
+def test_gzip_optional_header_fields(dec, oracle):
+    """Valid members with FEXTRA / FNAME / FCOMMENT / FHCRC are decoded, not
+    just rejected consistently (lib/gzip_decompress.c:69-100)."""
+    cases = []
+    for i, (s, want) in enumerate(streams.gzip_optional_field_streams()):
+        cases.append(("gzip", s, len(want), True, f"flg{2 * i}"))
+        cases.append(("gzip", s + b"trailing", len(want), False, f"flg{2 * i}/exact"))
+        # truncated inside the optional fields / with a reserved flag bit
+        cases.append(("gzip", s[:14], len(want), True, f"flg{2 * i}/cut"))
+        cases.append(("gzip", s[:3] + bytes([s[3] | 0x20]) + s[4:], len(want), True,
+                      f"flg{2 * i}/reserved"))
+    _run_cases(dec, oracle, cases)
+    for s, want in streams.gzip_optional_field_streams():
+        assert dec.decompress_ex("gzip", s, len(want)) == (0, len(s), len(want), want)
+
+
+def test_config4_full_count(dec):
+    """BASELINE configs[3] at its full count: 65 536 reference-compressed gzip
+    streams of the 64 KiB mix (4 GiB out), exact-fill mode, every byte
+    compared on the device; the streams beyond the resident grid are handed
+    out dynamically."""
+    import torch
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    n, size, distinct = 65536, 65536, 64
+    chunks = datagen.batch(distinct, size, 0x0E110004)
+    comp = [ref.compress("gzip", 6, c) for c in chunks]
+    offs, blob = [], bytearray()
+    for z in comp:
+        offs.append(len(blob))
+        blob += z
+        blob += bytes((-len(blob)) % 16)
+    blen = len(blob)
+    reps = n // distinct
+    d_in = torch.cat([torch.frombuffer(blob, dtype=torch.uint8).cuda().repeat(reps),
+                      torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    gi = torch.arange(n, device="cuda")
+    in_off = torch.tensor(offs, dtype=torch.int64).cuda()[gi % distinct] + (gi // distinct) * blen
+    in_n = torch.tensor([len(z) for z in comp], dtype=torch.int64).cuda()[gi % distinct]
+    d_out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+    out_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+    out_av = torch.full((n,), size, dtype=torch.int64, device="cuda")
+    res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    dec.decompress_batch("gzip", d_in, in_off, in_n, d_out, out_off, out_av, res)
+    torch.cuda.synchronize()
+    assert int((res != 0).sum()) == 0
+    want = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+    assert torch.equal(d_out.view(reps, distinct * size),
+                       want.expand(reps, distinct * size))

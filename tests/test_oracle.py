@@ -161,3 +161,19 @@ def test_config1_reference_benchmark(tmp_path):
     line = [l for l in r.stdout.splitlines() if "Compressed 1048576 =>" in l][0]
     pct = float(line.split("(")[1].split("%")[0])
     assert 25.0 < pct < 40.0, line      # target ratio 30-38 %
+
+
+def test_stored_then_match_and_gzip_fields(oracle, ref):
+    """The hand-built streams the GPU tests use: oracle == reference == zlib."""
+    import zlib
+    for s, want in streams.stored_then_match_streams():
+        assert zlib.decompress(s, -15) == want
+        for chk in (oracle, ref):
+            assert chk.decompress_ex("deflate", s, len(want)) == (0, len(s), len(want), want)
+    for s, want in streams.gzip_optional_field_streams():
+        assert zlib.decompress(s, 31) == want
+        for chk in (oracle, ref):
+            assert chk.decompress_ex("gzip", s, len(want)) == (0, len(s), len(want), want)
+        bad = s[:3] + bytes([s[3] | 0x20]) + s[4:]
+        assert oracle.decompress_ex("gzip", bad, len(want))[0] == \
+            ref.decompress_ex("gzip", bad, len(want))[0] == 1

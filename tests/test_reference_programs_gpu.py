@@ -46,3 +46,29 @@ def test_reference_benchmark_on_gpu_library(tmp_path, args):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "Compressed 1048576 =>" in r.stdout
     print(r.stdout[-300:])
+
+
+def test_soname_drop_in_without_relinking(tmp_path):
+    """A binary linked against the reference's SONAME (libdeflate.so.0,
+    SURVEY.md 8(b)) - here programs/benchmark.c linked against the reference
+    itself - runs on the GPU library when a directory holding the alias
+    libdeflate.so.0 -> libdeflate_amd.so (libdeflate_amd/csrc/Makefile makes
+    one next to the library) is put on its library path: no relinking."""
+    exe = os.path.join(DIR, "benchmark_soname")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/reftests not built")
+    f = _enwik_file(tmp_path)
+    libdir = str(tmp_path / "alias")
+    os.mkdir(libdir)
+    os.symlink(os.path.join(ROOT, "libdeflate_amd", "libdeflate_amd.so"),
+               os.path.join(libdir, "libdeflate.so.0"))
+    for path, want in ((DIR, "reftests/libdeflate.so.0"),
+                       (libdir, "alias/libdeflate.so.0")):
+        env = dict(os.environ, LD_LIBRARY_PATH=path, LD_DEBUG="libs")
+        r = subprocess.run([exe, "-6", "-s", "65536", f], capture_output=True,
+                           text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        assert "Compressed 1048576 =>" in r.stdout
+        loaded = [ln for ln in r.stderr.splitlines()
+                  if "calling init" in ln and "libdeflate" in ln]
+        assert any(want in ln for ln in loaded), (want, loaded)
