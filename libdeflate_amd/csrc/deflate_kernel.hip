@@ -59,7 +59,9 @@
 
 #define NT LDA_DEFLATE_THREADS
 #define NWAVES (NT / 64)
+#ifndef TILE
 #define TILE 4096
+#endif
 #define RING 32768u
 #define RMASK (RING - 1)
 #define LOOKAHEAD 272u
@@ -71,15 +73,14 @@
  * The matches of the current block live in HBM (8 bytes each, one list per
  * workgroup): nothing of a block has to stay in LDS until the block is
  * written, so a block can be as long as a whole 64 KiB buffer, like the
- * reference's for homogeneous data.  There is no adaptive block splitting
- * (lib/deflate_compress.c:2092-2218) yet: blocks end at tile boundaries once
- * they reach MAX_BLOCK_LEN, which bounds the cost of content that changes
- * inside a buffer.
+ * reference's for homogeneous data.  Blocks end where the content changes
+ * (the observation classes of lib/deflate_compress.c:2092-2218, evaluated per
+ * tile, see "block end?") or once they reach MAX_BLOCK_LEN.
  */
 #define MAX_BLOCK_LEN 65536u
 #define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
 #define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
-#define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256)	/* u64 words of HBM scratch per workgroup */
+#define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256 + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
 #define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
@@ -93,6 +94,20 @@
 #ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
 #endif
+#ifndef S3_RA_DEPTH
+#define S3_RA_DEPTH 4u		/* chain members the shallow pass measures at every position (hidden behind the insertion of the next tile) */
+#endif
+#ifndef S3_ITEMS_PER_WAVE
+#define S3_ITEMS_PER_WAVE 384u	/* round B: one more wave joins per so many items */
+#endif
+#ifndef S3_RULE_FIRST
+#define S3_RULE_FIRST 0		/* round 1 from a parse (0) or from a local rule (1, 2) */
+#endif
+#ifndef S3_ROUNDS
+#define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
+#endif
+#define WQ_CAP 2048u		/* round B items per round; the rest waits for the next round */
+#define WQ_SEG (WQ_CAP / NWAVES)
 #define STG_WORDS ((TILE + 8) / 2 - 8)	/* staging: STG_WORDS + 8 words = sizeof nxtA */
 
 #define M_FIRST 0x10000u
@@ -105,7 +120,7 @@ struct deflate_lds {
 	u16 head[1u << HASH_BITS];
 	u16 head3[1u << HASH3_BITS];	/* last position per 3-byte hash (no chain) */
 	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
-	u8 mark[TILE + 8];	/* 1 = literal chosen at this position */
+	u8 done[TILE + 8];	/* search depth class a position has had: DC_* */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
 	union {
 		struct {	/* live only while a block is being finished */
@@ -124,7 +139,12 @@ struct deflate_lds {
 	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 obs[1][10];		/* block-split observations of the block before this tile */
-	u32 vars[20];
+	u32 vars[24];
+	u64 pm[TILE / 64];	/* parse: token starts of the tile, one bit per position */
+	u64 nh[TILE / 64 + 2];	/* positions the parse consulted as look-ahead */
+	u64 lit1[TILE / 64];	/* step of the position is 1 (a literal) */
+	u64 lit2[TILE / 64];	/* step is 2 (two literals, lazy2 deferral) */
+	u32 qn[4];		/* round B: item counts of three generations in rotation */
 };
 
 /* LDS-resident: every pointer into the block carries the address space, and
@@ -144,8 +164,14 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
 	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY,
-	V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT
+	V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT, V_WCNT
 };
+
+/* depth classes of the progressive search (done[]): what a position has been
+ * searched with so far */
+#define DC_SHALLOW 0	/* the first, shallow pass over all positions */
+#define DC_HALF 1	/* depth / 2: consulted as lazy look-ahead */
+#define DC_FULL 2	/* full depth: a token starts here */
 
 struct level_params {
 	u32 depth;
@@ -1006,6 +1032,809 @@ static __device__ __forceinline__ void stg_save(lds_t *L, struct outstate *os)
 	__syncthreads();
 }
 
+/* ---------------- chain construction without a sort ---------------- */
+
+/*
+ * Masked exchange of one u16 half of an LDS dword, returning the old dword
+ * (ds_mskor_rtn_b32: MEM = (MEM & ~mask) | val).  Lanes of ONE instruction
+ * that hit the same address are served in ascending lane order on gfx950
+ * (measured: tools/hwtest_lds_order.hip, run by tests/test_abi_gpu.py), and a
+ * wave's LDS instructions execute in issue order.  So when the lanes of a
+ * wave are consecutive positions, "exchange my position into head[hash]"
+ * returns to every lane what a serial insertion loop would have found there:
+ * the previous position with its hash, whether that is in the same group of
+ * 64 or an earlier one.  That replaces the per-group sort and the ordered
+ * threading of the groups (lib/hc_matchfinder.h:360-399 is the serial loop).
+ * The asm has no wait: the caller waits once for a batch (lds_wait8).
+ */
+static __device__ __forceinline__ u32 lds_mskor_rtn(u32 byteaddr, u32 mask, u32 val)
+{
+	u32 old;
+	asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3"
+		     : "=v"(old) : "v"(byteaddr), "v"(mask), "v"(val) : "memory");
+	return old;
+}
+
+/* wait for the LDS results above; the operands tie the uses to the wait */
+static __device__ __forceinline__ void lds_wait8(u32 *o)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)"
+		     : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]),
+		       "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]) :: "memory");
+}
+
+#define HEAD_OFF ((u32)offsetof(struct deflate_lds, head))
+#define HEAD3_OFF ((u32)offsetof(struct deflate_lds, head3))
+
+/* hash word of a position in M[]: 4-byte hash | M_VALID | 3-byte hash << 19 | valid3 << 31 */
+#define MH_H3_SHIFT 19
+#define MH_V3 0x80000000u
+
+/*
+ * ONE wave inserts the positions [t, tend) into the hash chains (head[] /
+ * prev[], masked exchange, see above), another one into the single-slot
+ * 3-byte table (plain read + write: duplicates inside a group of 64 all get the slot's
+ * content from before the group, which only hides length-3 candidates 9..63
+ * bytes back; the distances 1..8 are probed in registers anyway), leaving the
+ * 3-byte candidate of every position in c3[] (HBM scratch: it is consumed a
+ * tile later).  Position order, 8 groups of 64 in flight.  An LDS atomic with return costs ~3 cycles per lane on the whole
+ * CU whichever wave issues it (measured: spreading the buckets over 16 waves
+ * by hash made the stage slower), so the insertion runs on one wave, one tile
+ * AHEAD, beside the other waves' shallow search of the current tile.
+ */
+static __device__ __forceinline__ void
+insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 lane)
+{
+	const u32 ngroups = (tend - t + 63) / 64;
+
+	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
+		u32 o[8], sh[8];
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			const u32 p = t + (g0 + k) * 64 + lane;
+			const u32 h = hash4(ld32(L->in, p));
+			const bool ok = g0 + k < ngroups && p + 4 <= n;
+			sh[k] = (h & 1) << 4;
+			/* a lane without a position exchanges nothing (mask 0) */
+			o[k] = lds_mskor_rtn(HEAD_OFF + ((h >> 1) << 2),
+					     ok ? 0xFFFFu << sh[k] : 0,
+					     ok ? (p & 0xFFFF) << sh[k] : 0);
+			sh[k] |= ok ? 0x100 : 0;
+		}
+		lds_wait8(o);
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			const u32 i = (g0 + k) * 64 + lane;
+			if (sh[k] & 0x100)
+				L->prev[(t + i) & RMASK] = (u16)(o[k] >> (sh[k] & 31));
+		}
+	}
+}
+
+/* the 3-byte table's share of the insertion, on a wave of its own */
+static __device__ __forceinline__ void
+insert_tile3(lds_t *L, u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lane)
+{
+	const u32 ngroups = (tend - t + 63) / 64;
+
+	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
+		u32 h3[8], v[8];
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			const u32 p = t + (g0 + k) * 64 + lane;
+			h3[k] = g0 + k < ngroups && p + 3 <= n ?
+				hash3(ld32(L->in, p)) : 0xFFFFFFFFu;
+		}
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			v[k] = 0x8000;
+			if (h3[k] != 0xFFFFFFFFu) {
+				v[k] = L->head3[h3[k]];
+				L->head3[h3[k]] = (u16)(t + (g0 + k) * 64 + lane);
+			}
+		}
+#pragma unroll
+		for (u32 k = 0; k < 8; k++)
+			if (h3[k] != 0xFFFFFFFFu)
+				c3[4 + (g0 + k) * 64 + lane] = (u16)v[k];
+	}
+}
+
+/* ---------------- match measurement ---------------- */
+
+/*
+ * Length of the match of position p against cp (both absolute), for the
+ * lanes with ev set; every lane of the wave must call it (matches longer
+ * than 28 bytes are measured by the whole wave, 256 bytes per pass).  cur =
+ * bytes p..p+3, nxt8 = bytes p+4..p+11.  0 when the first four bytes differ.
+ */
+static __device__ __forceinline__ u32
+match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
+	     u32 maxlen, u32 lane)
+{
+	u64 x = nxt8 ^ ld64(L->in, cp + 4);
+	u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
+	ev = ev && ld32(L->in, cp) == cur;
+	bool more = ev && x == 0 && 12 < maxlen;
+	/* bytes 12..27 lane by lane; only longer matches go to the wave */
+	if (__ballot(more)) {
+		u64 y = ld64(L->in, p + 12) ^ ld64(L->in, cp + 12);
+		if (more) {
+			len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
+			more = y == 0 && 20 < maxlen;
+		}
+		if (__ballot(more)) {
+			u64 z = ld64(L->in, p + 20) ^ ld64(L->in, cp + 20);
+			if (more) {
+				len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
+				more = z == 0 && 28 < maxlen;
+			}
+		}
+	}
+	for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
+		u32 src = (u32)__builtin_ctzll(mm);
+		u32 bp = bcast_lane(p, src);
+		u32 bc = bcast_lane(cp, src);
+		u32 bmax = bcast_lane(maxlen, src);
+		u32 off = 28 + 4 * lane;
+		u32 x4 = off < bmax ?
+			(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
+		u64 ne = __ballot(x4 != 0);
+		u32 tot = bmax;	/* 28 + 256 >= 258 */
+		if (ne) {
+			u32 kk = (u32)__builtin_ctzll(ne);
+			u32 xk = bcast_lane(x4, kk);
+			u32 o = 28 + 4 * kk;
+			if (o < bmax)
+				tot = o + ((u32)__builtin_ctz(xk) >> 3);
+		}
+		if (lane == src)
+			len = tot;
+	}
+	if (len > maxlen)
+		len = maxlen;
+	return ev ? len : 0;
+}
+
+/* ---------------- progressive search ---------------- */
+
+/*
+ * The reference searches only where a token can start and where the lazy
+ * rule looks ahead (lib/deflate_compress.c:2604-2808); the positions inside
+ * its matches are merely inserted.  On text that is a third of the positions
+ * and a seventh of the chain steps of "search everything".  The parse is
+ * serial, so the positions it will visit are not known in advance; they are
+ * found by iteration instead:
+ *   round A   EVERY position gets a shallow search (the `ra_depth` nearest
+ *             chain members, measured in full) + the length-3 probes;
+ *   parse     the lazy / greedy rule over the results so far (parse_tile());
+ *   round B   the token starts of that parse are searched to the full depth,
+ *             the positions its lazy rule consulted to half of it
+ *             (:2712-2721), each position at most once per class; then the
+ *             parse is repeated, and so on until the parse visits nothing
+ *             new (or a round limit).  At the fixed point the result IS a
+ *             serial lazy parse with full-depth searches at what it visits.
+ * Measured on the 64 KiB mix (CPU model of this scheme, scratch/sim_mf.c):
+ * 3.9 chain steps per position instead of 15.0 at level 6 on text, output
+ * 0.03 % smaller than the serial parse after two rounds.
+ */
+static __device__ __forceinline__ void
+round_a(lds_t *L, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lo_pos,
+	u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3, u32 tid)
+{
+	const u32 lane = tid & 63, wave = tid >> 6;
+
+	/* the last two waves are inserting the next tile meanwhile */
+#pragma unroll 1
+	for (u32 g = wave; g < TILE / 64; g += NWAVES - 2) {
+		const u32 i = 64 * g + lane, p = t + i;
+		const u32 c3v = min_len <= 3 ? c3[4 + i] : 0;
+		bool act = p < tend && p + 4 <= n;
+		const u32 cur = ld32(L->in, p);
+		const u64 nxt8 = ld64(L->in, p + 4);
+		const u32 maxlen = n - p < 258 ? n - p : 258;
+		const u32 dmaxp = p - lo_pos;
+		const u32 nic = nice < maxlen ? nice : maxlen;
+		u32 c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
+		u32 best = 3, bestd = 0, dprev = 0;
+
+		for (u32 s = 0; s < ra_depth; s++) {
+			u32 d = (p - c16) & 0xFFFF;
+			act = act && d > dprev && d <= dmaxp && best < nic;
+			if (!__ballot(act))
+				break;
+			u32 cp = p - d;
+			u32 len = match_length(L, act, p, cp, cur, nxt8, maxlen, lane);
+			if (len > best) {
+				best = len;
+				bestd = d;
+			}
+			if (act) {
+				c16 = LDS16(PREV_OFF + 2 * (cp & RMASK));
+				dprev = d;
+			}
+		}
+		u32 m = best >= 4 && best >= min_len ? best | (bestd << 16) : 0;
+		if (m == 0 && min_len <= 3 && p < tend && p + 3 <= n) {
+			u32 b3 = 0;
+			u32 bd = find_len3(L, p, cur, c3v, dmaxp, dlim3, &b3);
+			if (bd)
+				m = 3 | (bd << 16);
+		}
+		L->M[4 + i] = m;
+		/* a chain that ended inside the shallow pass has been searched in full */
+		const u32 dn = (p - c16) & 0xFFFF;
+		L->done[4 + i] = (u8)(act && dn > dprev && dn <= dmaxp && best < nic ?
+				      done_class : DC_FULL);
+	}
+}
+
+/*
+ * The parse, part 1 (whole workgroup, position-parallel): the step of every
+ * position of the tile, token_step(q): 1 = literal, 2 = two literals, else
+ * the match length - kept as two bitmaps (step 1, step 2) per 64 positions;
+ * the length of a match step is in M[].  The caller puts a barrier after it.
+ */
+static __device__ __forceinline__ void
+stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
+{
+	const u32 lane = tid & 63, wave = tid >> 6;
+
+#pragma unroll
+	for (u32 k = 0; k < TILE / NT; k++) {
+		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane, idx = q + 4;
+		u32 st = 1;
+		if ((s32)q < limit)
+			st = token_step(L->M[idx], L->M[idx + 1], L->M[idx + 2], mode, nice);
+		const u64 b1 = __ballot(st == 1), b2 = __ballot(st == 2);
+		if (lane == 0) {
+			L->lit1[g] = b1;
+			L->lit2[g] = b2;
+		}
+	}
+}
+
+/* the step of tile position q after stage_steps() */
+static __device__ __forceinline__ u32 step_of(const lds_t *L, u32 q)
+{
+	if ((L->lit1[q >> 6] >> (q & 63)) & 1)
+		return 1;
+	if ((L->lit2[q >> 6] >> (q & 63)) & 1)
+		return 2;
+	return L->M[4 + q] & 0xFFFF;
+}
+
+/*
+ * Part 2, one wave: lane l walks the positions [64 l, 64 l + 64) by
+ * p -> p + step(p) (a run of literals in one go, through the bitmap), first
+ * from a guessed start (its first position), then - a parse started anywhere
+ * falls in step with the true one within a few tokens - from where the path
+ * of the lane before it really arrives, until it meets its own earlier
+ * path; repeated until no lane's arrival point changes (lane 0 starts at the
+ * true entry, so lane k is exact after k passes at the latest; measured 2-3
+ * passes).  Result: pm[l] = token starts in lane l's 64 positions, V_PEXIT =
+ * where the path leaves [0, limit).  entry >= 0.
+ */
+static __device__ __forceinline__ void
+parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit)
+{
+	const s32 seg_lo = 64 * (s32)lane;
+	const s32 hi = seg_lo + 64 < limit ? seg_lo + 64 : limit;
+	const u64 lit = lane < TILE / 64 ? L->lit1[lane] : 0;
+	const u64 two = lane < TILE / 64 ? L->lit2[lane] : 0;
+	s32 ein = lane == 0 ? entry : seg_lo;
+	s32 q = ein, ex = ein;
+	u64 mask = 0, nm = 0;
+	bool walking = q < hi;
+
+	for (;;) {
+		while (__ballot(walking)) {
+			if (walking) {
+				/* a run of literals, then one more token */
+				const u32 rel = (u32)(q - seg_lo);
+				u32 run = (u32)__builtin_ctzll(~(lit >> rel) | (1ull << 63));
+				if (run > (u32)(hi - q))
+					run = (u32)(hi - q);
+				u64 add = (((1ull << run) - 1) << rel);
+				q += (s32)run;
+				if (q < hi) {
+					const u32 r2 = (u32)(q - seg_lo);
+					add |= 1ull << r2;
+					q += (two >> r2) & 1 ? 2 : (s32)(L->M[4 + q] & 0xFFFF);
+				}
+				const u64 hit = add & mask;
+				if (hit) {	/* met my earlier path */
+					const u64 below = (hit & (0 - hit)) - 1;
+					mask = nm | (add & below) | (mask & ~below);
+					walking = false;
+				} else {
+					nm |= add;
+					if (q >= hi) {
+						mask = nm;
+						ex = q;
+						walking = false;
+					}
+				}
+			}
+		}
+		/* where the path of the lane before me leaves its positions */
+		s32 pe = (s32)__builtin_amdgcn_update_dpp((u32)ex, (u32)ex, 0x138, 0xF, 0xF, false);
+		const s32 e = lane == 0 ? entry : pe;
+		const bool redo = e != ein;
+		if (!__ballot(redo))
+			break;
+		nm = 0;
+		if (redo) {
+			ein = e;
+			if (e >= hi) {	/* the path jumps over my positions */
+				mask = 0;
+				ex = e;
+			} else {
+				q = e;
+				walking = true;
+			}
+		}
+	}
+	if (lane < TILE / 64)
+		L->pm[lane] = mask;
+	if (lane == 63)
+		L->vars[V_PEXIT] = (u32)ex;
+}
+
+/*
+ * What the parse in pm[] visited and has not been searched deeply enough:
+ * token starts -> DC_FULL, the positions the lazy rule looked at -> DC_HALF
+ * (lazy2's second look-ahead as well: a superset of what the rule reads).
+ * Positions whose match already reaches the nice length are left alone.
+ * Builds the worklist W[] (position | class << 12; search_queue() has the
+ * layout), returns its length (at most WQ_CAP: what does not fit is asked
+ * for again by the next parse).
+ * Whole workgroup, three barriers.
+ */
+static __device__ __forceinline__ u32
+build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
+{
+	const u32 lane = tid & 63, wave = tid >> 6;
+
+	if (tid < TILE / 64 + 2)
+		L->nh[tid] = 0;
+	if (tid == 0) {
+		L->vars[V_WCNT] = 0;
+		L->vars[V_CTR] = 0;	/* the search that follows claims from 0 */
+	}
+	__syncthreads();
+	if (by_rule && S3_RULE_FIRST == 1) {
+		/* Before the first parse: a position INSIDE a match run (one byte
+		 * shorter than its predecessor's match, same distance) is where a
+		 * parse hardly ever starts a token; everything else - the first
+		 * position of every run, every literal - may well be one (pm), and
+		 * the position after the start of a run is what the lazy rule will
+		 * look at (nh).  Saves a parse; the set is larger than what that
+		 * parse would have visited. */
+#pragma unroll
+		for (u32 k = 0; k < TILE / NT; k++) {
+			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+			const u32 m = L->M[4 + q], mp = L->M[3 + q];
+			const u32 l = m & 0xFFFF, lp = mp & 0xFFFF;
+			const bool inside = lp >= 4 && l + 1 == lp && (m >> 16) == (mp >> 16);
+			const u64 b = __ballot(!inside);
+			const u64 bl = __ballot(!inside && l >= 3 && l < nice && mode >= 1);
+			if (lane == 0) {
+				L->pm[g] = b;
+				if (bl) {
+					atomicOr((unsigned long long *)&L->nh[g], bl << 1);
+					if (bl >> 63)
+						atomicOr((unsigned long long *)&L->nh[g + 1], bl >> 63);
+				}
+			}
+		}
+	} else if (by_rule) {
+		/* Before the first parse: where can a token start?  With the
+		 * matches of the shallow pass, a position whose own match does not
+		 * reach beyond what the matches before it already cover is where
+		 * a parse hardly ever starts one.  What remains - the positions
+		 * that extend the covered range, and the literals outside it - is
+		 * searched deeply (pm), and the position after the start of such a
+		 * match is what the lazy rule will look at (nh).  reach(q) = q +
+		 * len(q); P(q) = max(entry, max of reach over r < q): an exclusive
+		 * prefix maximum over the tile (DPP scan per 64, the wave's four
+		 * groups in sequence, the waves through LDS).  Saves a parse. */
+		u32 rq[TILE / NT], ex[TILE / NT], run = 0;
+#pragma unroll
+		for (u32 k = 0; k < TILE / NT; k++) {
+			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+			const u32 l = L->M[4 + q] & 0xFFFF;
+			rq[k] = q + l;
+			u32 v = rq[k];
+			u32 o;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); v = o > v ? o : v;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); v = o > v ? o : v;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); v = o > v ? o : v;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); v = o > v ? o : v;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = o > v ? o : v;
+			o = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = o > v ? o : v;
+			/* exclusive: the inclusive maximum of the lane before */
+			u32 e = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
+			e = lane ? e : 0;
+			ex[k] = e > run ? e : run;
+			const u32 tot = (u32)__builtin_amdgcn_readlane((int)v, 63);
+			run = tot > run ? tot : run;
+		}
+		if (lane == 0)
+			L->scan[0][wave] = run;
+		__syncthreads();
+		const s32 ent = (s32)L->vars[V_ENTRY];
+		u32 pre = ent > 0 ? (u32)ent : 0;
+		for (u32 w = 0; w < wave; w++) {
+			const u32 c = L->scan[0][w];
+			pre = c > pre ? c : pre;
+		}
+#pragma unroll
+		for (u32 k = 0; k < TILE / NT; k++) {
+			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+			const u32 P = ex[k] > pre ? ex[k] : pre;
+			const u32 l = rq[k] - q;
+			const bool cand = l >= 3 ? rq[k] > P : q >= P;
+			const u64 b = __ballot(cand);
+			const u64 bl = __ballot(cand && l >= 3 && l < nice && mode >= 1);
+			if (lane == 0) {
+				L->pm[g] = b;
+				if (bl) {
+					atomicOr((unsigned long long *)&L->nh[g], bl << 1);
+					if (bl >> 63)
+						atomicOr((unsigned long long *)&L->nh[g + 1], bl >> 63);
+				}
+			}
+		}
+	} else if (mode >= 1) {
+#pragma unroll
+		for (u32 k = 0; k < TILE / NT; k++) {
+			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+			const u64 mask = L->pm[g];
+			const u32 l0 = L->M[4 + q] & 0xFFFF;
+			const bool la = ((mask >> lane) & 1) && l0 >= 3 && l0 < nice;
+			const u64 b = __ballot(la);
+			u64 lo = b << 1, hi = b >> 63;
+			if (mode >= 2) {
+				lo |= b << 2;
+				hi |= b >> 62;
+			}
+			if (lane == 0 && b) {
+				atomicOr((unsigned long long *)&L->nh[g], lo);
+				if (hi)
+					atomicOr((unsigned long long *)&L->nh[g + 1], hi);
+			}
+		}
+	}
+	__syncthreads();
+	/* ranks by a scan, not by atomics: which items fall under the cap must
+	 * not depend on timing */
+	u32 want[TILE / NT];
+	u64 bal[TILE / NT];
+	u32 cw = 0;
+#pragma unroll
+	for (u32 k = 0; k < TILE / NT; k++) {
+		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+		want[k] = ((L->pm[g] >> lane) & 1) ? DC_FULL :
+			  ((L->nh[g] >> lane) & 1) ? DC_HALF : DC_SHALLOW;
+		const bool add = want[k] > L->done[4 + q] &&
+				 (L->M[4 + q] & 0xFFFF) < nice;
+		bal[k] = __ballot(add);
+		cw += (u32)__builtin_popcountll(bal[k]);
+	}
+	if (lane == 0)
+		L->scan[0][wave] = cw;
+	__syncthreads();
+	u32 base = 0, wc = 0;
+#pragma unroll
+	for (u32 w = 0; w < NWAVES; w++) {
+		const u32 c = L->scan[0][w];
+		if (w < wave)
+			base += c;
+		wc += c;
+	}
+#pragma unroll
+	for (u32 k = 0; k < TILE / NT; k++) {
+		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+		const u32 j = base + (u32)__builtin_popcountll(bal[k] & ((1ull << lane) - 1));
+		if (((bal[k] >> lane) & 1) && j < WQ_CAP) {
+			W[j] = q | (want[k] << 12);
+			L->done[4 + q] = (u8)want[k];
+		}
+		base += (u32)__builtin_popcountll(bal[k]);
+	}
+	if (tid == 0)
+		L->qn[0] = 0;
+	__syncthreads();
+	return wc < WQ_CAP ? wc : WQ_CAP;
+}
+
+/*
+ * Deep search of a list of positions (round B; levels 10-12: all positions
+ * of the tile).  Chain lengths differ wildly between positions, so lanes do
+ * not own fixed items: a lane claims the next unsearched item from a
+ * workgroup counter when it finishes one.  The kernel is instruction-issue
+ * bound, so the search is split into two kinds of wave-uniform passes:
+ *   walk      S3_WALK chain steps per lane, nothing but the link chase and a
+ *             4-byte compare at the offset where a longer match must differ
+ *             (the zlib scan_end idea); hits are queued (<= 4 distances
+ *             packed in a u64);
+ *   evaluate  every lane pops its oldest (closest) hit and measures it
+ *             (match_length()).
+ * A position that was searched before (round A) starts from the match it
+ * already has, so the filter rejects whatever cannot beat it; its M[] entry
+ * is only rewritten when a longer match turns up.
+ * W == NULL: the items are the positions 0..cnt-1 themselves, searched from
+ * scratch at full depth (the last S3_TAIL positions of a tile - claimed when
+ * the other waves are about to run dry - at a reduced depth, chosen by
+ * position so that the output does not depend on timing).
+ * Whole workgroup; V_CTR must be 0 on entry (barrier in between).
+ */
+static __device__ __forceinline__ void
+search_items(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
+	     u32 nice, const u16 *W, u32 cnt_items, u32 nwaves, u32 tid)
+{
+	const u32 lane = tid & 63;
+	/* a short list is searched by few waves: a lane must get several items,
+	 * or every wave ends up waiting for the deepest of its 64 first ones */
+	if ((tid >> 6) >= nwaves)
+		return;
+	const u32 drain = depth < 8 ? depth : depth >> 3 > 8 ? depth >> 3 : 8;
+	const u32 half = depth >> 1 ? depth >> 1 : 1;
+	u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
+	    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
+	    cnt = 0, boff = 0, curb = 0, best0 = 3;
+	u64 nxt8 = 0, q = 0;
+	bool have = false, fin = true, ended = false;
+	PROF_SEC_DECL;
+
+	for (;;) {
+		PROF_SEC(3);
+		u64 mh = __ballot(have);
+		u32 nf = __builtin_popcountll(__ballot(fin));
+		if (!mh && !nf)
+			break;
+		if (nf && (nf >= S3_CLAIM || !mh)) {
+			/* one counter update per wave; ranks by ballot */
+			const u64 fm = __ballot(fin);
+			u32 cbase = 0;
+			if (lane == 0)
+				cbase = atomicAdd((u32 *)&L->vars[V_CTR], nf);
+			cbase = bcast_first(cbase);
+			if (fin) {
+				if (my_i < TILE && (!W || best > best0))
+					L->M[4 + my_i] = best >= 4 && best >= min_len ?
+						(best | (bestd << 16)) : 0;
+				fin = false;
+				my_i = 0xFFFFFFFFu;
+				u32 it = cbase + __builtin_popcountll(fm & ((1ull << lane) - 1));
+				if (it < cnt_items) {
+					u32 item = W ? W[it] : it;
+					my_i = item & 0xFFF;
+					p = t + my_i;
+					if (p + 4 <= n) {
+						cur = ld32(L->in, p);
+						nxt8 = ld64(L->in, p + 4);
+						c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
+						maxlen = n - p < 258 ? n - p : 258;
+						dmaxp = p - lo_pos;
+						best = 3;
+						bestd = 0;
+						if (W) {
+							dep = (item >> 12) == DC_FULL ? depth : half;
+							u32 m = L->M[4 + my_i], l0 = m & 0xFFFF;
+							if (l0 >= 4) {
+								best = l0;
+								bestd = m >> 16;
+							}
+						} else {
+							dep = my_i >= TILE - S3_TAIL ? drain : depth;
+						}
+						best0 = best;
+						boff = best - 3;
+						curb = boff ? ld32(L->in, p + boff) : cur;
+						dprev = 0;
+						cnt = 0;
+						ended = false;
+						have = true;
+						if (best >= maxlen) {	/* nothing longer exists */
+							have = false;
+							fin = true;
+						}
+					} else {
+						fin = true;	/* no 4-byte match can start here */
+						best = best0 = 3;
+					}
+				}
+			}
+			PROF_SEC(0);
+			continue;
+		}
+		/* walk */
+#pragma unroll
+		for (int s = 0; s < S3_WALK; s++) {
+			u32 d = (p - c16) & 0xFFFF;
+			bool chain = dep && d > dprev && d <= dmaxp;
+			bool stall = ended || cnt >= 4;
+			bool ok = !stall && chain;
+			u32 cp = p - d;
+			u32 w = ld32(L->in, cp + boff);
+			u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
+			bool hit = ok && w == curb;
+			c16 = ok ? c16n : c16;
+			dprev = ok ? d : dprev;
+			dep -= ok ? 1 : 0;
+			ended = ended || (!stall && !chain);
+			q = hit ? ((q << 16) | d) : q;
+			cnt += hit ? 1 : 0;
+		}
+		if (!have)
+			cnt = 0;
+		PROF_SEC(1);
+		/* evaluate: a round when enough lanes hold a hit, or when no lane
+		 * can walk any further */
+		bool done = false;
+		u32 nev = __builtin_popcountll(__ballot(cnt > 0));
+		u32 nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
+		while (nev && (nev >= S3_EVMIN || !nwalk)) {
+			bool ev = cnt > 0;
+			u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
+			cnt -= ev ? 1 : 0;
+			u32 len = match_length(L, ev, p, p - d, cur, nxt8, maxlen, lane);
+			if (ev && len > best) {
+				best = len;
+				bestd = d;
+				if (len >= nice || len >= maxlen) {
+					done = true;
+					cnt = 0;
+				} else {
+					boff = len - 3;
+					curb = ld32(L->in, p + boff);
+				}
+			}
+			if (have && (done || (ended && cnt == 0))) {
+				have = false;
+				fin = true;
+				done = false;
+			}
+			nev = __builtin_popcountll(__ballot(cnt > 0));
+			nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
+		}
+		if (have && ended && cnt == 0) {
+			have = false;
+			fin = true;
+		}
+		PROF_SEC(2);
+	}
+	PROF_SEC_FLUSH(17);
+}
+
+/*
+ * Round B: deep search of the worklist.  Chain depths differ wildly between
+ * positions (1 to `depth` steps), and a wave pays for its deepest lane, so
+ * the items are not walked to the end by the lane that takes them: the search
+ * proceeds in GENERATIONS of a few walk passes (8 chain steps each) per item.
+ * An item that is not finished after its quantum goes to the next
+ * generation's list with the place it reached (the last chain member
+ * visited, 16 bits), and the next generation takes the survivors packed 64 to
+ * a wave again: every walk pass runs with (nearly) all lanes on useful steps.
+ * Two lists alternate (WA, WB); one barrier per generation.
+ * List entry: tile position | depth class << 12 | last visited << 16.
+ * A position starts from the match it already has (M[]), so the filter
+ * (4 bytes at the offset where a longer match must differ) rejects whatever
+ * cannot beat it; M[] is rewritten only when a longer match turns up.
+ * Whole workgroup; ends with a barrier.
+ */
+static __device__ __forceinline__ void
+search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
+	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid)
+{
+	const u32 lane = tid & 63, wave = tid >> 6;
+	const u32 half = depth >> 1 ? depth >> 1 : 1;
+	const u32 npass = depth >= 256 ? 4 : depth >= 64 ? 2 : 1;	/* walk passes per generation */
+	const u32 quantum = 8 * npass;
+	const u64 lt = (1ull << lane) - 1;
+	u32 ncur = wc;
+
+	PROF_COUNT(15, wc);
+	PROF_COUNT(18, 1);
+	for (u32 gen = 0;; gen++) {
+		PROF_COUNT(16, 1);
+		PROF_COUNT(14, (ncur + 63) / 64);
+		PROF_COUNT(19, ncur);
+		AS3 u32 *cur_l = gen & 1 ? WB : WA, *nxt_l = gen & 1 ? WA : WB;
+		AS3 u32 *ctr = &L->qn[gen % 3];
+		if (tid == 0)
+			L->qn[(gen + 1) % 3] = 0;
+		for (u32 base = 64 * wave; base < ncur; base += 64 * NWAVES) {
+			const bool have = base + lane < ncur;
+			const u32 e = have ? cur_l[base + lane] : 0;
+			const u32 i = e & 0xFFF, p = t + i;
+			const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
+			u32 dep = quantum * gen < cdepth ? cdepth - quantum * gen : 0;
+			dep = dep < quantum ? dep : quantum;
+			const u32 cur = ld32(L->in, p);
+			const u64 nxt8 = ld64(L->in, p + 4);
+			const u32 maxlen = n - p < 258 ? n - p : 258;
+			const u32 dmaxp = p - lo_pos;
+			const u32 nic = nice < maxlen ? nice : maxlen;
+			const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
+			u32 best = l0 >= 4 ? l0 : 3, bestd = l0 >= 4 ? m >> 16 : 0;
+			const u32 best0 = best;
+			u32 boff = best - 3;
+			u32 curb = ld32(L->in, p + boff);
+			u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
+			u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
+			bool act = have && p + 4 <= n && best < nic && dep;
+			bool ended = false;
+			for (u32 ps = 0; ps < npass; ps++) {
+				u32 cnt = 0;
+				u64 qh = 0;
+#pragma unroll
+				for (int s = 0; s < 8; s++) {
+					u32 d = (p - c16) & 0xFFFF;
+					bool chain = dep && d > dprev && d <= dmaxp;
+					bool stall = ended || cnt >= 4;
+					bool ok = act && !stall && chain;
+					u32 cp = p - d;
+					u32 w = ld32(L->in, cp + boff);
+					u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
+					bool hit = ok && w == curb;
+					c16 = ok ? c16n : c16;
+					dprev = ok ? d : dprev;
+					dep -= ok ? 1 : 0;
+					ended = ended || (act && !stall && !chain);
+					qh = hit ? ((qh << 16) | d) : qh;
+					cnt += hit ? 1 : 0;
+					PROF_COUNT(20, __builtin_popcountll(__ballot(ok)));
+					PROF_COUNT(17, __builtin_popcountll(__ballot(hit)));
+				}
+				PROF_COUNT(13, __builtin_popcountll(__ballot(have)));
+				/* evaluate: every lane pops its oldest (closest) hit.  (Dealing
+				 * the wave's hits out to all lanes through LDS - they are a
+				 * third of a hit per lane - measured slower: the five
+				 * cross-lane fetches per round cost more than the rounds
+				 * saved.) */
+				while (__ballot(cnt > 0)) {
+					PROF_COUNT(21, 1);
+					const bool ev = cnt > 0;
+					const u32 d = (u32)(qh >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
+					cnt -= ev ? 1 : 0;
+					const u32 len = match_length(L, ev, p, p - d, cur, nxt8,
+								     maxlen, lane);
+					if (ev && len > best) {
+						best = len;
+						bestd = d;
+					}
+				}
+				if (best >= nic)
+					act = false;
+				if (npass > 1) {
+					if (!__ballot(act && !ended && dep))
+						break;
+					boff = best - 3;
+					curb = ld32(L->in, p + boff);
+				}
+			}
+			if (best > best0)
+				L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
+			const bool surv = act && !ended && quantum * (gen + 1) < cdepth;
+			const u64 b = __ballot(surv);
+			u32 at = 0;
+			if (lane == 0 && b)
+				at = atomicAdd((u32 *)ctr, (u32)__builtin_popcountll(b));
+			at = bcast_first(at);
+			if (surv)
+				nxt_l[at + __builtin_popcountll(b & lt)] =
+					(e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);
+		}
+		__syncthreads();
+		ncur = *(volatile AS3 u32 *)ctr;
+		if (!ncur)
+			break;
+	}
+}
+
 #ifdef LDA_DEBUG_SPLIT	/* per-tile trace of the block-split inputs of buffer 0 (debug builds) */
 static __device__ u32 lda_dbg[2048];
 extern "C" __attribute__((visibility("default"))) void libdeflate_amd_debug_read(u32 *out)
@@ -1055,6 +1884,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	/* levels 10-12: byte histogram of the block before the previous tile
 	 * [256] and of the previous tile [256] */
 	u32 *__restrict__ bsave = fsave + 640;
+	/* 3-byte-table candidate of every position of the current and of the
+	 * next tile (two halves, by tile parity): written by the inserting wave
+	 * one tile ahead, read by the shallow search */
+	u16 *__restrict__ c3g = (u16 *)(bsave + 512);
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
@@ -1170,8 +2003,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			const u32 tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
 
 			PROF_MARK(0);
-			/* ---- S0: stage input up to tend + LOOKAHEAD ---- */
-			u32 want = tend + LOOKAHEAD < n ? tend + LOOKAHEAD : n;
+			/* ---- S0: stage input up to the end of the NEXT tile + LOOKAHEAD
+			 * (the next tile is inserted into the chains while this one
+			 * is searched) ---- */
+			const u32 tend2 = t + 2 * TILE < n ? t + 2 * TILE : n;
+			u32 want = tend2 + LOOKAHEAD < n ? tend2 + LOOKAHEAD : n;
 			if (aligned_in) {
 				u32 from = loaded & ~15u;
 				for (u32 p = from + tid * 16; p < want; p += NT * 16) {
@@ -1189,10 +2025,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				}
 			}
 			loaded = want;
-			for (u32 i = tid; i < TILE + 8; i += NT)
-				L->mark[i] = 0;
 			if (tid < 4)
 				L->M[TILE + 4 + tid] = 0;
+			if (tid == 0)
+				L->vars[V_CTR] = 0;
 			__syncthreads();
 			if (!prime && !stored_only) {
 				/* minimum match length from the distinct bytes of this
@@ -1221,337 +2057,74 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 
 			PROF_MARK(1);
 			if (!stored_only) {
-				/* ---- S1: hash + in-wave sort -> local links ---- */
-#pragma unroll
-				for (u32 gi = 0; gi < TILE / 64 / NWAVES; gi++) {
-					u32 g = wave + NWAVES * gi;
-					u32 gb = t + g * 64;
-					u32 p = gb + lane;
-					bool valid = p + 4 <= n;
-					u32 w4 = ld32(L->in, p);
-					u32 h = valid ? hash4(w4) : (0x4000u | lane);
-					u32 key = (h << 6) | lane;
-					/* 3-byte hash rides along in M (bits 19..30) for S2;
-					 * written before the sort scatters the hash4 part */
-					u32 h3v = p + 3 <= n ? (hash3(w4) | 0x1000u) : 0;
-#define SORT_STEP(K, J)                                                        \
-	do {                                                                   \
-		u32 other = lane_xor<J>(key);                                  \
-		bool up = (lane & (K)) == 0, lower = (lane & (J)) == 0;        \
-		u32 mn = key < other ? key : other;                            \
-		u32 mx = key < other ? other : key;                            \
-		key = (lower == up) ? mn : mx;                                 \
-	} while (0)
-					SORT_STEP(2, 1);
-					SORT_STEP(4, 2); SORT_STEP(4, 1);
-					SORT_STEP(8, 4); SORT_STEP(8, 2); SORT_STEP(8, 1);
-					SORT_STEP(16, 8); SORT_STEP(16, 4); SORT_STEP(16, 2);
-					SORT_STEP(16, 1);
-					SORT_STEP(32, 16); SORT_STEP(32, 8); SORT_STEP(32, 4);
-					SORT_STEP(32, 2); SORT_STEP(32, 1);
-					SORT_STEP(64, 32); SORT_STEP(64, 16); SORT_STEP(64, 8);
-					SORT_STEP(64, 4); SORT_STEP(64, 2); SORT_STEP(64, 1);
-#undef SORT_STEP
-					/* neighbours: DPP wave shifts (lane 0 / 63 keep their own) */
-					u32 left = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xF, 0xF, false);
-					u32 right = __builtin_amdgcn_update_dpp(key, key, 0x130, 0xF, 0xF, false);
-					bool first = lane == 0 || (left >> 6) != (key >> 6);
-					bool last = lane == 63 || (right >> 6) != (key >> 6);
-					u32 orig = key & 63, hh = key >> 6;
-					bool isv = hh < 0x4000u;
-					if (isv && !first)
-						L->prev[(gb + orig) & RMASK] =
-							(u16)(gb + (left & 63));
-					L->nxtB[4 + g * 64 + lane] = (u16)h3v;
-					L->M[4 + g * 64 + orig] = hh |
-						(first ? M_FIRST : 0) |
-						(last ? M_LAST : 0) |
-						(isv ? M_VALID : 0);
-				}
-				if (tid == NT - 1) {
-					L->vars[V_CTR] = 0;
-					L->vars[V_READY] = 0;
-				}
-				__syncthreads();
-
-				PROF_MARK(2);
-				/* ---- S2: thread groups through head[] in order ----
-				 * Only wave 0 (hash chains) and wave 1 (3-byte table) do
-				 * this; chains only ever look backwards, so the other waves
-				 * start searching at once and wave 0 publishes how far the
-				 * chains are complete (V_READY) after every batch of groups;
-				 * claims beyond that wait. */
-				/* A wave's LDS operations execute in issue order, so the
-				 * read-old-head / write-new-head pairs of all groups are
-				 * issued back to back (no wait in between); the values read
-				 * are stored to prev[] afterwards. */
-				if (wave == 0) {
-					const u32 ngroups = (tend - t + 63) / 64;
-					enum { GB = 8 };	/* groups in flight */
-					for (u32 g0 = 0; g0 < ngroups; g0 += GB) {
-						u32 v[GB];
-#pragma unroll
-						for (u32 k = 0; k < GB; k++)
-							v[k] = g0 + k < ngroups ?
-								L->M[4 + (g0 + k) * 64 + lane] : 0;
-#pragma unroll
-						for (u32 k = 0; k < GB; k++) {
-							u32 m = v[k];
-							u32 h = m & ((1u << HASH_BITS) - 1);
-							u32 old = 0xFFFFFFFFu;
-							if (m & M_VALID) {
-								if (m & M_FIRST)
-									old = L->head[h];
-								if (m & M_LAST)
-									L->head[h] = (u16)(t + (g0 + k) * 64 + lane);
-							}
-							v[k] = old;
-						}
-#pragma unroll
-						for (u32 k = 0; k < GB; k++)
-							if (v[k] != 0xFFFFFFFFu)
-								L->prev[(t + (g0 + k) * 64 + lane) & RMASK] =
-									(u16)v[k];
-						/* LDS writes of a wave land in issue order */
-						if (lane == 0)
-							*(volatile u32 *)&L->vars[V_READY] =
-								g0 + GB < ngroups ? (g0 + GB) * 64 : TILE;
+				/* ---- S1 + S2: the NEXT tile joins the chains (one wave,
+				 * insert_tile()) beside the search of this one; the first
+				 * tile of a buffer has to be inserted up front ---- */
+				/* a search of a few steps is done in full by the first pass */
+				const bool ra_all = depth <= 4;
+				const bool use3 = true;
+				u16 *c3cur = c3g + (tile & 1) * (TILE + 8);
+				u16 *c3nxt = c3g + ((tile + 1) & 1) * (TILE + 8);
+				if (tile == 0) {
+					if (wave == NWAVES - 1)
+						insert_tile(L, t, tend, n, lane);
+					if (wave == NWAVES - 2 && use3) {
+						insert_tile3(L, c3cur, t, tend, n, lane);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					}
-					if (lane == 0)
-						*(volatile u32 *)&L->vars[V_READY] = TILE;
-				} else if (wave == 1) {
-					/* 3-byte table, same order, on its own wave: candidate
-					 * = last position of an EARLIER group with this hash */
-					const u32 ngroups = (tend - t + 63) / 64;
-					enum { GB = 16 };
-					for (u32 g0 = 0; g0 < ngroups; g0 += GB) {
-						u32 v[GB];
-#pragma unroll
-						for (u32 k = 0; k < GB; k++)
-							v[k] = g0 + k < ngroups ?
-								L->nxtB[4 + (g0 + k) * 64 + lane] : 0;
-#pragma unroll
-						for (u32 k = 0; k < GB; k++) {
-							u32 h3v = v[k], c3 = 0;
-							if (h3v) {
-								c3 = L->head3[h3v & 0xFFF];
-								L->head3[h3v & 0xFFF] =
-									(u16)(t + (g0 + k) * 64 + lane);
-							}
-							v[k] = c3;
-						}
-#pragma unroll
-						for (u32 k = 0; k < GB; k++)
-							if (g0 + k < ngroups)
-								L->nxtA[4 + (g0 + k) * 64 + lane] = (u16)v[k];
-					}
+					__syncthreads();
 				}
-				if (prime) {	/* chains primed; nothing to search or emit */
+				if (prime) {	/* dictionary tile: nothing to search or emit */
+					if (wave == NWAVES - 1 && !last_tile)
+						insert_tile(L, tend, tend2, n, lane);
+					if (wave == NWAVES - 2 && !last_tile && use3) {
+						insert_tile3(L, c3nxt, tend, tend2, n, lane);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					}
 					__syncthreads();
 					continue;
 				}
-
-				PROF_MARK(3);
-				/* ---- S3: all positions search their chain ----
-				 * Chain lengths differ wildly between positions, so lanes
-				 * do not own fixed positions: a lane claims the next
-				 * unsearched position from a workgroup counter when it
-				 * finishes one.  The kernel is instruction-issue bound, so
-				 * the search is split into two kinds of wave-uniform passes:
-				 *   walk      S3_WALK chain steps per lane, nothing but the
-				 *             link chase and the 4-byte compare; hits are
-				 *             queued (<= 4 distances packed in a u64);
-				 *   evaluate  every lane pops its oldest (closest) hit and
-				 *             measures it: 8 bytes against the cached bytes
-				 *             p+4..p+11, longer ones by the whole wave, 256
-				 *             bytes per pass.
-				 * Positions that end without a match >= 4 get their
-				 * length-3 probe in a separate position-parallel pass. */
-				{
-					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
-					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
-					const u32 min_len = L->vars[V_MINLEN];
-					const u32 drain = depth < 8 ? depth : depth >> 3 > 8 ? depth >> 3 : 8;
-					u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
-					    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
-					    cnt = 0, boff = 0, curb = 0;
-					u64 nxt8 = 0, q = 0;
-					bool have = false, fin = true, ended = false;
-					PROF_SEC_DECL;
-
-					for (;;) {
-						PROF_SEC(3);
-						u64 mh = __ballot(have);
-						u32 nf = __builtin_popcountll(__ballot(fin));
-						if (!mh && !nf)
-							break;
-						if (nf && (nf >= S3_CLAIM || !mh)) {
-							/* one counter update per wave; ranks by ballot */
-							const u64 fm = __ballot(fin);
-							u32 cbase = 0;
-							if (lane == 0)
-								cbase = atomicAdd((u32 *)&L->vars[V_CTR], nf);
-							cbase = bcast_first(cbase);
-							{	/* chains complete up to the claimed ones? */
-								const u32 need = cbase + nf < TILE ? cbase + nf : TILE;
-								if (cbase < TILE)
-									while (*(volatile u32 *)&L->vars[V_READY] < need)
-										__builtin_amdgcn_s_sleep(4);
-							}
-							if (fin) {
-								if (my_i < TILE)
-									L->M[4 + my_i] =
-										best >= 4 && best >= min_len ?
-										(best | (bestd << 16)) : 0;
-								fin = false;
-								best = 3;
-								my_i = cbase + __builtin_popcountll(fm & ((1ull << lane) - 1));
-								if (my_i < TILE) {
-									p = t + my_i;
-									if (p + 4 <= n) {
-										cur = ld32(L->in, p);
-										curb = cur;
-										boff = 0;
-										nxt8 = ld64(L->in, p + 4);
-										c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
-										maxlen = n - p < 258 ? n - p : 258;
-										dmaxp = p - lo_pos;
-										/* the last positions of a tile are claimed when
-										 * the other waves are about to run dry: they
-										 * search less deep (by position, so the output
-										 * does not depend on timing) */
-										dep = my_i >= TILE - S3_TAIL ? drain : depth;
-										bestd = 0;
-										dprev = 0;
-										cnt = 0;
-										ended = false;
-										have = true;
-									} else {
-										fin = true;	/* M = 0; len 3 later */
-									}
-								}
-							}
-							PROF_SEC(0);
-							continue;
-						}
-						/* walk */
-#pragma unroll
-						for (int s = 0; s < S3_WALK; s++) {
-							u32 d = (p - c16) & 0xFFFF;
-							bool chain = dep && d > dprev && d <= dmaxp;
-							bool stall = ended || cnt >= 4;
-							bool ok = !stall && chain;
-							u32 cp = p - d;
-							u32 w = ld32(L->in, cp + boff);
-							u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
-							bool hit = ok && w == curb;
-							c16 = ok ? c16n : c16;
-							dprev = ok ? d : dprev;
-							dep -= ok ? 1 : 0;
-							ended = ended || (!stall && !chain);
-							q = hit ? ((q << 16) | d) : q;
-							cnt += hit ? 1 : 0;
-						}
-						if (!have)
-							cnt = 0;
-						PROF_SEC(1);
-						/* evaluate: a round when enough lanes hold a hit, or
-						 * when no lane can walk any further */
-						bool done = false;
-						u32 nev = __builtin_popcountll(__ballot(cnt > 0));
-						u32 nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
-						while (nev && (nev >= S3_EVMIN || !nwalk)) {
-							bool ev = cnt > 0;
-							u32 d = (u32)(q >> (16 * ((cnt - 1) & 3))) & 0xFFFF;
-							cnt -= ev ? 1 : 0;
-							u32 cp = p - d;
-							u64 x = nxt8 ^ ld64(L->in, cp + 4);
-							u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
-							ev = ev && ld32(L->in, cp) == cur;
-							bool more = ev && x == 0 && 12 < maxlen;
-							/* bytes 12..27 lane by lane; only longer matches
-							 * go to the wave */
-							if (__ballot(more)) {
-								u64 y = ld64(L->in, p + 12) ^ ld64(L->in, cp + 12);
-								if (more) {
-									len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
-									more = y == 0 && 20 < maxlen;
-								}
-								if (__ballot(more)) {
-									u64 z = ld64(L->in, p + 20) ^ ld64(L->in, cp + 20);
-									if (more) {
-										len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
-										more = z == 0 && 28 < maxlen;
-									}
-								}
-							}
-							for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
-								u32 src = (u32)__builtin_ctzll(mm);
-								u32 bp = bcast_lane(p, src);
-								u32 bc = bcast_lane(cp, src);
-								u32 bmax = bcast_lane(maxlen, src);
-								u32 off = 28 + 4 * lane;
-								u32 x4 = off < bmax ?
-									(ld32(L->in, bp + off) ^
-									 ld32(L->in, bc + off)) : 1;
-								u64 ne = __ballot(x4 != 0);
-								u32 tot = bmax;	/* 28 + 256 >= 258 */
-								if (ne) {
-									u32 kk = (u32)__builtin_ctzll(ne);
-									u32 xk = bcast_lane(x4, kk);
-									u32 o = 28 + 4 * kk;
-									if (o < bmax)
-										tot = o + ((u32)__builtin_ctz(xk) >> 3);
-								}
-								if (lane == src)
-									len = tot;
-							}
-							if (ev) {
-								if (len > maxlen)
-									len = maxlen;
-								if (len > best) {
-									best = len;
-									bestd = d;
-									if (len >= nice || len >= maxlen) {
-										done = true;
-										cnt = 0;
-									} else {
-										boff = len - 3;
-										curb = ld32(L->in, p + boff);
-									}
-								}
-							}
-							if (have && (done || (ended && cnt == 0))) {
-								have = false;
-								fin = true;
-								done = false;
-							}
-							nev = __builtin_popcountll(__ballot(cnt > 0));
-							nwalk = __builtin_popcountll(__ballot(have && !ended && cnt < 4));
-						}
-						if (have && ended && cnt == 0) {
-							have = false;
-							fin = true;
-						}
-						PROF_SEC(2);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				PROF_MARK(2);
+				/* ---- S3: search (see "progressive search") ---- */
+				const u32 min_len = L->vars[V_MINLEN];
+				const u32 dlim3 = mode ? 8192u : 4096u;
+				s32 lo_s = (s32)(t + 2 * TILE + LOOKAHEAD) - (s32)RING;
+				const u32 lo_pos = lo_s > 0 ? (u32)lo_s : 0;
+				const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
+				if (wave == NWAVES - 1) {
+					if (!last_tile)
+						insert_tile(L, tend, tend2, n, lane);
+				} else if (wave == NWAVES - 2) {
+					if (!last_tile && use3) {
+						insert_tile3(L, c3nxt, tend, tend2, n, lane);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					}
-					PROF_SEC_FLUSH(17);
+				} else if (OPT && mode == 3) {
+					/* the min-cost parse prices every position: all of
+					 * them are searched to the full depth */
+					search_items(L, t, n, lo_pos, min_len, depth, nice,
+						     NULL, TILE, NWAVES - 2, tid);
+				} else {
+					round_a(L, c3cur, t, tend, n, lo_pos, min_len, ra_depth,
+						ra_all ? DC_FULL :
+						ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW,
+						nice, dlim3, tid);
 				}
-				__syncthreads();
-				PROF_MARK(16);
-				/* length-3 matches for the positions left without a match */
-				if (L->vars[V_MINLEN] <= 3) {
-					s32 lo = (s32)(t + TILE + LOOKAHEAD) - (s32)RING;
-					const u32 lo_pos = lo > 0 ? (u32)lo : 0;
-					const u32 dlim3 = mode ? 8192u : 4096u;
-					for (u32 i = tid; i < TILE; i += NT) {
-						u32 p = t + i, b3 = 0;
-						if (p + 3 <= n && L->M[4 + i] == 0) {
-							u32 bd = find_len3(L, p, ld32(L->in, p),
-									   L->nxtA[4 + i], p - lo_pos,
-									   dlim3, &b3);
-							if (bd)
-								L->M[4 + i] = 3 | (bd << 16);
+				if (OPT && mode == 3) {
+					__syncthreads();
+					PROF_MARK(16);
+					/* length-3 matches for the positions left without a match */
+					if (min_len <= 3) {
+						for (u32 i = tid; i < TILE; i += NT) {
+							u32 p = t + i, b3 = 0;
+							if (p + 3 <= n && L->M[4 + i] == 0) {
+								u32 bd = find_len3(L, p, ld32(L->in, p),
+										   c3cur[4 + i], p - lo_pos,
+										   dlim3, &b3);
+								if (bd)
+									L->M[4 + i] = 3 | (bd << 16);
+							}
 						}
 					}
 				}
@@ -1622,58 +2195,55 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					}
 					__syncthreads();
 				}
-				/* ---- S4: token choice by pointer jumping ----
+				/* ---- S4: token choice ----
 				 * step(p) is a pure function of M[p..p+2]; the chosen
 				 * tokens are the positions reachable from the entry point
-				 * by p -> p + step(p); idx = p + 4.  Each wave owns a
-				 * segment of 128 idx (the last one 132) and works without
-				 * workgroup barriers: 8 doubling rounds give, for every idx,
-				 * the first position its path reaches outside the segment;
-				 * after ONE barrier every wave chains the segment exits up
-				 * to its own entry point and marks its part of the path by
-				 * replaying the doubling steps from the largest down. */
-				{
-					const s32 entry = (s32)L->vars[V_ENTRY];
-					const s32 limit = last_tile ? (s32)(tend - t) :
-							  (s32)TILE - 2;
-					const u32 lim_idx = (u32)(limit + 4);
-					enum { SEG = TILE / NWAVES, SL = SEG / 64,
-					       JR = SEG == 128 ? 7 : 8 };	/* 2^JR >= SEG */
-					/* wave w owns idx [4 + SEG w, 4 + SEG (w + 1)); the
-					 * carried-in idx 2, 3 can only be the entry itself */
-					const u32 seg_lo = 4 + SEG * wave, seg_hi = seg_lo + SEG;
-					u16 *J = L->nxtA, *Jn = L->nxtB;
-					u32 jh[JR][SL], jc[SL];	/* J^(2^r) of the own idx */
-					u32 m0[SL];		/* M of the own idx */
-#pragma unroll
-					for (u32 k = 0; k < SL; k++) {
-						u32 idx = seg_lo + lane + 64 * k;
-						u32 p = idx - 4;
-						u32 nx = p;
-						m0[k] = L->M[idx];
-						if ((s32)p < limit)
-							nx = p + token_step(m0[k], L->M[idx + 1],
-									    L->M[idx + 2], s4mode, nice);
-						jc[k] = nx + 4;	/* stored as idx */
-						J[idx] = (u16)jc[k];
+				 * by p -> p + step(p); idx = p + 4.  One wave finds the path
+				 * (parse_tile()); between parses the positions the path
+				 * visits are searched deeper, until it visits nothing new
+				 * ("progressive search"). */
+				const s32 entry = (s32)L->vars[V_ENTRY];
+				const s32 limit = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
+				const u32 lim_idx = (u32)(limit + 4);
+				const u32 rounds = opt || ra_all ? 0 : S3_ROUNDS;
+				for (u32 r = 0;; r++) {
+					if (S3_RULE_FIRST && r == 0 && rounds) {
+						/* round 1 takes its positions from a local rule
+						 * instead of a parse */
+						const u32 wc0 = build_worklist(L, (AS3 u32 *)L->nxtB, true,
+									       s4mode, nice, tid);
+						if (wc0)
+							search_queue(L, t, n, lo_pos, min_len, depth, nice,
+								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA,
+								     wc0, tid);
+						PROF_MARK(3);
+						continue;
 					}
-					wave_sync();
-#pragma unroll
-					for (u32 r = 0; r < JR; r++) {
-#pragma unroll
-						for (u32 k = 0; k < SL; k++) {
-							u32 idx = seg_lo + lane + 64 * k;
-							u32 q = jc[k];
-							jh[r][k] = q;
-							if (q < seg_hi && q < lim_idx)
-								jc[k] = J[q];
-							Jn[idx] = (u16)jc[k];
-						}
-						wave_sync();
-						u16 *tmp = J; J = Jn; Jn = tmp;
-					}
+					/* the carried-in idx 2, 3 can only be the entry itself */
+					u32 e = (u32)(entry + 4);
+					for (u32 pre = 0; pre < 2; pre++)
+						if (e < 4 && e < lim_idx)
+							e += token_step(L->M[e], L->M[e + 1], L->M[e + 2],
+									s4mode, nice);
+					stage_steps(L, limit, s4mode, nice, tid);
+					__syncthreads();
+					if (wave == 0)
+						parse_tile(L, lane, (s32)e - 4, limit);
 					__syncthreads();
 					PROF_MARK(12);
+					if (r >= rounds)
+						break;
+					const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, false, s4mode, nice, tid);
+					if (wc == 0)
+						break;
+					search_queue(L, t, n, lo_pos, min_len, depth, nice,
+						     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
+					PROF_MARK(3);
+				}
+				{
+					enum { SEG = TILE / NWAVES, SL = SEG / 64 };
+					/* wave w owns idx [4 + SEG w, 4 + SEG (w + 1)) */
+					const u32 seg_lo = 4 + SEG * wave;
 					u32 e = (u32)(entry + 4);
 					const u32 seq0 = L->vars[V_NSEQ];
 					u32 npre = 0;
@@ -1685,12 +2255,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							u32 l0 = mm & 0xFFFF;
 							bool ism = st == l0 && l0;
 							if (tid == 0) {
-								s32 np = (s32)e - 4 + (s32)st;
 								u32 pos = (u32)((s32)t + (s32)e - 4);
-								if (e + st >= lim_idx) {
-									L->vars[V_WALKPOS_LO] = (u32)((s32)t + np);
-									L->vars[V_ENTRY] = (u32)(np - (s32)TILE);
-								}
 								if (ism) {
 									u32 sl, xb, xv;
 									seqg[seq0 + npre] = (pos - block_start) |
@@ -1709,48 +2274,23 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							e += st;
 						}
 					}
-					for (u32 sgm = 0; sgm < wave; sgm++)
-						if (e < 4 + SEG * (sgm + 1) && e < lim_idx)
-							e = J[e];
-					bool mk[SL];
-#pragma unroll
-					for (u32 k = 0; k < SL; k++) {
-						u32 idx = seg_lo + lane + 64 * k;
-						mk[k] = idx == e && e < lim_idx;
-					}
-#pragma unroll
-					for (s32 r = JR - 1; r >= 0; r--) {
-#pragma unroll
-						for (u32 k = 0; k < SL; k++) {
-							u32 q = jh[r][k];
-							if (mk[k] && q < seg_hi && q < lim_idx)
-								L->mark[q] = 1;
-						}
-						wave_sync();
-#pragma unroll
-						for (u32 k = 0; k < SL; k++) {
-							u32 idx = seg_lo + lane + 64 * k;
-							mk[k] = mk[k] || L->mark[idx];
-						}
-					}
-					PROF_MARK(13);
 					/* emit: the lanes on the path classify their token,
 					 * count it for the block's Huffman codes and append
 					 * the matches to seq[] in position order (ballot ranks
 					 * inside the wave, one workgroup scan across waves) */
 					bool ism[SL];
+					u32 m0[SL];
 #pragma unroll
 					for (u32 k = 0; k < SL; k++) {
-						u32 idx = seg_lo + lane + 64 * k;
-						u32 st = jh[0][k] - idx, l0 = m0[k] & 0xFFFF;
-						ism[k] = mk[k] && st == l0 && l0;
-						if (mk[k]) {
-							u32 pos = t + idx - 4;
-							if (idx + st >= lim_idx) {
-								s32 np = (s32)idx - 4 + (s32)st;
-								L->vars[V_WALKPOS_LO] = (u32)((s32)t + np);
-								L->vars[V_ENTRY] = (u32)(np - (s32)TILE);
-							}
+						const u32 idx = seg_lo + lane + 64 * k;
+						const bool mk = (L->pm[SL * wave + k] >> lane) & 1;
+						m0[k] = L->M[idx];
+						ism[k] = false;
+						if (mk) {
+							const u32 st = step_of(L, idx - 4);
+							const u32 l0 = m0[k] & 0xFFFF;
+							const u32 pos = t + idx - 4;
+							ism[k] = st == l0 && l0;
 							if (ism[k]) {
 								u32 sl, xb, xv;
 								length_code(l0, &sl, &xb, &xv);
@@ -1764,9 +2304,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							}
 						}
 					}
-					if (tid == 0 && entry >= limit) {
-						L->vars[V_WALKPOS_LO] = (u32)((s32)t + entry);
-						L->vars[V_ENTRY] = (u32)(entry - (s32)TILE);
+					if (tid == 0) {
+						/* where the path leaves the tile */
+						const s32 px = (s32)L->vars[V_PEXIT];
+						L->vars[V_WALKPOS_LO] = (u32)((s32)t + px);
+						L->vars[V_ENTRY] = (u32)(px - (s32)TILE);
 					}
 					u64 bal[SL];
 					u32 cw = 0;
@@ -1813,10 +2355,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				opt_build_costs(L, tid, opt_stage == 0, false, t, tend - t, bsave);
 				for (u32 i = tid; i < 320; i += NT)
 					L->freq[i] = 0;
-				for (u32 i = tid; i < TILE + 8; i += NT) {
-					L->mark[i] = 0;
+				for (u32 i = tid; i < TILE + 8; i += NT)
 					L->M[i] = msave[i];
-				}
 				if (tid == 0) {
 					L->vars[V_ENTRY] = ent0;
 					L->vars[V_NSEQ] = nseq0;
@@ -2086,7 +2626,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_NPRE] = ni;
 				}
 				__syncthreads();
-				PROF_MARK(21);
+				PROF_MARK(23);
 				if (wave == 0)
 					make_code(L->pre_freq, 19, 7, L->pre_lens, L->pre_codes,
 						  L->sorted, (huff_scratch<32> *)L->hw,

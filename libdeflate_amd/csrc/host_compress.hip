@@ -327,8 +327,9 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 {
 	const size_t S = LDA_SEG_BYTES;
 	const size_t tile = lda_deflate_tile();
-	/* usable window is 32 KiB minus a tile and the lookahead; whole tiles */
-	const size_t D = (32768 - tile - 272) / tile * tile;
+	/* usable window is 32 KiB minus two tiles (the kernel inserts one tile
+	 * ahead) and the lookahead; whole tiles */
+	const size_t D = (32768 - 2 * tile - 272) / tile * tile;
 	const size_t nseg = (n + S - 1) / S;
 	const size_t slot = align_up(libdeflate_deflate_compress_bound(c, S) + 32, 16);
 	const uint32_t hdr = format == LIBDEFLATE_AMD_GZIP ? 10 :

@@ -63,11 +63,11 @@ def main():
         bench_deflate(a, fmt=a.fmt, level=a.level)
 
 
-PHASES_DEFLATE = ["init/other", "S0 load", "S1 sort", "S2 link", "S3 search",
-                  "S4 walk", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
-                  "S4 doubling", "S4 chain+mark", "#walk passes (w0)", "#lanes walking at pass start",
-                  "S3 total (w0)", "S3 claim (w0)", "S3 walk (w0)", "S3 evaluate (w0)",
-                  "S3 loop (w0)", "S5 precode RLE (t0)", "S5 precode tree"]
+PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist", "S3 round A",
+                  "S4 emit", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
+                  "S4 parse", "#w0 item-passes", "#RB chunks", "#RB items (gen 0)",
+                  "#RB generations", "#w0 hits", "#RB rounds", "#RB item-generations",
+                  "#w0 chain steps", "#w0 evaluate rounds", "S5 precode tree"]
 
 
 def read_profile(name, labels):
