@@ -1,0 +1,25 @@
+"""Hardware behaviour the compress kernel relies on, measured on the device
+the tests run on: one LDS read-modify-write instruction serves the lanes that
+hit the SAME address in ascending lane order (tools/hwtest_lds_order.hip; the
+chain insertion of deflate_kernel.hip is a serial insertion loop only if that
+holds).  Undocumented, hence tested: a device that behaves differently must
+fail here, loudly, not compress a little worse."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lds_atomics_are_served_in_lane_order():
+    exe = os.path.join(ROOT, "tools", "hwtest_lds_order")
+    if not os.path.exists(exe):
+        pytest.skip("tools/hwtest_lds_order not built (__graft_entry__.build() builds it)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["lane_order"] is True and out["mismatches"] == 0
+    assert out["same_instruction_conflicts"] > 1_000_000     # the test did exercise conflicts

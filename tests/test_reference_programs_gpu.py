@@ -72,3 +72,30 @@ def test_soname_drop_in_without_relinking(tmp_path):
         loaded = [ln for ln in r.stderr.splitlines()
                   if "calling init" in ln and "libdeflate" in ln]
         assert any(want in ln for ln in loaded), (want, loaded)
+
+
+@pytest.mark.parametrize("args", [
+    ["-6", "-s", "65536", "-C", "mi355x", "-D", "libdeflate"],
+    ["-6", "-s", "65536", "-C", "libdeflate", "-D", "mi355x"],
+    ["-6", "-s", "65536", "-C", "mi355x", "-D", "libz", "-z"],
+    ["-1", "-g", "-s", "65536", "-B", "-C", "mi355x", "-D", "mi355x"],
+    ["-9", "-z", "-s", "4096", "-B", "-C", "mi355x", "-D", "libdeflate"],
+    ["-6", "-g", "-s", "4096", "-B", "-C", "libdeflate", "-D", "mi355x"],
+])
+def test_mi355x_engine_cross_checks(tmp_path, args):
+    """The reference's harness with the third engine (oracle/mi355x_engine.h):
+    the GPU library and the REAL reference in one process, each compressing
+    for the other on the 1 MiB enwik-style buffer; -B hands all chunks of the
+    file to the GPU engine in one call.  The harness verifies every chunk
+    itself (programs/benchmark.c:470-493)."""
+    exe = os.path.join(DIR, "benchmark_mi355x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/reftests not built")
+    r = subprocess.run([exe] + args + [_enwik_file(tmp_path)], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "Compressed 1048576 =>" in r.stdout
+    eng = [a for a in args if a in ("mi355x", "libdeflate", "libz")]
+    assert f"Compression engine: {eng[0]}" in r.stdout
+    assert f"Decompression engine: {eng[1]}" in r.stdout
+    print(r.stdout[-400:])
