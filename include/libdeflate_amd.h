@@ -315,6 +315,24 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 				     int32_t *results, size_t *actual_in,
 				     size_t *actual_out /* NULL allowed */);
 
+/*
+ * A gzip buffer of SEVERAL members (concatenated .gz files, pigz -i, BGZF).
+ * libdeflate_gzip_decompress decodes the first member only
+ * (lib/gzip_decompress.c:103-131, libdeflate.h:289-296); its caller loops, as
+ * programs/gzip.c:236-299 does.  This is that loop in one call: members that
+ * state their size (BGZF "BC" extra subfield) are indexed from their headers
+ * and decoded as ONE device batch, anything else member after member.  `out`
+ * receives the members' outputs back to back; fails with the first member's
+ * non-success result.  The three result pointers may be NULL.
+ */
+LIBDEFLATEAPI enum libdeflate_result
+libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
+				       const void *in, size_t in_nbytes,
+				       void *out, size_t out_nbytes_avail,
+				       size_t *actual_in_nbytes_ret,
+				       size_t *actual_out_nbytes_ret,
+				       size_t *members_ret);
+
 #ifdef __cplusplus
 }
 #endif

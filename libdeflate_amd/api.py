@@ -133,6 +133,18 @@ class Decompressor:
         nout = ao.value if want_actual_out else out_avail
         return r, ao.value, out[:nout].tobytes()
 
+    def gzip_decompress_members(self, data, out_avail):
+        """All members of a multi-member gzip buffer (the loop of
+        programs/gzip.c:236-299 in one call) -> (result, actual_in,
+        actual_out, members, bytes)."""
+        p, n = _buf(data)
+        out = np.zeros(max(out_avail, 1), dtype=np.uint8)
+        ai, ao, nm = c_size_t(0), c_size_t(0), c_size_t(0)
+        r = self._lib.libdeflate_amd_gzip_decompress_members(
+            self._h, p, n, out.ctypes.data_as(c_void_p), out_avail,
+            ctypes.byref(ai), ctypes.byref(ao), ctypes.byref(nm))
+        return r, ai.value, ao.value, nm.value, out[:ao.value].tobytes()
+
     def decompress_batch(self, fmt, data, in_offsets, in_nbytes, out,
                          out_offsets, out_avail, results, actual_in=None,
                          actual_out=None, stream=None):

@@ -43,6 +43,7 @@ BATCH_SYMBOLS = [
     "libdeflate_amd_compress_batch_host",
     "libdeflate_amd_decompress_batch_host",
     "libdeflate_amd_compact_offsets_len", "libdeflate_amd_compact_batch",
+    "libdeflate_amd_gzip_decompress_members",
 ]
 
 _lib = None
@@ -107,6 +108,7 @@ def load():
         P)
     sig("libdeflate_amd_decompress_batch_host", c_int, P, c_int, SZ, P, P, P,
         P, P, P, P)
+    sig("libdeflate_amd_gzip_decompress_members", c_int, P, P, SZ, P, SZ, psz, psz, psz)
     sig("libdeflate_amd_compact_offsets_len", SZ, SZ)
     sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib

@@ -95,10 +95,16 @@
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
 #endif
 #ifndef S3_RA_DEPTH
-#define S3_RA_DEPTH 4u		/* chain members the shallow pass measures at every position (hidden behind the insertion of the next tile) */
+#define S3_RA_DEPTH 2u		/* chain members the shallow pass measures at every position */
 #endif
 #ifndef S3_ITEMS_PER_WAVE
 #define S3_ITEMS_PER_WAVE 384u	/* round B: one more wave joins per so many items */
+#endif
+#ifndef INS_SPLIT
+#define INS_SPLIT 64u		/* groups of the next tile inserted beside round A, the rest beside the first parse (64 = all beside round A: splitting measured 1.5 % slower, round A itself is what that phase waits for) */
+#endif
+#ifndef S3_HALF
+#define S3_HALF 1		/* 0: the lazy rule's look-ahead positions are not searched deeper */
 #endif
 #ifndef S3_RULE_FIRST
 #define S3_RULE_FIRST 0		/* round 1 from a parse (0) or from a local rule (1, 2) */
@@ -729,6 +735,8 @@ template <int N> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 	  u16 *sorted, huff_scratch<N> *H, u32 used, bool presorted, u32 lane)
 {
+	PROF_DECL;
+	PROF_START();
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
 	if (!presorted) {
@@ -770,6 +778,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		if (lane < 40)
 			H->cntI[lane] = 0;
 		wave_sync();
+		if (N == 288) PROF_MARK(13);
 		if (lane == 0) {
 			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
 			 * creation order (ascending too); heads cached in registers
@@ -805,6 +814,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			}
 		}
 		wave_sync();
+		if (N == 288) PROF_MARK(14);
 		/* depth of every internal node by pointer jumping (root = m-2) */
 		{
 			const u32 root = m - 2;
@@ -859,6 +869,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 				H->cnt[lane] = lane ? 2 * H->cntI[lane - 1] - H->cntI[lane] : 0;
 			wave_sync();
 		}
+		if (N == 288) PROF_MARK(15);
 		if (lane == 0) {
 			/* clamp to maxlen, repair Kraft sum (zlib-style) */
 			u32 over = 0;
@@ -899,6 +910,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		}
 		wave_sync();
 	}
+	if (N == 288) PROF_MARK(17);
 	/* canonical codewords, bit-reversed: codes of one length go to the
 	 * symbols in increasing symbol order -> ballot ranks */
 	if (lane == 0) {
@@ -1083,11 +1095,13 @@ static __device__ __forceinline__ void lds_wait8(u32 *o)
  * AHEAD, beside the other waves' shallow search of the current tile.
  */
 static __device__ __forceinline__ void
-insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 lane)
+insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 g_lo, u32 g_hi, u32 lane)
 {
-	const u32 ngroups = (tend - t + 63) / 64;
+	u32 ngroups = (tend - t + 63) / 64;
 
-	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
+	if (ngroups > g_hi)
+		ngroups = g_hi;
+	for (u32 g0 = g_lo; g0 < ngroups; g0 += 8) {
 		u32 o[8], sh[8];
 #pragma unroll
 		for (u32 k = 0; k < 8; k++) {
@@ -1486,7 +1500,7 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 				}
 			}
 		}
-	} else if (mode >= 1) {
+	} else if (mode >= 1 && S3_HALF) {
 #pragma unroll
 		for (u32 k = 0; k < TILE / NT; k++) {
 			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
@@ -2067,7 +2081,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				u16 *c3nxt = c3g + ((tile + 1) & 1) * (TILE + 8);
 				if (tile == 0) {
 					if (wave == NWAVES - 1)
-						insert_tile(L, t, tend, n, lane);
+						insert_tile(L, t, tend, n, 0, TILE / 64, lane);
 					if (wave == NWAVES - 2 && use3) {
 						insert_tile3(L, c3cur, t, tend, n, lane);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2076,7 +2090,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				}
 				if (prime) {	/* dictionary tile: nothing to search or emit */
 					if (wave == NWAVES - 1 && !last_tile)
-						insert_tile(L, tend, tend2, n, lane);
+						insert_tile(L, tend, tend2, n, 0, TILE / 64, lane);
 					if (wave == NWAVES - 2 && !last_tile && use3) {
 						insert_tile3(L, c3nxt, tend, tend2, n, lane);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2093,8 +2107,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				const u32 lo_pos = lo_s > 0 ? (u32)lo_s : 0;
 				const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
 				if (wave == NWAVES - 1) {
+					/* the first half of the next tile's chain insertion;
+					 * the second half runs beside the first parse, which
+					 * keeps only one wave busy */
 					if (!last_tile)
-						insert_tile(L, tend, tend2, n, lane);
+						insert_tile(L, tend, tend2, n, 0, INS_SPLIT, lane);
 				} else if (wave == NWAVES - 2) {
 					if (!last_tile && use3) {
 						insert_tile3(L, c3nxt, tend, tend2, n, lane);
@@ -2168,6 +2185,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						}
 					}
 				}
+				bool ins_done = false;	/* second half of the next tile's insertion */
 				for (;;) {
 				/* opaque again: see the top of the tile loop */
 				u32 tid_opaque2 = threadIdx.x;
@@ -2229,6 +2247,9 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					__syncthreads();
 					if (wave == 0)
 						parse_tile(L, lane, (s32)e - 4, limit);
+					if (wave == NWAVES - 1 && !ins_done && !last_tile)
+						insert_tile(L, tend, tend2, n, INS_SPLIT, TILE / 64, lane);
+					ins_done = true;
 					__syncthreads();
 					PROF_MARK(12);
 					if (r >= rounds)

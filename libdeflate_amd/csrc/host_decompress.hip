@@ -364,3 +364,124 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 DEFINE_DECOMPRESS(deflate, LIBDEFLATE_AMD_DEFLATE)
 DEFINE_DECOMPRESS(zlib, LIBDEFLATE_AMD_ZLIB)
 DEFINE_DECOMPRESS(gzip, LIBDEFLATE_AMD_GZIP)
+
+/*
+ * A gzip buffer made of SEVERAL members (what `cat a.gz b.gz`, pigz -i and
+ * the BGZF container of BAM / tabix files produce).  libdeflate_gzip_decompress
+ * decodes the first member only, by design (lib/gzip_decompress.c:103-131);
+ * its caller loops, as programs/gzip.c:236-299 does.  This is that loop behind
+ * one call - and where the members say how long they are (the "BC" extra
+ * subfield of BGZF: total member size - 1) the whole file is indexed from the
+ * headers alone, the output offsets follow from the ISIZE footers, and ALL
+ * members go to the device as ONE batch.  Anything else (plain concatenations)
+ * is decoded member after member: a member's end is only known once it has
+ * been decoded.
+ */
+extern "C" LIBDEFLATEAPI enum libdeflate_result
+libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
+				       const void *in_, size_t in_nbytes,
+				       void *out_, size_t out_avail,
+				       size_t *actual_in_ret,
+				       size_t *actual_out_ret,
+				       size_t *members_ret)
+{
+	const uint8_t *in = (const uint8_t *)in_;
+	uint8_t *out = (uint8_t *)out_;
+	std::vector<size_t> off, len, osz;
+	size_t pos = 0, total = 0;
+	bool indexed = true;
+
+	while (pos < in_nbytes && indexed) {
+		const uint8_t *p = in + pos;
+		const size_t left = in_nbytes - pos;
+		size_t bsize = 0;
+
+		if (left < 18 + 6 || p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 ||
+		    !(p[3] & 4)) {
+			indexed = false;
+			break;
+		}
+		const size_t xlen = p[10] | ((size_t)p[11] << 8);
+		if (12 + xlen + 8 > left) {
+			indexed = false;
+			break;
+		}
+		for (size_t x = 12; x + 4 <= 12 + xlen;) {
+			const size_t slen = p[x + 2] | ((size_t)p[x + 3] << 8);
+			if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen)
+				bsize = (size_t)(p[x + 4] | ((size_t)p[x + 5] << 8)) + 1;
+			x += 4 + slen;
+		}
+		if (bsize < 12 + xlen + 8 || bsize > left) {
+			indexed = false;
+			break;
+		}
+		const size_t isize = p[bsize - 4] | ((size_t)p[bsize - 3] << 8) |
+				     ((size_t)p[bsize - 2] << 16) | ((size_t)p[bsize - 1] << 24);
+		off.push_back(pos);
+		len.push_back(bsize);
+		osz.push_back(isize);
+		total += isize;
+		pos += bsize;
+	}
+	if (indexed && !off.empty()) {
+		if (total > out_avail)
+			return LIBDEFLATE_INSUFFICIENT_SPACE;
+		const size_t n = off.size();
+		std::vector<const void *> ins(n);
+		std::vector<void *> outs(n);
+		std::vector<int32_t> res(n);
+		std::vector<size_t> ain(n);
+		size_t o = 0;
+		for (size_t i = 0; i < n; i++) {
+			ins[i] = in + off[i];
+			outs[i] = out + o;
+			o += osz[i];
+		}
+		/* exact fill: a member whose ISIZE lies comes back SHORT_OUTPUT /
+		 * INSUFFICIENT_SPACE and fails the call */
+		int rc = libdeflate_amd_decompress_batch_host(
+			d, LIBDEFLATE_AMD_GZIP, n, ins.data(), len.data(), outs.data(),
+			osz.data(), res.data(), ain.data(), NULL);
+		if (rc != LIBDEFLATE_AMD_OK) {
+			complain("libdeflate_amd_gzip_decompress_members", rc);
+			return rc == LIBDEFLATE_AMD_OOM ? LIBDEFLATE_INSUFFICIENT_SPACE :
+							  LIBDEFLATE_BAD_DATA;
+		}
+		for (size_t i = 0; i < n; i++) {
+			if (res[i] != LIBDEFLATE_SUCCESS)
+				return (enum libdeflate_result)res[i];
+			if (ain[i] != len[i])	/* the member is shorter than it says */
+				return LIBDEFLATE_BAD_DATA;
+		}
+		if (actual_in_ret)
+			*actual_in_ret = pos;
+		if (actual_out_ret)
+			*actual_out_ret = total;
+		if (members_ret)
+			*members_ret = n;
+		return LIBDEFLATE_SUCCESS;
+	}
+	/* member after member (programs/gzip.c:236-299) */
+	size_t ipos = 0, opos = 0, members = 0;
+	do {
+		size_t ain = 0, aout = 0;
+		enum libdeflate_result r = decompress_one(
+			d, LIBDEFLATE_AMD_GZIP, in + ipos, in_nbytes - ipos, out + opos,
+			out_avail - opos, &ain, &aout);
+		if (r != LIBDEFLATE_SUCCESS)
+			return r;
+		if (ain == 0 || ain > in_nbytes - ipos)
+			return LIBDEFLATE_BAD_DATA;
+		ipos += ain;
+		opos += aout;
+		members++;
+	} while (ipos < in_nbytes);
+	if (actual_in_ret)
+		*actual_in_ret = ipos;
+	if (actual_out_ret)
+		*actual_out_ret = opos;
+	if (members_ret)
+		*members_ret = members;
+	return LIBDEFLATE_SUCCESS;
+}

@@ -331,3 +331,55 @@ def test_config4_full_count(dec):
     want = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
     assert torch.equal(d_out.view(reps, distinct * size),
                        want.expand(reps, distinct * size))
+
+
+def _bgzf_member(data, level=6):
+    """One BGZF block: gzip member whose FEXTRA carries 'BC' = size - 1."""
+    import struct
+    body = streams._zcompress("deflate", level, data)
+    bsize = 18 + len(body) + 8
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" +
+            struct.pack("<H", bsize - 1) + body +
+            struct.pack("<II", zlib.crc32(data), len(data)))
+
+
+def test_multi_member_gzip(dec, ref):
+    """Concatenated members, the way programs/gzip.c:236-299 handles them:
+    the reference decoded member after member is the expectation; BGZF-style
+    members (sized headers) go to the device as one batch, plain
+    concatenations member by member."""
+    def ref_loop(buf, avail):
+        pos, out = 0, b""
+        while pos < len(buf):
+            r, ain, aout, o = ref.decompress_ex("gzip", buf[pos:], avail - len(out))
+            if r != 0:
+                return r, out
+            pos += ain
+            out += o
+        return 0, out
+    parts = [datagen.chunk(i, n, 0x0E110050) for i, n in
+             enumerate([65280, 1, 0, 40000, 65280, 777, 65280, 12345] * 8)]
+    plain = b"".join(parts)
+    bgzf = b"".join(_bgzf_member(p) for p in parts)
+    assert ref_loop(bgzf, len(plain)) == (0, plain)
+    r, ain, aout, nm, out = dec.gzip_decompress_members(bgzf, len(plain))
+    assert (r, ain, aout, nm) == (0, len(bgzf), len(plain), len(parts)) and out == plain
+    # ordinary members (no size in the header): the sequential path
+    cat = b"".join(streams._zcompress("gzip", 6, p) for p in parts[:9])
+    want = b"".join(parts[:9])
+    assert ref_loop(cat, len(want)) == (0, want)
+    r, ain, aout, nm, out = dec.gzip_decompress_members(cat, len(want) + 10)
+    assert (r, ain, aout, nm) == (0, len(cat), len(want), 9) and out == want
+    # failures agree with the reference's loop: output too small, corrupt member,
+    # trailing garbage after the last member
+    assert dec.gzip_decompress_members(bgzf, len(plain) - 1)[0] == 3
+    assert dec.gzip_decompress_members(cat, len(want) - 1)[0] == ref_loop(cat, len(want) - 1)[0] == 3
+    bad = bytearray(bgzf)
+    bad[len(bgzf) // 2] ^= 0x10
+    assert dec.gzip_decompress_members(bytes(bad), len(plain))[0] != 0
+    assert ref_loop(bytes(bad), len(plain))[0] != 0
+    assert dec.gzip_decompress_members(cat + b"junk", len(want))[0] == \
+        ref_loop(cat + b"junk", len(want))[0] == 1
+    # a single ordinary member is the one-member case of the same call
+    one = streams._zcompress("gzip", 6, parts[0])
+    assert dec.gzip_decompress_members(one, len(parts[0]))[:4] == (0, len(one), len(parts[0]), 1)

@@ -65,8 +65,8 @@ def main():
 
 PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist", "S3 round A",
                   "S4 emit", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
-                  "S4 parse", "#w0 item-passes", "#RB chunks", "#RB items (gen 0)",
-                  "#RB generations", "#w0 hits", "#RB rounds", "#RB item-generations",
+                  "S4 parse", "mc: setup", "mc: merge", "mc: depths",
+                  "#RB generations", "mc: clamp+lens", "#RB rounds", "#RB item-generations",
                   "#w0 chain steps", "#w0 evaluate rounds", "S5 precode tree"]
 
 
