@@ -78,8 +78,18 @@
  * tile, see "block end?") or once they reach MAX_BLOCK_LEN.
  */
 #define MAX_BLOCK_LEN 65536u
-#define SEQ_TILE_MAX (TILE / 3 + 40)	/* > new matches per tile (min match 3) */
-#define SEQ_GCAP (MAX_BLOCK_LEN / 3 + 2 * TILE)
+/*
+ * The tokens of the current block live in HBM, one u32 each, in position
+ * order (one list per workgroup): a literal is its byte; a match is
+ * TOK_MATCH | (length - 3) | (distance - 1) << 8.  Nothing of a block has to
+ * stay in LDS until the block is written, so a block can be as long as a
+ * whole 64 KiB buffer, and the encode pass runs over tokens (all lanes busy),
+ * not over positions (most of them inside a match).
+ */
+#define TOK_MATCH 0x80000000u
+#define TOK_TILE_MAX (TILE + 8)		/* >= new tokens per tile */
+#define TOK_CAP (MAX_BLOCK_LEN + 2 * TILE + 64)	/* u32 entries */
+#define SEQ_GCAP (TOK_CAP / 2)			/* the same in u64 words */
 #define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256 + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
 #define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
@@ -99,6 +109,9 @@
 #endif
 #ifndef S3_ITEMS_PER_WAVE
 #define S3_ITEMS_PER_WAVE 384u	/* round B: one more wave joins per so many items */
+#endif
+#ifndef S6_ALWAYS_FLUSH
+#define S6_ALWAYS_FLUSH 0
 #endif
 #ifndef INS_SPLIT
 #define INS_SPLIT 64u		/* groups of the next tile inserted beside round A, the rest beside the first parse (64 = all beside round A: splitting measured 1.5 % slower, round A itself is what that phase waits for) */
@@ -1346,10 +1359,13 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit)
 			if (walking) {
 				/* a run of literals, then one more token */
 				const u32 rel = (u32)(q - seg_lo);
-				u32 run = (u32)__builtin_ctzll(~(lit >> rel) | (1ull << 63));
+				/* (the shift brings in zeros, so only a segment of 64
+				 * literals walked from its first position has no end) */
+				const u64 inv = ~(lit >> rel);
+				u32 run = inv ? (u32)__builtin_ctzll(inv) : 64;
 				if (run > (u32)(hi - q))
 					run = (u32)(hi - q);
-				u64 add = (((1ull << run) - 1) << rel);
+				u64 add = run >= 64 ? ~0ull : (((1ull << run) - 1) << rel);
 				q += (s32)run;
 				if (q < hi) {
 					const u32 r2 = (u32)(q - seg_lo);
@@ -1887,8 +1903,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	const u32 tid = threadIdx.x;
 	if ((u32)(uintptr_t)(__attribute__((address_space(3))) u8 *)lds_raw != 0)
 		__builtin_trap();	/* see LDS32(): the dynamic LDS block must start at 0 */
-	/* block-relative position | length << 32 | distance << 41 */
 	u64 *__restrict__ seqg = seq_scratch + (size_t)blockIdx.x * SEQ_STRIDE;
+	u32 *__restrict__ tokg = (u32 *)seqg;	/* the block's tokens, see TOK_MATCH */
 	/* levels 10-12: the search results of a block's first tile, kept while
 	 * that tile is parsed more than once */
 	u32 *__restrict__ msave = (u32 *)(seqg + SEQ_GCAP);
@@ -2275,53 +2291,61 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 									    s4mode, nice);
 							u32 l0 = mm & 0xFFFF;
 							bool ism = st == l0 && l0;
+							u32 pos = (u32)((s32)t + (s32)e - 4);
 							if (tid == 0) {
-								u32 pos = (u32)((s32)t + (s32)e - 4);
 								if (ism) {
 									u32 sl, xb, xv;
-									seqg[seq0 + npre] = (pos - block_start) |
-										((u64)l0 << 32) | ((u64)(mm >> 16) << 41);
+									tokg[seq0 + npre] = TOK_MATCH | (l0 - 3) |
+											    (((mm >> 16) - 1) << 8);
 									length_code(l0, &sl, &xb, &xv);
 									atomicAdd((u32 *)&L->freq[257 + sl], 1u);
 									dist_code(mm >> 16, &sl, &xb, &xv);
 									atomicAdd((u32 *)&L->freq[288 + sl], 1u);
 								} else {
-									atomicAdd((u32 *)&L->freq[L->in[pos & RMASK]], 1u);
-									if (st == 2)
-										atomicAdd((u32 *)&L->freq[L->in[(pos + 1) & RMASK]], 1u);
+									u32 b0 = L->in[pos & RMASK];
+									tokg[seq0 + npre] = b0;
+									atomicAdd((u32 *)&L->freq[b0], 1u);
+									if (st == 2) {
+										u32 b1 = L->in[(pos + 1) & RMASK];
+										tokg[seq0 + npre + 1] = b1;
+										atomicAdd((u32 *)&L->freq[b1], 1u);
+									}
 								}
 							}
-							npre += ism ? 1 : 0;
+							npre += !ism && st == 2 ? 2 : 1;
 							e += st;
 						}
 					}
 					/* emit: the lanes on the path classify their token,
-					 * count it for the block's Huffman codes and append
-					 * the matches to seq[] in position order (ballot ranks
-					 * inside the wave, one workgroup scan across waves) */
-					bool ism[SL];
-					u32 m0[SL];
+					 * count it for the block's Huffman codes and append it
+					 * to the block's token list in position order (ballot
+					 * ranks inside the wave, one workgroup scan across
+					 * waves) */
+					u32 tk[SL], tk2[SL];	/* the token(s) of this lane; ~0 = none */
 #pragma unroll
 					for (u32 k = 0; k < SL; k++) {
 						const u32 idx = seg_lo + lane + 64 * k;
 						const bool mk = (L->pm[SL * wave + k] >> lane) & 1;
-						m0[k] = L->M[idx];
-						ism[k] = false;
+						tk[k] = tk2[k] = 0xFFFFFFFFu;
 						if (mk) {
+							const u32 m0 = L->M[idx];
 							const u32 st = step_of(L, idx - 4);
-							const u32 l0 = m0[k] & 0xFFFF;
+							const u32 l0 = m0 & 0xFFFF;
 							const u32 pos = t + idx - 4;
-							ism[k] = st == l0 && l0;
-							if (ism[k]) {
+							if (st == l0 && l0) {
 								u32 sl, xb, xv;
+								tk[k] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
 								length_code(l0, &sl, &xb, &xv);
 								atomicAdd((u32 *)&L->freq[257 + sl], 1u);
-								dist_code(m0[k] >> 16, &sl, &xb, &xv);
+								dist_code(m0 >> 16, &sl, &xb, &xv);
 								atomicAdd((u32 *)&L->freq[288 + sl], 1u);
 							} else {
-								atomicAdd((u32 *)&L->freq[L->in[pos & RMASK]], 1u);
-								if (st == 2)
-									atomicAdd((u32 *)&L->freq[L->in[(pos + 1) & RMASK]], 1u);
+								tk[k] = L->in[pos & RMASK];
+								atomicAdd((u32 *)&L->freq[tk[k]], 1u);
+								if (st == 2) {
+									tk2[k] = L->in[(pos + 1) & RMASK];
+									atomicAdd((u32 *)&L->freq[tk2[k]], 1u);
+								}
 							}
 						}
 					}
@@ -2331,12 +2355,13 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_WALKPOS_LO] = (u32)((s32)t + px);
 						L->vars[V_ENTRY] = (u32)(px - (s32)TILE);
 					}
-					u64 bal[SL];
+					u64 bal[SL], bal2[SL];
 					u32 cw = 0;
 #pragma unroll
 					for (u32 k = 0; k < SL; k++) {
-						bal[k] = __ballot(ism[k]);
-						cw += __builtin_popcountll(bal[k]);
+						bal[k] = __ballot(tk[k] != 0xFFFFFFFFu);
+						bal2[k] = __ballot(tk2[k] != 0xFFFFFFFFu);
+						cw += __builtin_popcountll(bal[k]) + __builtin_popcountll(bal2[k]);
 					}
 					u32 *sc = L->scan[tog];
 					tog ^= 1;
@@ -2354,18 +2379,18 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					const u64 lt = (1ull << lane) - 1;
 #pragma unroll
 					for (u32 k = 0; k < SL; k++) {
-						if (ism[k]) {
-							u32 idx = seg_lo + lane + 64 * k;
-							u32 at = base + __builtin_popcountll(bal[k] & lt);
-							seqg[at] = (t + idx - 4 - block_start) |
-								   ((u64)(m0[k] & 0xFFFF) << 32) |
-								   ((u64)(m0[k] >> 16) << 41);
+						if (tk[k] != 0xFFFFFFFFu) {
+							u32 at = base + __builtin_popcountll(bal[k] & lt) +
+								 __builtin_popcountll(bal2[k] & lt);
+							tokg[at] = tk[k];
+							if (tk2[k] != 0xFFFFFFFFu)
+								tokg[at + 1] = tk2[k];
 						}
-						base += __builtin_popcountll(bal[k]);
+						base += __builtin_popcountll(bal[k]) + __builtin_popcountll(bal2[k]);
 					}
 					if (tid == 0)
 						L->vars[V_NSEQ] = seq0 + npre + tot;
-					/* the match list is read back by other waves at the
+					/* the token list is read back by other waves at the
 					 * end of the block */
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				}
@@ -2471,7 +2496,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * than the minimum, the block ends after the tile. */
 			const u32 splitv = !stored_only && !last_tile ? L->vars[V_SPLIT] : 0;
 			bool end_block = last_tile || splitv ||
-				(!stored_only && L->vars[V_NSEQ] + SEQ_TILE_MAX > SEQ_GCAP) ||
+				(!stored_only && L->vars[V_NSEQ] + 2 * TOK_TILE_MAX > TOK_CAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
 				continue;
@@ -2811,94 +2836,20 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				stg_flush(L, &os, false);
 
 				PROF_MARK(9);
-				/* tokens, EWIN positions at a time.  Four barriers per
-				 * window: after the match scatter, in the bit-offset scan,
-				 * and two in the staging flush.  KD[] (what starts at each
-				 * position: 0 literal, len | dist << 16 match, ~0 covered)
-				 * is re-initialised for the next window by the thread that
-				 * just consumed the entry; the covered prefix and the match
-				 * count travel in two alternating pairs of LDS words. */
-				u32 *KD = L->M;
-				u32 seq_lo = 0;
-				for (u32 i = tid; i < EWIN; i += NT)
-					KD[i] = 0;
-				if (tid == 0) {
-					L->vars[V_SPILL] = 0;
-					L->vars[V_SPILL1] = 0;
-					L->vars[V_SEQCNT] = 0;
-					L->vars[V_SEQCNT1] = 0;
-				}
-				__syncthreads();
-				u32 wpar = 0;
+				/* tokens, NT at a time: one token per thread, a workgroup
+				 * prefix sum of the bit lengths (single-barrier scan),
+				 * ds_or into the staging area.  The staging area is only
+				 * written out when another window might not fit (a token is
+				 * at most 48 bits: 6 KiB per window in the worst case, a
+				 * fifth of that on text). */
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				for (u32 w0 = bstart; w0 < bend; w0 += EWIN, wpar ^= 1) {
-					u32 wend = w0 + EWIN < bend ? w0 + EWIN : bend;
-					const u32 v_spill_next = wpar ? V_SPILL : V_SPILL1;
-					const u32 v_cnt = wpar ? V_SEQCNT1 : V_SEQCNT;
-					/* this thread's input bytes: from the LDS ring while it
-					 * still holds them, else from HBM (a block may be longer
-					 * than the ring); in flight during the scatter */
-					u8 litb[(EWIN + NT - 1) / NT];
-#pragma unroll
-					for (u32 k = 0; k < (EWIN + NT - 1) / NT; k++) {
-						u32 pos = w0 + tid * ((EWIN + NT - 1) / NT) + k;
-						litb[k] = pos >= wend ? 0 :
-							  pos + RING >= loaded + 32 ? L->in[pos & RMASK] : inp[pos];
-					}
-					/* matches that start in this window (the list is
-					 * position-sorted and holds < NT of them per window) */
-					{
-						u32 cw = 0;
-						for (u32 sidx = seq_lo + tid; ; sidx += NT) {
-							bool mine = false;
-							if (sidx < nseq) {
-								u64 sq = seqg[sidx];
-								u32 pos = bstart + (u32)sq;
-								if (pos < wend) {
-									u32 len = (u32)(sq >> 32) & 0x1FF;
-									u32 q = pos - w0;
-									mine = true;
-									KD[q] = len | ((u32)(sq >> 41) << 16);
-									for (u32 j = 1; j < len && q + j < EWIN; j++)
-										KD[q + j] = 0xFFFFFFFFu;
-									if (pos + len > w0 + EWIN)
-										atomicMax((u32 *)&L->vars[v_spill_next],
-											  pos + len - (w0 + EWIN));
-								}
-							}
-							const u64 mm = __ballot(mine);
-							cw += __builtin_popcountll(mm);
-							if (mm != ~0ull)	/* the list is position-sorted */
-								break;
-						}
-						if (lane == 0 && cw)
-							atomicAdd((u32 *)&L->vars[v_cnt], cw);
-					}
-					__syncthreads();
-					seq_lo += L->vars[v_cnt];
-					const u32 spill_next = L->vars[v_spill_next];
-					/* each thread: EPT consecutive positions */
-					enum { EPT = (EWIN + NT - 1) / NT };
-					u64 code[EPT];
-					u32 nb[EPT];
-#pragma unroll
-					for (u32 k = 0; k < EPT; k++) {
-						u32 q = tid * EPT + k;
-						u32 pos = w0 + q;
-						code[k] = 0;
-						nb[k] = 0;
-						u32 kd = KD[q];
-						KD[q] = q < spill_next ? 0xFFFFFFFFu : 0;
-						if (pos >= wend)
-							continue;
-						if (kd == 0xFFFFFFFFu)
-							continue;
-						if (kd == 0) {
-							u32 b = litb[k];
-							code[k] = L->codes[b];
-							nb[k] = L->lens[b];
-						} else {
-							u32 len = kd & 0xFFFF, dist = kd >> 16;
+				for (u32 b0 = 0; b0 < nseq; b0 += NT) {
+					u64 code = 0;
+					u32 nb = 0;
+					if (b0 + tid < nseq) {
+						const u32 tok = tokg[b0 + tid];
+						if (tok & TOK_MATCH) {
+							const u32 len = (tok & 0xFF) + 3, dist = ((tok >> 8) & 0x7FFF) + 1;
 							u32 sl, xb, xv, ds, dxb, dxv;
 							length_code(len, &sl, &xb, &xv);
 							dist_code(dist, &ds, &dxb, &dxv);
@@ -2912,29 +2863,22 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							sh += dl;
 							v |= (u64)dxv << sh;
 							sh += dxb;
-							code[k] = v;
-							nb[k] = sh;
+							code = v;
+							nb = sh;
+						} else {
+							code = L->codes[tok];
+							nb = L->lens[tok];
 						}
 					}
-					u32 tot, mine = 0;
-#pragma unroll
-					for (u32 k = 0; k < EPT; k++)
-						mine += nb[k];
-					u32 off = block_scan1(L, mine, &tot, &tog);
-					/* everyone has read this window's words: clear them for
-					 * the window after the next one */
-					if (tid == 0) {
-						L->vars[v_cnt] = 0;
-						L->vars[wpar ? V_SPILL1 : V_SPILL] = 0;
-					}
-#pragma unroll
-					for (u32 k = 0; k < EPT; k++) {
-						stg_put(L, &os, os.bits + off, code[k], nb[k]);
-						off += nb[k];
-					}
+					u32 tot;
+					u32 off = block_scan1(L, nb, &tot, &tog);
+					stg_put(L, &os, os.bits + off, code, nb);
 					os.bits += tot;
-					stg_flush(L, &os, false);
+					/* room for one more window of 48-bit tokens? */
+					if (S6_ALWAYS_FLUSH || os.bits - 8 * os.sg + 48 * NT + 64 > 32 * STG_WORDS)
+						stg_flush(L, &os, false);
 				}
+				stg_flush(L, &os, false);
 				__syncthreads();
 				/* end of block */
 				if (tid == 0)
@@ -2961,20 +2905,19 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			if (OPT && mode == 3 && tid < 256)
 				bsave[tid] = 0;	/* the previous tile's bytes are added by the next one */
 			if (retro) {
-				/* the last tile's tokens open the next block: its matches
-				 * move to the front of the list (positions are relative to
-				 * the block start), its histogram becomes the block's */
-				const u32 cnt = nseq_all - nseq;	/* <= SEQ_TILE_MAX < 2 NT */
-				u64 e0 = 0, e1 = 0;
-				if (tid < cnt)
-					e0 = seqg[nseq + tid];
-				if (tid + NT < cnt)
-					e1 = seqg[nseq + NT + tid];
+				/* the last tile's tokens open the next block: they move to
+				 * the front of the list, its histogram becomes the block's */
+				const u32 cnt = nseq_all - nseq;	/* <= TOK_TILE_MAX */
+				enum { RPT = (TOK_TILE_MAX + NT - 1) / NT };
+				u32 mv[RPT];
+#pragma unroll
+				for (u32 k = 0; k < RPT; k++)
+					mv[k] = tid + NT * k < cnt ? tokg[nseq + tid + NT * k] : 0;
 				__syncthreads();
-				if (tid < cnt)
-					seqg[tid] = e0 - blen;
-				if (tid + NT < cnt)
-					seqg[NT + tid] = e1 - blen;
+#pragma unroll
+				for (u32 k = 0; k < RPT; k++)
+					if (tid + NT * k < cnt)
+						tokg[tid + NT * k] = mv[k];
 				if (tid < 320)
 					L->freq[tid] = fsave[320 + tid];
 				if (tid == 0)
