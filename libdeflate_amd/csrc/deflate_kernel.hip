@@ -1098,14 +1098,19 @@ static __device__ __forceinline__ void lds_wait8(u32 *o)
 /*
  * ONE wave inserts the positions [t, tend) into the hash chains (head[] /
  * prev[], masked exchange, see above), another one into the single-slot
- * 3-byte table (plain read + write: duplicates inside a group of 64 all get the slot's
- * content from before the group, which only hides length-3 candidates 9..63
- * bytes back; the distances 1..8 are probed in registers anyway), leaving the
- * 3-byte candidate of every position in c3[] (HBM scratch: it is consumed a
- * tile later).  Position order, 8 groups of 64 in flight.  An LDS atomic with return costs ~3 cycles per lane on the whole
- * CU whichever wave issues it (measured: spreading the buckets over 16 waves
- * by hash made the stage slower), so the insertion runs on one wave, one tile
- * AHEAD, beside the other waves' shallow search of the current tile.
+ * 3-byte table (plain read + write: duplicates inside a group of 64 all get
+ * the slot's content from before the group, which only hides length-3
+ * candidates 9..63 bytes back; the distances 1..8 are probed in registers
+ * anyway), leaving the 3-byte candidate of every position in c3[] (HBM
+ * scratch: it is consumed a tile later).  Position order, 8 groups of 64 in
+ * flight (16 measured slower).  An LDS atomic with return costs ~3 cycles per
+ * lane on the WHOLE CU whichever wave issues it: spreading the buckets over 16
+ * waves by hash made the stage slower, and while the atomics run, the other
+ * waves' LDS traffic queues behind them.  So the insertion runs on one wave,
+ * one tile AHEAD, beside the shallow search of the current tile (the phase
+ * with the most independent work per wave); moving parts of it beside the
+ * single-wave parse phases, which looked free, made those 1.5x longer and the
+ * kernel 5 % slower.
  */
 static __device__ __forceinline__ void
 insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 g_lo, u32 g_hi, u32 lane)
@@ -1761,7 +1766,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
 	const u32 half = depth >> 1 ? depth >> 1 : 1;
-	const u32 npass = depth >= 256 ? 4 : depth >= 64 ? 2 : 1;	/* walk passes per generation */
+	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;	/* walk passes per generation */
 	const u32 quantum = 8 * npass;
 	const u64 lt = (1ull << lane) - 1;
 	u32 ncur = wc;
