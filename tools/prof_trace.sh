@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 tag=${1:-r01}
 rm -rf $R/gpurun_out/trace_$tag; mkdir -p $R/gpurun_out/trace_$tag
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace_$tag -o bench --output-format csv -- \
-    python $R/bench.py --steps 3 --warmup 1 --no-cpu > $R/gpurun_out/trace_$tag/bench_stdout.log 2>&1 || true
+    python $R/bench.py --steps 3 --warmup 1 --no-cpu --configs headline > $R/gpurun_out/trace_$tag/bench_stdout.log 2>&1 || true
 tail -2 $R/gpurun_out/trace_$tag/bench_stdout.log
 find $R/gpurun_out/trace_$tag -name "*kernel_stats.csv" | head -1 | xargs cat | head -12
 # keep only the small summaries
