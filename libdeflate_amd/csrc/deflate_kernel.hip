@@ -1103,14 +1103,20 @@ static __device__ __forceinline__ void lds_wait8(u32 *o)
  * candidates 9..63 bytes back; the distances 1..8 are probed in registers
  * anyway), leaving the 3-byte candidate of every position in c3[] (HBM
  * scratch: it is consumed a tile later).  Position order, 8 groups of 64 in
- * flight (16 measured slower).  An LDS atomic with return costs ~3 cycles per
- * lane on the WHOLE CU whichever wave issues it: spreading the buckets over 16
- * waves by hash made the stage slower, and while the atomics run, the other
- * waves' LDS traffic queues behind them.  So the insertion runs on one wave,
- * one tile AHEAD, beside the shallow search of the current tile (the phase
- * with the most independent work per wave); moving parts of it beside the
- * single-wave parse phases, which looked free, made those 1.5x longer and the
- * kernel 5 % slower.
+ * flight (16 measured slower).  The LDS pipeline is not what bounds it
+ * (tools/hwtest_lds_atomic_rate.hip: with 16 waves issuing, a 64-lane
+ * ds_mskor_rtn_b32 on random addresses completes every 11 cycles CU-wide, a
+ * 32-bit exchange or a plain read / write every 6; one wave alone gets one
+ * through every ~50 cycles, its own address arithmetic included): one wave
+ * inserting a tile is 64 dependent batches of its own instruction stream,
+ * ~22 K cycles.  Spreading the buckets over 16 waves by hash made every wave
+ * run that whole stream (slower); moving parts of it beside the single-wave
+ * parse phases made those 1.5x longer (the waves share the LDS queue) and the
+ * kernel 5 % slower; preparing the whole next tile (insertion AND shallow
+ * search) beside the first parse, with the results waiting in HBM, cost more
+ * at the top of the tile than the overlap saved (13.3 vs 12.4 ms).  So the
+ * insertion runs on one wave, one tile AHEAD, beside the shallow search of
+ * the current tile, the phase with the most independent work per wave.
  */
 static __device__ __forceinline__ void
 insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 g_lo, u32 g_hi, u32 lane)
