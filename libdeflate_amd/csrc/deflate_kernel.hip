@@ -1260,11 +1260,18 @@ static __device__ __forceinline__ void
 round_a(lds_t *L, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lo_pos,
 	u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3, u32 tid)
 {
-	const u32 lane = tid & 63, wave = tid >> 6;
+	const u32 lane = tid & 63;
 
-	/* the last two waves are inserting the next tile meanwhile */
+	/* groups of 64 positions are taken from a counter: the two waves that
+	 * insert the next tile meanwhile join in when they are done */
 #pragma unroll 1
-	for (u32 g = wave; g < TILE / 64; g += NWAVES - 2) {
+	for (;;) {
+		u32 g = 0;
+		if (lane == 0)
+			g = atomicAdd((u32 *)&L->vars[V_CTR], 1u);
+		g = bcast_first(g);
+		if (g >= TILE / 64)
+			break;
 		const u32 i = 64 * g + lane, p = t + i;
 		const u32 c3v = min_len <= 3 ? c3[4 + i] : 0;
 		bool act = p < tend && p + 4 <= n;
@@ -2134,22 +2141,29 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				const u32 lo_pos = lo_s > 0 ? (u32)lo_s : 0;
 				const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
 				if (wave == NWAVES - 1) {
-					/* the first half of the next tile's chain insertion;
-					 * the second half runs beside the first parse, which
-					 * keeps only one wave busy */
+					/* the next tile's chain insertion: one wave's serial
+					 * instruction stream, the longest item of this phase -
+					 * it gets the issue slots of its SIMD first */
+					__builtin_amdgcn_s_setprio(3);
 					if (!last_tile)
 						insert_tile(L, tend, tend2, n, 0, INS_SPLIT, lane);
+					__builtin_amdgcn_s_setprio(0);
 				} else if (wave == NWAVES - 2) {
+					__builtin_amdgcn_s_setprio(2);
 					if (!last_tile && use3) {
 						insert_tile3(L, c3nxt, tend, tend2, n, lane);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					}
-				} else if (OPT && mode == 3) {
+					__builtin_amdgcn_s_setprio(0);
+				}
+				if (OPT && mode == 3) {
+					if (wave < NWAVES - 2)
 					/* the min-cost parse prices every position: all of
 					 * them are searched to the full depth */
 					search_items(L, t, n, lo_pos, min_len, depth, nice,
 						     NULL, TILE, NWAVES - 2, tid);
 				} else {
+					/* (V_CTR was zeroed at the top of the tile) */
 					round_a(L, c3cur, t, tend, n, lo_pos, min_len, ra_depth,
 						ra_all ? DC_FULL :
 						ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW,
