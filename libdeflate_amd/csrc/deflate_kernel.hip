@@ -1444,13 +1444,11 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
 
-	if (tid < TILE / 64 + 2)
-		L->nh[tid] = 0;
-	if (tid == 0) {
-		L->vars[V_WCNT] = 0;
-		L->vars[V_CTR] = 0;	/* the search that follows claims from 0 */
+	if (by_rule) {
+		if (tid < TILE / 64 + 2)
+			L->nh[tid] = 0;
+		__syncthreads();
 	}
-	__syncthreads();
 	if (by_rule && S3_RULE_FIRST == 1) {
 		/* Before the first parse: a position INSIDE a match run (one byte
 		 * shorter than its predecessor's match, same distance) is where a
@@ -1534,27 +1532,25 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 				}
 			}
 		}
-	} else if (mode >= 1 && S3_HALF) {
-#pragma unroll
-		for (u32 k = 0; k < TILE / NT; k++) {
-			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-			const u64 mask = L->pm[g];
-			const u32 l0 = L->M[4 + q] & 0xFFFF;
-			const bool la = ((mask >> lane) & 1) && l0 >= 3 && l0 < nice;
-			const u64 b = __ballot(la);
-			u64 lo = b << 1, hi = b >> 63;
-			if (mode >= 2) {
-				lo |= b << 2;
-				hi |= b >> 62;
-			}
-			if (lane == 0 && b) {
-				atomicOr((unsigned long long *)&L->nh[g], lo);
-				if (hi)
-					atomicOr((unsigned long long *)&L->nh[g + 1], hi);
-			}
-		}
 	}
-	__syncthreads();
+	if (by_rule)
+		__syncthreads();
+	/* parse-based: the positions the lazy rule looked at are the one (lazy2:
+	 * two) after a token start that holds a match shorter than the nice
+	 * length.  A wave owns four consecutive groups of 64, so the bits that
+	 * spill into the next group travel in a register; only the spill from
+	 * the group before the wave's first is recomputed from that group's last
+	 * two positions. */
+	u64 spill = 0;
+	if (!by_rule && mode >= 1 && S3_HALF && wave) {
+		const u32 g0 = wave * (TILE / NT), q1 = 64 * g0 - 1;
+		const u64 pmask = L->pm[g0 - 1];
+		const u32 l1 = L->M[4 + q1] & 0xFFFF, l2 = L->M[4 + q1 - 1] & 0xFFFF;
+		if ((pmask >> 63) && l1 >= 3 && l1 < nice)
+			spill = mode >= 2 ? 3 : 1;
+		if (mode >= 2 && ((pmask >> 62) & 1) && l2 >= 3 && l2 < nice)
+			spill |= 1;
+	}
 	/* ranks by a scan, not by atomics: which items fall under the cap must
 	 * not depend on timing */
 	u32 want[TILE / NT];
@@ -1563,8 +1559,19 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-		want[k] = ((L->pm[g] >> lane) & 1) ? DC_FULL :
-			  ((L->nh[g] >> lane) & 1) ? DC_HALF : DC_SHALLOW;
+		const u64 tmask = L->pm[g];
+		u64 hmask;
+		if (by_rule) {
+			hmask = L->nh[g];
+		} else {
+			const u32 l0 = L->M[4 + q] & 0xFFFF;
+			const u64 b = mode >= 1 && S3_HALF ?
+				__ballot(((tmask >> lane) & 1) && l0 >= 3 && l0 < nice) : 0;
+			hmask = (b << 1) | (mode >= 2 ? b << 2 : 0) | spill;
+			spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
+		}
+		want[k] = ((tmask >> lane) & 1) ? DC_FULL :
+			  ((hmask >> lane) & 1) ? DC_HALF : DC_SHALLOW;
 		const bool add = want[k] > L->done[4 + q] &&
 				 (L->M[4 + q] & 0xFFFF) < nice;
 		bal[k] = __ballot(add);
