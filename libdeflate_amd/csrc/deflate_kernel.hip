@@ -57,7 +57,12 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#ifndef NT
 #define NT LDA_DEFLATE_THREADS
+#endif
+/* sections written for one element per thread of a 1024-thread workgroup run
+ * VPT consecutive elements per thread in a smaller one */
+#define VPT (1024 / NT)
 #define NWAVES (NT / 64)
 #ifndef TILE
 #define TILE 4096
@@ -2199,8 +2204,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				/* the block as it is before this tile's tokens: if the tile
 				 * turns out to be of different content, the block ends in
 				 * front of it (see "block end?") */
-				if (tid < 320)
-					fsave[tid] = L->freq[tid];
+				for (u32 i = tid; i < 320; i += NT)
+					fsave[i] = L->freq[i];
 				if (tid == 0) {
 					L->vars[V_NSEQ_PRE] = L->vars[V_NSEQ];
 					L->vars[V_WPOS_PRE] = walkpos;
@@ -2353,52 +2358,25 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					 * to the block's token list in position order (ballot
 					 * ranks inside the wave, one workgroup scan across
 					 * waves) */
-					u32 tk[SL], tk2[SL];	/* the token(s) of this lane; ~0 = none */
+					/* tokens of this wave's positions: one per token start,
+					 * two where the step is "two literals" */
+					u32 cw = 0;
 #pragma unroll
 					for (u32 k = 0; k < SL; k++) {
-						const u32 idx = seg_lo + lane + 64 * k;
-						const bool mk = (L->pm[SL * wave + k] >> lane) & 1;
-						tk[k] = tk2[k] = 0xFFFFFFFFu;
-						if (mk) {
-							const u32 m0 = L->M[idx];
-							const u32 st = step_of(L, idx - 4);
-							const u32 l0 = m0 & 0xFFFF;
-							const u32 pos = t + idx - 4;
-							if (st == l0 && l0) {
-								u32 sl, xb, xv;
-								tk[k] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
-								length_code(l0, &sl, &xb, &xv);
-								atomicAdd((u32 *)&L->freq[257 + sl], 1u);
-								dist_code(m0 >> 16, &sl, &xb, &xv);
-								atomicAdd((u32 *)&L->freq[288 + sl], 1u);
-							} else {
-								tk[k] = L->in[pos & RMASK];
-								atomicAdd((u32 *)&L->freq[tk[k]], 1u);
-								if (st == 2) {
-									tk2[k] = L->in[(pos + 1) & RMASK];
-									atomicAdd((u32 *)&L->freq[tk2[k]], 1u);
-								}
-							}
-						}
+						const u64 pmk = L->pm[SL * wave + k];
+						cw += (u32)__builtin_popcountll(pmk) +
+						      (u32)__builtin_popcountll(pmk & L->lit2[SL * wave + k]);
 					}
+					u32 *sc = L->scan[tog];
+					tog ^= 1;
+					if (lane == 0)
+						sc[wave] = cw;
 					if (tid == 0) {
 						/* where the path leaves the tile */
 						const s32 px = (s32)L->vars[V_PEXIT];
 						L->vars[V_WALKPOS_LO] = (u32)((s32)t + px);
 						L->vars[V_ENTRY] = (u32)(px - (s32)TILE);
 					}
-					u64 bal[SL], bal2[SL];
-					u32 cw = 0;
-#pragma unroll
-					for (u32 k = 0; k < SL; k++) {
-						bal[k] = __ballot(tk[k] != 0xFFFFFFFFu);
-						bal2[k] = __ballot(tk2[k] != 0xFFFFFFFFu);
-						cw += __builtin_popcountll(bal[k]) + __builtin_popcountll(bal2[k]);
-					}
-					u32 *sc = L->scan[tog];
-					tog ^= 1;
-					if (lane == 0)
-						sc[wave] = cw;
 					__syncthreads();
 					u32 base = seq0 + npre, tot = 0;
 #pragma unroll
@@ -2409,16 +2387,37 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						tot += c;
 					}
 					const u64 lt = (1ull << lane) - 1;
-#pragma unroll
+#pragma unroll 4
 					for (u32 k = 0; k < SL; k++) {
-						if (tk[k] != 0xFFFFFFFFu) {
-							u32 at = base + __builtin_popcountll(bal[k] & lt) +
-								 __builtin_popcountll(bal2[k] & lt);
-							tokg[at] = tk[k];
-							if (tk2[k] != 0xFFFFFFFFu)
-								tokg[at + 1] = tk2[k];
+						const u32 idx = seg_lo + lane + 64 * k;
+						const u64 pmk = L->pm[SL * wave + k];
+						const u64 two = pmk & L->lit2[SL * wave + k];
+						if ((pmk >> lane) & 1) {
+							const u32 m0 = L->M[idx];
+							const u32 st = step_of(L, idx - 4);
+							const u32 l0 = m0 & 0xFFFF;
+							const u32 pos = t + idx - 4;
+							const u32 at = base + (u32)__builtin_popcountll(pmk & lt) +
+								       (u32)__builtin_popcountll(two & lt);
+							if (st == l0 && l0) {
+								u32 sl, xb, xv;
+								tokg[at] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
+								length_code(l0, &sl, &xb, &xv);
+								atomicAdd((u32 *)&L->freq[257 + sl], 1u);
+								dist_code(m0 >> 16, &sl, &xb, &xv);
+								atomicAdd((u32 *)&L->freq[288 + sl], 1u);
+							} else {
+								const u32 b0 = L->in[pos & RMASK];
+								tokg[at] = b0;
+								atomicAdd((u32 *)&L->freq[b0], 1u);
+								if (st == 2) {
+									const u32 b1 = L->in[(pos + 1) & RMASK];
+									tokg[at + 1] = b1;
+									atomicAdd((u32 *)&L->freq[b1], 1u);
+								}
+							}
 						}
-						base += __builtin_popcountll(bal[k]) + __builtin_popcountll(bal2[k]);
+						base += (u32)__builtin_popcountll(pmk) + (u32)__builtin_popcountll(two);
 					}
 					if (tid == 0)
 						L->vars[V_NSEQ] = seq0 + npre + tot;
@@ -2543,10 +2542,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			const u32 nseq = retro ? L->vars[V_NSEQ_PRE] : nseq_all;
 			const u32 is_final = last_tile && seg_last ? 1 : 0;
 			if (retro) {
-				if (tid < 320) {
-					u32 f = L->freq[tid], fp = fsave[tid];
-					fsave[320 + tid] = f - fp;
-					L->freq[tid] = fp;
+				for (u32 i = tid; i < 320; i += NT) {
+					u32 f = L->freq[i], fp = fsave[i];
+					fsave[320 + i] = f - fp;
+					L->freq[i] = fp;
 				}
 				__syncthreads();
 			}
@@ -2567,37 +2566,43 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					for (u32 i = tid; i < 324; i += NT)
 						L->M[i] = 0;
 					__syncthreads();
-					if (tid < 864) {
-						u32 sidx = tid / 3, part = tid % 3;
-						u32 f = L->freq[sidx];
-						if (f) {
-							u32 key = (f << 9) | sidx, r = 0;
-							for (u32 q = part * 96; q < part * 96 + 96; q++) {
-								u32 ft = L->freq[q];
-								r += (ft != 0) & (((ft << 9) | q) < key);
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						const u32 vt = tid * VPT + j;
+						if (vt < 864) {
+							u32 sidx = vt / 3, part = vt % 3;
+							u32 f = L->freq[sidx];
+							if (f) {
+								u32 key = (f << 9) | sidx, r = 0;
+								for (u32 q = part * 96; q < part * 96 + 96; q++) {
+									u32 ft = L->freq[q];
+									r += (ft != 0) & (((ft << 9) | q) < key);
+								}
+								atomicAdd(&rk[sidx], r);
+								if (part == 0)
+									atomicAdd(&usedv[0], 1u);
 							}
-							atomicAdd(&rk[sidx], r);
-							if (part == 0)
-								atomicAdd(&usedv[0], 1u);
-						}
-					} else if (tid < 896) {
-						u32 sidx = tid - 864;
-						u32 f = L->freq[288 + sidx];
-						if (f) {
-							u32 key = (f << 9) | sidx, r = 0;
-							for (u32 q = 0; q < 32; q++) {
-								u32 ft = L->freq[288 + q];
-								r += (ft != 0) & (((ft << 9) | q) < key);
+						} else if (vt < 896) {
+							u32 sidx = vt - 864;
+							u32 f = L->freq[288 + sidx];
+							if (f) {
+								u32 key = (f << 9) | sidx, r = 0;
+								for (u32 q = 0; q < 32; q++) {
+									u32 ft = L->freq[288 + q];
+									r += (ft != 0) & (((ft << 9) | q) < key);
+								}
+								rk[288 + sidx] = r;
+								atomicAdd(&usedv[1], 1u);
 							}
-							rk[288 + sidx] = r;
-							atomicAdd(&usedv[1], 1u);
 						}
 					}
 					__syncthreads();
-					if (tid < 288 && L->freq[tid])
-						L->sorted[rk[tid]] = (u16)tid;
-					else if (tid >= 288 && tid < 320 && L->freq[tid])
-						sortedO[rk[tid]] = (u16)(tid - 288);
+					for (u32 vt = tid; vt < 320; vt += NT) {
+						if (vt < 288 && L->freq[vt])
+							L->sorted[rk[vt]] = (u16)vt;
+						else if (vt >= 288 && L->freq[vt])
+							sortedO[rk[vt]] = (u16)(vt - 288);
+					}
 					__syncthreads();
 					PROF_MARK(10);
 					/* the two trees are built side by side on two waves */
@@ -2625,79 +2630,103 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					if (tid < 19)
 						L->pre_freq[tid] = 0;
 					__syncthreads();
-					if (tid < 288 && tid >= 257 && L->lens[tid])
-						atomicMax((u32 *)&L->vars[V_TMP1], tid + 1);
-					if (tid >= 288 && tid < 320 && L->lens[tid])
-						atomicMax((u32 *)&L->vars[V_TMP2], tid - 288 + 1);
+					for (u32 vt = tid; vt < 320; vt += NT) {
+						if (vt < 288 && vt >= 257 && L->lens[vt])
+							atomicMax((u32 *)&L->vars[V_TMP1], vt + 1);
+						if (vt >= 288 && L->lens[vt])
+							atomicMax((u32 *)&L->vars[V_TMP2], vt - 288 + 1);
+					}
 					__syncthreads();
 					const u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
 					const u32 total = nlit + noff;
-					u32 v = 0, isst = 0;
-					if (tid < total) {
-						v = L->lens[tid < nlit ? tid : 288 + (tid - nlit)];
-						u32 pv = 0xFF;
-						if (tid)
-							pv = L->lens[tid - 1 < nlit ? tid - 1 :
-								     288 + (tid - 1 - nlit)];
-						isst = pv != v;
+					/* element e of the concatenated lengths: thread tid owns
+					 * the VPT consecutive elements from tid * VPT */
+					u32 isst[VPT], nst = 0;
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						const u32 e = tid * VPT + j;
+						isst[j] = 0;
+						if (e < total) {
+							u32 v = L->lens[e < nlit ? e : 288 + (e - nlit)];
+							u32 pv = 0xFF;
+							if (e)
+								pv = L->lens[e - 1 < nlit ? e - 1 :
+									     288 + (e - 1 - nlit)];
+							isst[j] = pv != v;
+						}
+						nst += isst[j];
 					}
 					u32 nruns;
-					u32 ridx = block_scan(L, isst, &nruns);
-					if (isst)
-						starts[ridx] = tid;
+					u32 ridx = block_scan(L, nst, &nruns);
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						if (isst[j])
+							starts[ridx] = tid * VPT + j;
+						ridx += isst[j];
+					}
 					if (tid == 0)
 						starts[nruns] = total;
 					__syncthreads();
-					/* thread r < nruns owns run r */
-					u32 rv = 0, rlen = 0, nitems = 0;
-					if (tid < nruns) {
-						u32 st = starts[tid];
-						rlen = starts[tid + 1] - st;
-						rv = L->lens[st < nlit ? st : 288 + (st - nlit)];
-						if (rv == 0) {
-							u32 full = rlen / 138, rem = rlen % 138;
-							nitems = full + (rem >= 3 ? 1 : rem);
-						} else if (rlen >= 4) {
-							u32 l1 = rlen - 1;
-							nitems = 1 + l1 / 6 + (l1 % 6 >= 3 ? 1 : l1 % 6);
-						} else {
-							nitems = rlen;
+					/* run r: thread tid owns the runs from tid * VPT */
+					u32 rv[VPT], rlen[VPT], nitems[VPT], nit = 0;
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						const u32 r = tid * VPT + j;
+						rv[j] = rlen[j] = nitems[j] = 0;
+						if (r < nruns) {
+							u32 st = starts[r];
+							rlen[j] = starts[r + 1] - st;
+							rv[j] = L->lens[st < nlit ? st : 288 + (st - nlit)];
+							if (rv[j] == 0) {
+								u32 full = rlen[j] / 138, rem = rlen[j] % 138;
+								nitems[j] = full + (rem >= 3 ? 1 : rem);
+							} else if (rlen[j] >= 4) {
+								u32 l1 = rlen[j] - 1;
+								nitems[j] = 1 + l1 / 6 + (l1 % 6 >= 3 ? 1 : l1 % 6);
+							} else {
+								nitems[j] = rlen[j];
+							}
 						}
+						nit += nitems[j];
 					}
 					u32 ni;
-					u32 at = block_scan(L, nitems, &ni);
-					if (tid < nruns) {
-						u32 left = rlen;
-						if (rv == 0) {
-							while (left >= 11) {
-								u32 r = left > 138 ? 138 : left;
-								L->pre_items[at++] = 18 | ((r - 11) << 5);
-								atomicAdd((u32 *)&L->pre_freq[18], 1u);
-								left -= r;
+					u32 at = block_scan(L, nit, &ni);
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						if (tid * VPT + j < nruns) {
+							u32 left = rlen[j];
+							const u32 rvj = rv[j];
+							if (rvj == 0) {
+								while (left >= 11) {
+									u32 r = left > 138 ? 138 : left;
+									L->pre_items[at++] = 18 | ((r - 11) << 5);
+									atomicAdd((u32 *)&L->pre_freq[18], 1u);
+									left -= r;
+								}
+								if (left >= 3) {
+									L->pre_items[at++] = 17 | ((left - 3) << 5);
+									atomicAdd((u32 *)&L->pre_freq[17], 1u);
+									left = 0;
+								}
+							} else if (left >= 4) {
+								L->pre_items[at++] = (u16)rvj;
+								left--;
+								u32 n16 = 0;
+								while (left >= 3) {
+									u32 r = left > 6 ? 6 : left;
+									L->pre_items[at++] = 16 | ((r - 3) << 5);
+									n16++;
+									left -= r;
+								}
+								atomicAdd((u32 *)&L->pre_freq[16], n16);
+								atomicAdd((u32 *)&L->pre_freq[rvj], 1u);
 							}
-							if (left >= 3) {
-								L->pre_items[at++] = 17 | ((left - 3) << 5);
-								atomicAdd((u32 *)&L->pre_freq[17], 1u);
-								left = 0;
+							if (left)
+								atomicAdd((u32 *)&L->pre_freq[rvj], left);
+							while (left) {
+								L->pre_items[at++] = (u16)rvj;
+								left--;
 							}
-						} else if (left >= 4) {
-							L->pre_items[at++] = (u16)rv;
-							left--;
-							u32 n16 = 0;
-							while (left >= 3) {
-								u32 r = left > 6 ? 6 : left;
-								L->pre_items[at++] = 16 | ((r - 3) << 5);
-								n16++;
-								left -= r;
-							}
-							atomicAdd((u32 *)&L->pre_freq[16], n16);
-							atomicAdd((u32 *)&L->pre_freq[rv], 1u);
-						}
-						if (left)
-							atomicAdd((u32 *)&L->pre_freq[rv], left);
-						while (left) {
-							L->pre_items[at++] = (u16)rv;
-							left--;
 						}
 					}
 					if (tid == 0)
@@ -2713,21 +2742,21 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				PROF_MARK(22);
 				/* exact costs (deflate_compress.c:1747-1808) */
 				u32 dyn = 0, stat = 0;
-				if (tid < 320) {
-					u32 f = L->freq[tid];
+				for (u32 vt = tid; vt < 320; vt += NT) {
+					u32 f = L->freq[vt];
 					u32 xb = 0, sl = 8;
-					if (tid < 288) {
-						sl = tid < 144 ? 8 : tid < 256 ? 9 : tid < 280 ? 7 : 8;
-						if (tid >= 265 && tid < 285)
-							xb = (tid - 261) >> 2;
+					if (vt < 288) {
+						sl = vt < 144 ? 8 : vt < 256 ? 9 : vt < 280 ? 7 : 8;
+						if (vt >= 265 && vt < 285)
+							xb = (vt - 261) >> 2;
 					} else {
-						u32 ds = tid - 288;
+						u32 ds = vt - 288;
 						sl = 5;
 						if (ds >= 4)
 							xb = (ds >> 1) - 1;
 					}
-					dyn = f * (L->lens[tid] + xb);
-					stat = f * (sl + xb);
+					dyn += f * (L->lens[vt] + xb);
+					stat += f * (sl + xb);
 				}
 				if (tid < 19) {
 					u32 xb = tid == 16 ? 2 : tid == 17 ? 3 : tid == 18 ? 7 : 0;
@@ -2833,36 +2862,47 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				 * 1..nexp the precode lengths, then one thread per
 				 * precode item; bit offsets by a workgroup scan */
 				{
-					u64 hcode = 0;
-					u32 hbits = 0;
+					u64 hcode[VPT];
+					u32 hbits[VPT], hsum = 0;
 					const u32 nexp = btype == 2 ? L->vars[V_TMP3] : 0;
 					const u32 ni = btype == 2 ? L->vars[V_NPRE] : 0;
-					if (tid == 0) {
-						hcode = is_final | (btype << 1);
-						hbits = 3;
-						if (btype == 2) {
-							u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
-							hcode |= (u64)((nlit - 257) | ((noff - 1) << 5) |
-								       ((nexp - 4) << 10)) << 3;
-							hbits = 17;
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						const u32 vt = tid * VPT + j;	/* header item */
+						hcode[j] = 0;
+						hbits[j] = 0;
+						if (vt == 0) {
+							hcode[j] = is_final | (btype << 1);
+							hbits[j] = 3;
+							if (btype == 2) {
+								u32 nlit = L->vars[V_TMP1], noff = L->vars[V_TMP2];
+								hcode[j] |= (u64)((nlit - 257) | ((noff - 1) << 5) |
+										  ((nexp - 4) << 10)) << 3;
+								hbits[j] = 17;
+							}
+						} else if (vt <= nexp) {
+							static const u8 perm2[19] = { 16, 17, 18, 0, 8, 7,
+								9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+							hcode[j] = L->pre_lens[perm2[vt - 1]];
+							hbits[j] = 3;
+						} else if (vt <= nexp + ni) {
+							u32 it = L->pre_items[vt - nexp - 1];
+							u32 sym = it & 31, ex = it >> 5;
+							u32 l = L->pre_lens[sym];
+							u32 xb = sym == 16 ? 2 : sym == 17 ? 3 :
+								 sym == 18 ? 7 : 0;
+							hcode[j] = L->pre_codes[sym] | ((u64)ex << l);
+							hbits[j] = l + xb;
 						}
-					} else if (tid <= nexp) {
-						static const u8 perm2[19] = { 16, 17, 18, 0, 8, 7,
-							9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-						hcode = L->pre_lens[perm2[tid - 1]];
-						hbits = 3;
-					} else if (tid <= nexp + ni) {
-						u32 it = L->pre_items[tid - nexp - 1];
-						u32 sym = it & 31, ex = it >> 5;
-						u32 l = L->pre_lens[sym];
-						u32 xb = sym == 16 ? 2 : sym == 17 ? 3 :
-							 sym == 18 ? 7 : 0;
-						hcode = L->pre_codes[sym] | ((u64)ex << l);
-						hbits = l + xb;
+						hsum += hbits[j];
 					}
 					u32 htot;
-					u32 hoff = block_scan(L, hbits, &htot);
-					stg_put(L, &os, os.bits + hoff, hcode, hbits);
+					u32 hoff = block_scan(L, hsum, &htot);
+#pragma unroll
+					for (u32 j = 0; j < VPT; j++) {
+						stg_put(L, &os, os.bits + hoff, hcode[j], hbits[j]);
+						hoff += hbits[j];
+					}
 					os.bits += htot;
 				}
 				stg_flush(L, &os, false);
@@ -2950,8 +2990,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				for (u32 k = 0; k < RPT; k++)
 					if (tid + NT * k < cnt)
 						tokg[tid + NT * k] = mv[k];
-				if (tid < 320)
-					L->freq[tid] = fsave[320 + tid];
+				for (u32 i = tid; i < 320; i += NT)
+					L->freq[i] = fsave[320 + i];
 				if (tid == 0)
 					L->vars[V_NSEQ] = cnt;
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
