@@ -245,7 +245,7 @@ def roundtrip_config(torch, dist, world, rank, dev, stream, api, shard, chunks,
         if ev:
             ev[0].record(stream)
         comp_c.compress_batch(fmt, data, in_off, in_n, comp, c_off, c_av, c_n,
-                              stream=stream)
+                              stream=stream, max_chunk=size)
         if ev:
             ev[1].record(stream)
         dec.decompress_batch(fmt, comp, c_off, c_n, out, in_off, in_n, res,

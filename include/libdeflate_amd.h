@@ -227,6 +227,23 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *compressor,
 			      uint64_t *d_out_nbytes, void *stream);
 
 /*
+ * The same with an upper bound of the chunk sizes stated by the caller (the
+ * sizes themselves live in HBM, where the host cannot see them): batches of
+ * small chunks - at most 4096 bytes, the filesystem-block shape - run on a
+ * kernel that keeps three chunks per CU in flight instead of one.  A chunk
+ * larger than the bound reports 0, like one that does not fit its slot.
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_compress_batch_bounded(struct libdeflate_compressor *compressor,
+				      int format, size_t n_chunks,
+				      const void *d_in, const uint64_t *d_in_offsets,
+				      const uint64_t *d_in_nbytes,
+				      void *d_out, const uint64_t *d_out_offsets,
+				      const uint64_t *d_out_avail,
+				      uint64_t *d_out_nbytes, size_t max_in_nbytes,
+				      void *stream);
+
+/*
  * Decompress: d_results[i] receives the enum libdeflate_result of chunk i.
  * d_actual_in / d_actual_out may be NULL; a NULL d_actual_out has the
  * reference's meaning (the stream must fill d_out_avail[i] exactly, else

@@ -64,14 +64,26 @@ class Compressor:
         return out[:r].tobytes()
 
     def compress_batch(self, fmt, data, in_offsets, in_nbytes, out,
-                       out_offsets, out_avail, out_nbytes, stream=None):
+                       out_offsets, out_avail, out_nbytes, stream=None,
+                       max_chunk=None):
         """Device batch: all arguments are torch CUDA tensors (uint8 data,
-        int64 descriptors).  Enqueues on `stream` (torch stream or None)."""
-        check(self._lib.libdeflate_amd_compress_batch(
-            self._h, FORMATS[fmt], in_offsets.numel(), data.data_ptr(),
-            in_offsets.data_ptr(), in_nbytes.data_ptr(), out.data_ptr(),
-            out_offsets.data_ptr(), out_avail.data_ptr(),
-            out_nbytes.data_ptr(), _stream_ptr(stream)), "compress_batch")
+        int64 descriptors).  Enqueues on `stream` (torch stream or None).
+        max_chunk: an upper bound of the chunk sizes, if the caller knows one
+        (libdeflate_amd_compress_batch_bounded: small chunks get their own
+        kernel)."""
+        if max_chunk is None:
+            check(self._lib.libdeflate_amd_compress_batch(
+                self._h, FORMATS[fmt], in_offsets.numel(), data.data_ptr(),
+                in_offsets.data_ptr(), in_nbytes.data_ptr(), out.data_ptr(),
+                out_offsets.data_ptr(), out_avail.data_ptr(),
+                out_nbytes.data_ptr(), _stream_ptr(stream)), "compress_batch")
+        else:
+            check(self._lib.libdeflate_amd_compress_batch_bounded(
+                self._h, FORMATS[fmt], in_offsets.numel(), data.data_ptr(),
+                in_offsets.data_ptr(), in_nbytes.data_ptr(), out.data_ptr(),
+                out_offsets.data_ptr(), out_avail.data_ptr(),
+                out_nbytes.data_ptr(), int(max_chunk), _stream_ptr(stream)),
+                "compress_batch_bounded")
 
     def compress_batch_host(self, fmt, chunks, out_avail=None):
         """List of bytes -> list of compressed bytes (None where it did not

@@ -39,6 +39,7 @@ DROPIN_SYMBOLS = [
 BATCH_SYMBOLS = [
     "libdeflate_amd_device_ready", "libdeflate_amd_last_error",
     "libdeflate_amd_compress_batch", "libdeflate_amd_decompress_batch",
+    "libdeflate_amd_compress_batch_bounded",
     "libdeflate_amd_crc32_batch", "libdeflate_amd_adler32_batch",
     "libdeflate_amd_compress_batch_host",
     "libdeflate_amd_decompress_batch_host",
@@ -102,6 +103,8 @@ def load():
     sig("libdeflate_amd_adler32_batch", c_int, SZ, P, P, P, P, P, P)
     sig("libdeflate_amd_compress_batch", c_int, P, c_int, SZ, P, P, P, P, P,
         P, P, P)
+    sig("libdeflate_amd_compress_batch_bounded", c_int, P, c_int, SZ, P, P, P, P, P,
+        P, P, SZ, P)
     sig("libdeflate_amd_decompress_batch", c_int, P, c_int, SZ, P, P, P, P, P,
         P, P, P, P, P)
     sig("libdeflate_amd_compress_batch_host", c_int, P, c_int, SZ, P, P, P, P,

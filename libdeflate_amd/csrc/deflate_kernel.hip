@@ -67,13 +67,17 @@
 #ifndef TILE
 #define TILE 4096
 #endif
+#ifndef RING
 #define RING 32768u
+#endif
 #define RMASK (RING - 1)
 #define LOOKAHEAD 272u
 #ifndef HASH_BITS
 #define HASH_BITS 13
 #endif
+#ifndef HASH3_BITS
 #define HASH3_BITS 12
+#endif
 /*
  * The matches of the current block live in HBM (8 bytes each, one list per
  * workgroup): nothing of a block has to stay in LDS until the block is
@@ -130,9 +134,14 @@
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
 #endif
+#ifndef WQ_CAP
 #define WQ_CAP 2048u		/* round B items per round; the rest waits for the next round */
+#endif
 #define WQ_SEG (WQ_CAP / NWAVES)
-#define STG_WORDS ((TILE + 8) / 2 - 8)	/* staging: STG_WORDS + 8 words = sizeof nxtA */
+/* nxtA / nxtB: two scratch arrays of NXT_ELEMS u16 (round B lists of WQ_CAP
+ * u32 each, the bit staging area, block-end tables) */
+#define NXT_ELEMS (2 * WQ_CAP + 8)
+#define STG_WORDS (NXT_ELEMS / 2 - 8)	/* staging: STG_WORDS + 8 words = sizeof nxtA */
 
 #define M_FIRST 0x10000u
 #define M_LAST 0x20000u
@@ -157,9 +166,9 @@ struct deflate_lds {
 			u8 pre_lens[20];
 			u16 pre_codes[20];
 		};
-		u16 nxtB[TILE + 8];	/* live only during the token choice */
+		u16 nxtB[NXT_ELEMS];	/* live only during the token choice */
 	};
-	u16 nxtA[TILE + 8] __attribute__((aligned(16)));	/* S6: bit staging */
+	u16 nxtA[NXT_ELEMS] __attribute__((aligned(16)));	/* S6: bit staging */
 	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 obs[1][10];		/* block-split observations of the block before this tile */
@@ -181,7 +190,13 @@ struct deflate_lds {
 #endif
 typedef AS3 struct deflate_lds lds_t;
 
+#ifdef LDA_SMALL
+static_assert(sizeof(struct deflate_lds) <= 163840 / 3, "three workgroups per CU");
+static_assert(RING >= TILE && NXT_ELEMS * 2 >= 3600, "one tile per buffer; block-end tables fit nxtB");
+#else
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
+static_assert(NXT_ELEMS == TILE + 8, "levels 10-12 keep one u16 per position in nxtA");
+#endif
 static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at LDS offset 0");
 #define PREV_OFF ((u32)offsetof(struct deflate_lds, prev))
 
@@ -1979,6 +1994,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			overflow = true;
 		if (n64 > 0xFFFFFF00u)	/* positions are 32-bit here */
 			overflow = true;
+#ifdef LDA_SMALL
+		if (n64 > TILE)		/* the caller's size bound was wrong */
+			overflow = true;
+#endif
 		const u32 n = (u32)n64;
 
 		/* ---- per-buffer init ---- */
@@ -2149,8 +2168,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				/* ---- S3: search (see "progressive search") ---- */
 				const u32 min_len = L->vars[V_MINLEN];
 				const u32 dlim3 = mode ? 8192u : 4096u;
+#ifdef LDA_SMALL
+				const u32 lo_pos = 0;	/* the whole buffer is resident */
+#else
 				s32 lo_s = (s32)(t + 2 * TILE + LOOKAHEAD) - (s32)RING;
 				const u32 lo_pos = lo_s > 0 ? (u32)lo_s : 0;
+#endif
 				const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
 				if (wave == NWAVES - 1) {
 					/* the next tile's chain insertion: one wave's serial
@@ -2556,52 +2579,43 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (tid == 0)
 					L->freq[256]++;
 				__syncthreads();
-				/* rank sort of both alphabets by the whole workgroup:
-				 * thread (s, part) counts the keys below key(s) in one
-				 * third of the litlen alphabet; M[] is free scratch here */
+				/* rank sort of both alphabets by the whole workgroup: the
+				 * used symbols are collected first (their keys, freq << 9 |
+				 * symbol, in any order), then every key counts the keys
+				 * below it - a block uses a third of the litlen alphabet,
+				 * a small one a fifth; M[] is free scratch here */
 				{
-					u32 *rk = L->M;			/* [320] ranks */
+					u32 *keys = L->M;		/* [288] litlen, [288, 320) offset keys */
 					u32 *usedv = L->M + 320;	/* [2] used counts */
 					u16 *sortedO = (u16 *)(L->M + 324);	/* [32] */
-					for (u32 i = tid; i < 324; i += NT)
-						L->M[i] = 0;
+					if (tid < 2)
+						usedv[tid] = 0;
 					__syncthreads();
-#pragma unroll
-					for (u32 j = 0; j < VPT; j++) {
-						const u32 vt = tid * VPT + j;
-						if (vt < 864) {
-							u32 sidx = vt / 3, part = vt % 3;
-							u32 f = L->freq[sidx];
-							if (f) {
-								u32 key = (f << 9) | sidx, r = 0;
-								for (u32 q = part * 96; q < part * 96 + 96; q++) {
-									u32 ft = L->freq[q];
-									r += (ft != 0) & (((ft << 9) | q) < key);
-								}
-								atomicAdd(&rk[sidx], r);
-								if (part == 0)
-									atomicAdd(&usedv[0], 1u);
-							}
-						} else if (vt < 896) {
-							u32 sidx = vt - 864;
-							u32 f = L->freq[288 + sidx];
-							if (f) {
-								u32 key = (f << 9) | sidx, r = 0;
-								for (u32 q = 0; q < 32; q++) {
-									u32 ft = L->freq[288 + q];
-									r += (ft != 0) & (((ft << 9) | q) < key);
-								}
-								rk[288 + sidx] = r;
-								atomicAdd(&usedv[1], 1u);
-							}
+					for (u32 vt = tid; vt < 320; vt += NT) {
+						const u32 f = L->freq[vt];
+						if (f) {
+							if (vt < 288)
+								keys[atomicAdd(&usedv[0], 1u)] = (f << 9) | vt;
+							else
+								keys[288 + atomicAdd(&usedv[1], 1u)] =
+									(f << 9) | (vt - 288);
 						}
 					}
 					__syncthreads();
-					for (u32 vt = tid; vt < 320; vt += NT) {
-						if (vt < 288 && L->freq[vt])
-							L->sorted[rk[vt]] = (u16)vt;
-						else if (vt >= 288 && L->freq[vt])
-							sortedO[rk[vt]] = (u16)(vt - 288);
+					{
+						const u32 m1 = usedv[0], m2 = usedv[1];
+						for (u32 i = tid; i < m1 + m2; i += NT) {
+							const bool lit = i < m1;
+							const u32 lo = lit ? 0 : 288, m = lit ? m1 : m2;
+							const u32 key = keys[lit ? i : 288 + i - m1];
+							u32 r = 0;
+							for (u32 q = 0; q < m; q++)
+								r += keys[lo + q] < key;
+							if (lit)
+								L->sorted[r] = (u16)(key & 511);
+							else
+								sortedO[r] = (u16)(key & 511);
+						}
 					}
 					__syncthreads();
 					PROF_MARK(10);
@@ -3065,6 +3079,29 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	in_offsets, in_nbytes, out_base, out_offsets, out_avail_arr,           \
 	out_nbytes, sums, seq_scratch, seg_info, next_chunk
 
+#ifdef LDA_SMALL
+/* buffers of at most TILE bytes, 256 threads, three workgroups per CU:
+ * deflate_small.hip */
+/* (three workgroups per CU = three waves per SIMD: at most 168 VGPRs) */
+extern "C" __global__ void __launch_bounds__(NT, 3)
+lda_deflate_small_kernel(DEFLATE_KERNEL_PARAMS)
+{
+	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	deflate_batch_body<false>(DEFLATE_KERNEL_ARGS);
+}
+
+extern "C" size_t lda_deflate_small_lds_bytes(void)
+{
+	return sizeof(struct deflate_lds);
+}
+
+extern "C" size_t lda_deflate_small_max(void)
+{
+	return TILE;
+}
+
+LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate_small)
+#else
 extern "C" __global__ void __launch_bounds__(NT)
 lda_deflate_batch_kernel(DEFLATE_KERNEL_PARAMS)
 {
@@ -3096,3 +3133,5 @@ extern "C" size_t lda_deflate_seq_words(void)
 }
 
 LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate)
+
+#endif /* LDA_SMALL */

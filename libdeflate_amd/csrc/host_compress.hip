@@ -124,7 +124,7 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		    const uint64_t *d_in_nbytes, void *d_out,
 		    const uint64_t *d_out_offsets, const uint64_t *d_out_avail,
 		    uint64_t *d_out_nbytes, void *stream,
-		    const uint32_t *d_seg_info)
+		    const uint32_t *d_seg_info, size_t max_in_nbytes = SIZE_MAX)
 {
 	DeviceCtx *ctx = device_ctx();
 	hipStream_t st = (hipStream_t)stream;
@@ -139,8 +139,14 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		set_error("compress_batch: bad argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	/* scratch: [match lists: u64 x words x grid][chunk counter][sums u32 x n] */
-	size_t grid = n < (size_t)ctx->num_cus ? n : (size_t)ctx->num_cus;
+	/* buffers of at most 4 KiB (filesystem blocks): the 256-thread kernel,
+	 * three workgroups per CU (deflate_small.hip); levels 10-12 keep the
+	 * big one (their parse wants its LDS) */
+	const bool small = max_in_nbytes <= lda_deflate_small_max() &&
+			   c->level <= 9 && !d_seg_info && !getenv("LDA_NO_SMALL");
+	/* scratch: [token lists: u64 x words x grid][chunk counter][sums u32 x n] */
+	size_t grid_max = (size_t)ctx->num_cus * (small ? 3 : 1);
+	size_t grid = n < grid_max ? n : grid_max;
 	size_t seq_bytes = grid * lda_deflate_seq_words() * 8;
 	uint8_t *scr = (uint8_t *)c->scratch.reserve(seq_bytes + 16 + n * 4);
 	if (!scr)
@@ -159,8 +165,12 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 			return rc;
 	}
 	static bool attr_set[16];
-	size_t lds = lda_deflate_lds_bytes();
+	size_t lds = small ? lda_deflate_small_lds_bytes() : lda_deflate_lds_bytes();
 	if (!attr_set[ctx->device]) {
+		LDA_HIP_TRY(hipFuncSetAttribute(
+				(const void *)lda_deflate_small_kernel,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				(int)lda_deflate_small_lds_bytes()), LIBDEFLATE_AMD_NO_DEVICE);
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_deflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -172,9 +182,11 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		attr_set[ctx->device] = true;
 	}
 	const level_cfg &lv = k_levels[c->level];
-	hipLaunchKernelGGL(lv.mode == 3 ? lda_deflate_opt_kernel :
+	hipLaunchKernelGGL(small ? lda_deflate_small_kernel :
+			   lv.mode == 3 ? lda_deflate_opt_kernel :
 					  lda_deflate_batch_kernel, dim3((unsigned)grid),
-			   dim3(LDA_DEFLATE_THREADS), lds, st, (uint64_t)n, format, c->level,
+			   dim3(small ? LDA_DEFLATE_SMALL_THREADS : LDA_DEFLATE_THREADS),
+			   lds, st, (uint64_t)n, format, c->level,
 			   lv.depth, lv.nice, lv.mode, (const uint8_t *)d_in,
 			   d_in_offsets, d_in_nbytes, (uint8_t *)d_out,
 			   d_out_offsets, d_out_avail, d_out_nbytes, sums,
@@ -195,6 +207,21 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *c, int format,
 	return compress_batch_impl(c, format, n, d_in, d_in_offsets, d_in_nbytes,
 				   d_out, d_out_offsets, d_out_avail,
 				   d_out_nbytes, stream, NULL);
+}
+
+extern "C" LIBDEFLATEAPI int
+libdeflate_amd_compress_batch_bounded(struct libdeflate_compressor *c, int format,
+				      size_t n, const void *d_in,
+				      const uint64_t *d_in_offsets,
+				      const uint64_t *d_in_nbytes, void *d_out,
+				      const uint64_t *d_out_offsets,
+				      const uint64_t *d_out_avail,
+				      uint64_t *d_out_nbytes, size_t max_in_nbytes,
+				      void *stream)
+{
+	return compress_batch_impl(c, format, n, d_in, d_in_offsets, d_in_nbytes,
+				   d_out, d_out_offsets, d_out_avail,
+				   d_out_nbytes, stream, NULL, max_in_nbytes);
 }
 
 extern "C" LIBDEFLATEAPI int
@@ -240,9 +267,12 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 	if (rc != LIBDEFLATE_AMD_OK)
 		return rc;
 	uint64_t *d_desc = (uint64_t *)st;
-	rc = libdeflate_amd_compress_batch(c, format, n, st, d_desc, d_desc + n, st,
-					   d_desc + 2 * n, d_desc + 3 * n,
-					   d_desc + 4 * n, NULL);
+	size_t max_in = 0;
+	for (size_t i = 0; i < n; i++)
+		max_in = in_nbytes[i] > max_in ? in_nbytes[i] : max_in;
+	rc = libdeflate_amd_compress_batch_bounded(c, format, n, st, d_desc, d_desc + n,
+						   st, d_desc + 2 * n, d_desc + 3 * n,
+						   d_desc + 4 * n, max_in, NULL);
 	if (rc != LIBDEFLATE_AMD_OK)
 		return rc;
 	rc = libdeflate_amd_compact_batch(n, st, d_desc + 2 * n, d_desc + 4 * n,

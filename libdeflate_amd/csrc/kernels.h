@@ -64,6 +64,19 @@ lda_deflate_opt_kernel(uint64_t n_chunks, int format, int level,
 		       uint64_t *out_nbytes, const uint32_t *sums,
 		       uint64_t *seq_scratch, const uint32_t *seg_info,
 		       uint32_t *next_chunk);
+/* deflate_small.hip: buffers of at most lda_deflate_small_max() bytes */
+#define LDA_DEFLATE_SMALL_THREADS 256
+extern "C" __global__ void
+lda_deflate_small_kernel(uint64_t n_chunks, int format, int level,
+			 uint32_t depth, uint32_t nice, uint32_t mode,
+			 const uint8_t *in_base, const uint64_t *in_offsets,
+			 const uint64_t *in_nbytes, uint8_t *out_base,
+			 const uint64_t *out_offsets, const uint64_t *out_avail,
+			 uint64_t *out_nbytes, const uint32_t *sums,
+			 uint64_t *seq_scratch, const uint32_t *seg_info,
+			 uint32_t *next_chunk);
+extern "C" size_t lda_deflate_small_lds_bytes(void);
+extern "C" size_t lda_deflate_small_max(void);
 extern "C" size_t lda_deflate_tile(void);	/* positions per tile (dictionary granularity) */
 extern "C" size_t lda_deflate_lds_bytes(void);
 extern "C" size_t lda_deflate_seq_words(void);	/* u64 match-list entries per workgroup */

@@ -225,7 +225,7 @@ def test_small_blocks_zlib_level9(oracle):
     c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
     c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
     c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
-    c.compress_batch("zlib", data, in_off, in_n, comp, c_off, c_av, c_n)
+    c.compress_batch("zlib", data, in_off, in_n, comp, c_off, c_av, c_n, max_chunk=size)
     out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
     res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     d.decompress_batch("zlib", comp, c_off, c_n, out, in_off, in_n, res)
@@ -451,3 +451,49 @@ def test_batch_host_many_small_chunks():
     back = d.decompress_batch_host("zlib", comp, [size] * n)
     assert all(r[0] == 0 for r in back)
     assert all(back[i][3] == chunks[i] for i in range(0, n, 61))
+
+
+@pytest.mark.parametrize("level", [0, 1, 3, 6, 9])
+def test_small_buffer_kernel(level, oracle):
+    """Batches whose chunks are all <= 4096 bytes run on the 256-thread kernel
+    (deflate_small.hip; the host-pointer batch knows the sizes and picks it):
+    every size class around its limits, all content kinds, all formats; and
+    the device entry point with a size bound that a chunk violates reports 0
+    for that chunk only."""
+    import torch
+    from libdeflate_amd import api
+    rng = np.random.default_rng(0x0E110070 + level)
+    sizes = [0, 1, 2, 3, 4, 5, 18, 19, 31, 32, 33, 51, 52, 63, 64, 65, 255, 256,
+             511, 512, 513, 1000, 2047, 2048, 2049, 4000, 4094, 4095, 4096]
+    sizes += [int(rng.integers(0, 4097)) for _ in range(60)]
+    chunks = [_weird_chunk(rng, n) if i % 2 else datagen.chunk(i, n, 0x0E110071, datagen.MIX4K)
+              for i, n in enumerate(sizes)]
+    c = api.Compressor(level)
+    for fmt in ("deflate", "zlib", "gzip"):
+        comps = c.compress_batch_host(fmt, chunks)
+        for d, z in zip(chunks, comps):
+            _check_roundtrip(oracle, fmt, d, z, ("small", level, fmt, len(d)))
+            assert len(z) <= c.bound(fmt, len(d))
+    # too small an output slot -> 0 for that chunk, the others unaffected
+    avail = [c.bound("zlib", len(d)) for d in chunks]
+    big = max(range(len(chunks)), key=lambda i: len(chunks[i]))
+    avail[big] = 20
+    comps = c.compress_batch_host("zlib", chunks, out_avail=avail)
+    assert comps[big] is None and all(z is not None for i, z in enumerate(comps) if i != big)
+    # a chunk above the stated bound: 0 for it alone
+    n = 8
+    data = [datagen.chunk(i, 4096, 0x0E110072, datagen.MIX4K) for i in range(n)]
+    blob = torch.frombuffer(bytearray(b"".join(data) + bytes(4096)), dtype=torch.uint8).cuda()
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * 4096
+    in_n = torch.full((n,), 4096, dtype=torch.int64, device="cuda")
+    in_n[3] = 5000
+    bound = 5120
+    out = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+    o_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
+    o_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
+    o_n = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    c.compress_batch("deflate", blob, in_off, in_n, out, o_off, o_av, o_n, max_chunk=4096)
+    torch.cuda.synchronize()
+    got = o_n.cpu().numpy()
+    assert got[3] == 0 and (np.delete(got, 3) > 0).all()
+    c.close()

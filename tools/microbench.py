@@ -138,15 +138,18 @@ def bench_deflate(a, fmt="gzip", level=6):
     c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
     c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
     c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
-    f = lambda: c.compress_batch(fmt, data, offs, nb, comp, c_off, c_av, c_n)
+    f = lambda: c.compress_batch(fmt, data, offs, nb, comp, c_off, c_av, c_n, max_chunk=a.size)
     f(); torch.cuda.synchronize()
-    read_profile("libdeflate_amd_profile_read_deflate", PHASES_DEFLATE)  # reset
+    reader = ("libdeflate_amd_profile_read_deflate_small"
+              if a.size <= 4096 and level <= 9 and not os.environ.get("LDA_NO_SMALL")
+              else "libdeflate_amd_profile_read_deflate")
+    read_profile(reader, PHASES_DEFLATE)  # reset
     t = timeit(f, iters=a.iters, warmup=0)
     U = n * a.size
     C = int(c_n.sum())
     print(f"deflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic "
           f"{(U+C)/t/1e9:.2f} GB/s, {t*1e3:.2f} ms, ratio {C/U:.4f}")
-    read_profile("libdeflate_amd_profile_read_deflate", PHASES_DEFLATE)
+    read_profile(reader, PHASES_DEFLATE)
 
 
 if __name__ == "__main__":
