@@ -19,39 +19,44 @@
  *   head[]  most recent position per hash bucket; head3[] for 3-byte matches
  *   M[]     per-position best (length, distance) of the current tile
  *
- * and advances in TILES of 4096 positions:
+ * and advances in TILES of 4096 positions (each stage is a function below;
+ * deflate_batch_body() is the schedule):
  *
- *   S1  every lane hashes its positions; each wave bitonic-sorts 64
- *       (hash, position) keys with DPP exchanges so equal hashes become
- *       neighbours: that yields the in-order "previous occurrence" links
- *       inside the group without any serial insertion;
- *   S2  wave 0 threads the groups through head[] in position order (first /
- *       last of each hash run only), wave 1 does the same for head3[]; the
- *       other waves already search the part of the tile published so far;
- *   S3  ALL positions of the tile search their chain in parallel (depth and
- *       nice length per level as lib/deflate_compress.c:3927-3979), in
- *       alternating "walk" passes (8 chain steps, filtered on the byte at the
- *       best length so far) and "evaluate" passes (8-byte-at-a-time
- *       extension of the queued hits); waves claim work dynamically;
+ *   S0  input of this tile AND the next (the next tile joins the chains
+ *       while this one is searched);
+ *   S1+S2  chain insertion WITHOUT a sort (insert_tile): a masked LDS
+ *       exchange per position; conflicting lanes of one LDS atomic are
+ *       served in lane order, so 64 consecutive positions per instruction
+ *       get what a serial insertion loop would have returned.  One wave, one
+ *       tile ahead, beside round A;
+ *   S3  progressive search: round A - every position measures its two
+ *       nearest chain members (round_a); then, after a parse, round B - only
+ *       the positions that parse visited are searched to the full depth
+ *       (depth / nice length per level as lib/deflate_compress.c:3927-3979),
+ *       in packed generations of 16 chain steps (build_worklist,
+ *       search_queue).  Levels 10-12 search every position (search_items);
  *   S4  the greedy / lazy / lazy2 choice is a pure function of the
  *       per-position results (rules of deflate_compress.c:2573-2575,
- *       2712-2755): "next token start" is a forest over the positions, so
- *       the parse is pointer doubling per wave segment plus a short chain
- *       across segments; matches are appended to a per-workgroup list in HBM
- *       and the symbol histogram is built in the same pass;
+ *       2712-2755): steps position-parallel (stage_steps), the path by one
+ *       wave of 64 speculative segment walkers (parse_tile); the tokens go to
+ *       a per-workgroup list in HBM, the symbol histogram is built in the
+ *       same pass;
  *   S5  at block end (content-driven split, deflate_compress.c:2143-2256, or
  *       64 Ki positions): length-limited canonical Huffman codes, exact cost
  *       of dynamic / static / stored, header;
- *   S6  tokens are encoded position-parallel in windows of 4096 positions:
- *       every lane looks up its codeword(s), a workgroup prefix sum of the
+ *   S6  the tokens are encoded one per thread: a workgroup prefix sum of the
  *       bit lengths gives the bit offset, ds_or packs the bits into an LDS
  *       staging buffer that is written to HBM with coalesced stores.
  *
- * HBM traffic beyond input-once / output-once: the match list (8 B per match,
- * written in S4, read in S6) and literals of a block that have left the LDS
- * ring by the time the block is flushed.  The compressed bytes differ from
- * the reference's (libdeflate.h:76-83 leaves them unpinned); validity, round
- * trip, compress_bound and ratio-vs-reference are what the tests check.
+ * HBM traffic beyond input-once / output-once: the token list (4 B per token,
+ * written in S4, read in S6) and the 3-byte-table candidates (2 B per
+ * position, from the inserting wave to the next tile's round A).  The
+ * compressed bytes differ from the reference's (libdeflate.h:76-83 leaves
+ * them unpinned); validity, round trip, compress_bound and
+ * ratio-vs-reference are what the tests check.
+ *
+ * deflate_small.hip compiles this file a second time (LDA_SMALL: 256 threads,
+ * one tile of state) for batches of buffers of at most 4096 bytes.
  */
 #include <stddef.h>
 #include "device_common.h"
@@ -100,7 +105,6 @@
 #define TOK_CAP (MAX_BLOCK_LEN + 2 * TILE + 64)	/* u32 entries */
 #define SEQ_GCAP (TOK_CAP / 2)			/* the same in u64 words */
 #define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256 + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
-#define EWIN TILE		/* encode window (positions) */
 #ifndef S3_WALK
 #define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
 #endif
@@ -143,8 +147,6 @@
 #define NXT_ELEMS (2 * WQ_CAP + 8)
 #define STG_WORDS (NXT_ELEMS / 2 - 8)	/* staging: STG_WORDS + 8 words = sizeof nxtA */
 
-#define M_FIRST 0x10000u
-#define M_LAST 0x20000u
 #define M_VALID 0x40000u
 
 struct deflate_lds {
@@ -152,7 +154,7 @@ struct deflate_lds {
 	u16 prev[RING];
 	u16 head[1u << HASH_BITS];
 	u16 head3[1u << HASH3_BITS];	/* last position per 3-byte hash (no chain) */
-	u32 M[TILE + 8];	/* tile scratch; encode: KD[EWIN] + staging */
+	u32 M[TILE + 8];	/* tile scratch: best length | distance << 16 per position; block end: Huffman scratch */
 	u8 done[TILE + 8];	/* search depth class a position has had: DC_* */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
 	union {
@@ -201,9 +203,8 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 #define PREV_OFF ((u32)offsetof(struct deflate_lds, prev))
 
 enum {
-	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPILL, V_NPRE, V_TMP0, V_TMP1,
-	V_TMP2, V_TMP3, V_CTR, V_MINLEN, V_SPILL1, V_SEQCNT, V_SEQCNT1, V_READY,
-	V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT, V_WCNT
+	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
+	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT
 };
 
 /* depth classes of the progressive search (done[]): what a position has been

@@ -159,22 +159,29 @@ static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 #define PROF_COUNT(slot, v) do { unsigned long long v_ = (v); if (threadIdx.x == 0) \
 		atomicAdd(&lda_prof[slot], v_); } while (0)
 /* section timers kept in registers, flushed once per tile by PROF_SEC_FLUSH */
-#define PROF_SEC_DECL unsigned long long sec_[4] = { 0, 0, 0, 0 }, sec_t_ = __builtin_readcyclecounter()
+#define PROF_SEC_DECL unsigned long long sec_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, sec_t_ = __builtin_readcyclecounter()
 #define PROF_SEC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); \
 		sec_[i] += n_ - sec_t_; sec_t_ = n_; } while (0)
 #define PROF_SEC_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 4; i_++) \
 		atomicAdd(&lda_prof[(base) + i_], sec_[i_]); } while (0)
+#define PROF_SEC_FLUSH8(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) \
+		atomicAdd(&lda_prof[(base) + i_], sec_[i_]); } while (0)
+#define PROF_SEC_ADD(i, v) do { sec_[i] += (v); } while (0)
 #else
 #define PROF_COUNT(slot, v) do { } while (0)
 #define PROF_SEC_DECL
 #define PROF_SEC(i) do { } while (0)
 #define PROF_SEC_FLUSH(base) do { } while (0)
+#define PROF_SEC_FLUSH8(base) do { } while (0)
+#define PROF_SEC_ADD(i, v) do { } while (0)
 #endif
 #else
 #define PROF_COUNT(slot, v) do { } while (0)
 #define PROF_SEC_DECL
 #define PROF_SEC(i) do { } while (0)
 #define PROF_SEC_FLUSH(base) do { } while (0)
+#define PROF_SEC_FLUSH8(base) do { } while (0)
+#define PROF_SEC_ADD(i, v) do { } while (0)
 #define PROF_DECL
 #define PROF_START() do { } while (0)
 #define PROF_MARK(slot) do { } while (0)

@@ -525,14 +525,15 @@ ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
 #ifndef PAR_CB
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
 #endif
-#ifndef PAR_TOKCAP
-#define PAR_TOKCAP 8192u	/* tokens per round held in the wave's scratch */
-#endif
+#define PAR_LANECAP (PAR_CB / 2)	/* tokens one lane may find in its piece (2 bits each) */
+#define PAR_SCRATCH (64u * PAR_LANECAP)	/* u32 words per wave */
+#define PAR_MAP_BYTES (256u + 128u)	/* tok_fetch: marks + tbase table */
 enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
 
 struct par_bits {
 	u64 buf;
 	u64 nb;		/* next input byte to load */
+	u64 nxt;	/* the 8 bytes at nb, loaded one token ahead */
 	u32 cnt;
 };
 
@@ -542,18 +543,27 @@ struct par_bits {
 #define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
 static_assert(PAR_SPAN <= 256u * 4 + 2 * 1088u, "the staged input span shares the copy phase's LDS");
 
-static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
+static __device__ __forceinline__ u64 pb_load(const u8 *inp, u64 nb)
 {
 	const u32 *w = (const u32 *)inp;
-	u32 i = (u32)b->nb >> 2, sh = (u32)b->nb & 3;
+	u32 i = (u32)nb >> 2, sh = (u32)nb & 3;
 	if (i + 2 >= PAR_SPAN / 4)	/* stopped lanes only; keeps reads inside */
 		i = PAR_SPAN / 4 - 3;
 	u32 a = w[i], c = w[i + 1], d = w[i + 2];
-	u64 v = ((u64)__builtin_amdgcn_alignbyte(d, c, sh) << 32) |
-		__builtin_amdgcn_alignbyte(c, a, sh);
-	b->buf |= v << b->cnt;
+	return ((u64)__builtin_amdgcn_alignbyte(d, c, sh) << 32) |
+	       __builtin_amdgcn_alignbyte(c, a, sh);
+}
+
+/* The bytes a refill adds start at nb whatever the bit count is, so they are
+ * loaded right after the previous refill moved nb: the LDS round trip runs
+ * beside the decode of the token in between instead of in front of the next
+ * one (the refill rule itself is decompress_template.h's REFILL_BITS). */
+static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
+{
+	b->buf |= b->nxt << b->cnt;
 	b->nb += (63 - b->cnt) >> 3;
 	b->cnt |= 56;
+	b->nxt = pb_load(inp, b->nb);
 }
 
 static __device__ __forceinline__ void pb_init(struct par_bits *b, const u8 *inp, u64 pos)
@@ -561,6 +571,7 @@ static __device__ __forceinline__ void pb_init(struct par_bits *b, const u8 *inp
 	b->nb = pos >> 3;
 	b->buf = 0;
 	b->cnt = 0;
+	b->nxt = pb_load(inp, b->nb);
 	pb_refill(b, inp);
 	b->buf >>= (u32)pos & 7;
 	b->cnt -= (u32)pos & 7;
@@ -576,41 +587,54 @@ struct par_token {
 
 /*
  * Codewords longer than the primary tables.  All lanes of a wave parse the
- * same block, so the canonical first-code / count / index triples of the
- * lengths beyond the table are wave-uniform: they are fetched once per round
- * (par_long_init) and the search over the remaining lengths is branch-free.
+ * same block, so everything about the lengths beyond the table is
+ * wave-uniform and fetched once per round (par_long_init).  Left-justified
+ * to 16 bits, canonical codewords grow with their length (deflate's
+ * canonical code, RFC 1951 3.2.2), so the length of a long codeword is the
+ * number of per-length upper limits it reaches: one compare and one
+ * conditional add per length, which also accumulate what turns the codeword
+ * into its rank among the sorted symbols.
  */
 struct par_long {
-	u32 first[16], count[16], index[16];
+	u32 limit[16];	/* (first + count) << (16 - l): end of length l */
+	u32 inc[16];	/* 1 | (adj[l + 1] - adj[l]) << 16 */
+	u32 acc0;	/* from | adj[from] << 16; adj[l] = index[l] - first[l] */
 };
 
 static __device__ __forceinline__ void
 par_long_init(struct par_long *pl, const struct canon16 *cn, u32 from)
 {
+	u32 adj[16];
 #pragma unroll
 	for (u32 l = 1; l < 16; l++) {
 		if (l >= from) {
-			pl->first[l] = bcast_first(cn->first[l]);
-			pl->count[l] = bcast_first(cn->count[l]);
-			pl->index[l] = bcast_first(cn->index[l]);
+			const u32 first = bcast_first(cn->first[l]);
+			const u32 count = bcast_first(cn->count[l]);
+			const u32 index = bcast_first(cn->index[l]);
+			pl->limit[l] = (first + count) << (16 - l);
+			adj[l] = (index - first) & 0xFFFF;
 		}
 	}
+	pl->acc0 = from | (adj[from] << 16);
+#pragma unroll
+	for (u32 l = 1; l < 15; l++)
+		if (l >= from)
+			pl->inc[l] = 1 + (((adj[l + 1] - adj[l]) & 0xFFFF) << 16);
 }
 
-template <u32 FROM> static __device__ __forceinline__ u32
+template <u32 FROM, u32 MASK> static __device__ __forceinline__ u32
 par_long_decode(const struct par_long *pl, const u16 *sorted, u64 bits, u32 *len_ret)
 {
-	const u32 rev = __brev((u32)bits);	/* first code bit on top */
-	u32 idx = 0, len = 15;
+	const u32 rev = __brev((u32)bits) >> 16;	/* first code bit on top */
+	u32 acc = pl->acc0;
 #pragma unroll
-	for (u32 l = 15; l >= FROM; l--) {	/* prefix-free: at most one hit */
-		u32 rel = (rev >> (32 - l)) - pl->first[l];
-		bool hit = rel < pl->count[l];
-		idx = hit ? pl->index[l] + rel : idx;
-		len = hit ? l : len;
-	}
+	for (u32 l = FROM; l < 15; l++)
+		acc += rev >= pl->limit[l] ? pl->inc[l] : 0;
+	const u32 len = acc & 15;
 	*len_ret = len;
-	return sorted[idx];
+	/* lanes that are not on a long codeword compute nonsense: keep the
+	 * read inside the stream's tables */
+	return sorted[((acc >> 16) + (rev >> (16 - len))) & MASK];
 }
 
 static __device__ __forceinline__ struct par_token
@@ -623,31 +647,34 @@ par_decode(const struct stream_lds *S, const struct shared_lds *SH,
 
 	if (__ballot(cl == 0)) {
 		u32 l2;
-		u32 sym = par_long_decode<LIT_TB + 1>(pll, S->lit_sorted, buf, &l2);
+		u32 sym = par_long_decode<LIT_TB + 1, 511>(pll, S->lit_sorted, buf, &l2);
 		if (cl == 0) {
 			cl = l2;
 			kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
 			pay = sym < 256 ? sym : sym - 257;
 		}
 	}
+	/* base and extra-bit count of the length / distance symbol are computed:
+	 * a handful of ALU operations where a table would put another LDS round
+	 * trip on the token-to-token dependence chain */
 	u64 bb = buf >> cl;
-	u32 lt = SH->len_tab[pay & 31];
-	u32 xb = lt >> 16;
-	t.length = (lt & 0xFFFF) + ((u32)bb & ((1u << xb) - 1));
+	u32 lbase, xb;
+	len_sym(pay & 31, &lbase, &xb);
+	t.length = lbase + ((u32)bb & ((1u << xb) - 1));
 	bb >>= xb;
 	u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
 	u32 ol = e2 & 15, osym = e2 >> 4;
 	if (__ballot(kind == K_LEN && ol == 0)) {
 		u32 l2;
-		u32 sym = par_long_decode<OFF_TB + 1>(plo, S->off_sorted, bb, &l2);
+		u32 sym = par_long_decode<OFF_TB + 1, 31>(plo, S->off_sorted, bb, &l2);
 		if (ol == 0) {
 			ol = l2;
 			osym = sym;
 		}
 	}
-	u32 dt = SH->dist_tab[osym & 31];
-	u32 dxb = dt >> 16;
-	t.dist = (dt & 0xFFFF) + ((u32)(bb >> ol) & ((1u << dxb) - 1));
+	u32 dbase, dxb;
+	off_sym(osym & 31, &dbase, &dxb);
+	t.dist = dbase + ((u32)(bb >> ol) & ((1u << dxb) - 1));
 	t.kind = kind;
 	t.lit = pay & 0xFF;
 	t.used = cl + (kind == K_LEN ? xb + ol + dxb : 0);
@@ -678,11 +705,99 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 	return ((u64)bcast_lane((u32)(v >> 32), l) << 32) | bcast_lane((u32)v, l);
 }
 
+typedef __attribute__((address_space(1))) u8 gu8;	/* output bytes in HBM */
+typedef __attribute__((address_space(3))) u8 lu8;	/* LDS */
+
+/*
+ * Output positions [flushed, end) are in the LDS mirror and not yet in
+ * memory: store the whole 4-byte words among them (words of the POSITION, the
+ * alignment the mirror can be read with) and return the new 'flushed'.  The
+ * rest, less than a word, waits for the next group or the end of the round.
+ */
+static __device__ __forceinline__ u64
+flush_ring(gu8 *gout, const u8 *win, u64 flushed, u64 end, u32 lane)
+{
+	u64 a = (flushed + 3) & ~(u64)3;
+	if (a > end)
+		return flushed;
+	if (flushed + lane < a)		/* up to 3 bytes in front of the first word */
+		gout[flushed + lane] = win[(u32)(flushed + lane) & (PAR_RW - 1)];
+	const u64 e = end & ~(u64)3;
+	if (e <= a)
+		return a;
+	const u32 nw = (u32)(e - a) >> 2;
+	gu8 *dst = gout + a;
+	const u32 a32 = (u32)a;
+	for (u32 w = lane; w < nw; w += 64) {
+		const u32 v = *(const u32 *)(win + ((a32 + 4 * w) & (PAR_RW - 1)));
+		__builtin_memcpy(dst + 4 * w, &v, 4);
+	}
+	return e;
+}
+
+/*
+ * Tokens g + 4 * lane .. + 3 of the round, in stream order, from the
+ * lane-interleaved rows.  Lane l owns tokens [tbase, tbase + cnt); every
+ * owner whose range starts inside the group drops its number at that token,
+ * a running maximum spreads it (the tokens before the first mark belong to
+ * the owner of token g).  Words past `total` read as 0.
+ */
+static __device__ __forceinline__ uint4
+tok_fetch(const u32 *__restrict__ rows, u8 *mk, const u16 *tb, u32 tbase,
+	  u32 cnt, u32 g, u32 total, u32 lane)
+{
+	((u32 *)mk)[lane] = 0;
+	const u64 holds = __ballot(cnt != 0 && tbase <= g && g - tbase < cnt);
+	const u32 first = holds ? (u32)__builtin_ctzll(holds) + 1 : 1;
+	wave_sync();
+	if (cnt != 0 && tbase - g - 1 < 255u)	/* g < tbase < g + 256 */
+		mk[tbase - g] = (u8)(lane + 1);
+	wave_sync();
+	const u32 m4 = ((const u32 *)mk)[lane];
+	u32 o[4];
+	o[0] = m4 & 0xFF;
+	o[1] = (m4 >> 8) & 0xFF;
+	o[2] = (m4 >> 16) & 0xFF;
+	o[3] = m4 >> 24;
+	o[1] = o[1] > o[0] ? o[1] : o[0];
+	o[2] = o[2] > o[1] ? o[2] : o[1];
+	o[3] = o[3] > o[2] ? o[3] : o[2];
+	/* exclusive running maximum of the lanes' last values */
+	u32 c = o[3];
+#define DPP_MAX(ctrl, rm, bc)                                                  \
+	do {                                                                   \
+		u32 t_ = __builtin_amdgcn_update_dpp(0, c, ctrl, rm, 0xF, bc);  \
+		c = c > t_ ? c : t_;                                           \
+	} while (0)
+	DPP_MAX(0x111, 0xF, true);
+	DPP_MAX(0x112, 0xF, true);
+	DPP_MAX(0x114, 0xF, true);
+	DPP_MAX(0x118, 0xF, true);
+	DPP_MAX(0x142, 0xA, false);
+	DPP_MAX(0x143, 0xC, false);
+#undef DPP_MAX
+	c = __builtin_amdgcn_update_dpp(0, c, 0x138, 0xF, 0xF, true);	/* wave_shr:1, lane 0 gets 0 */
+	c = c > first ? c : first;
+	u32 w[4];
+#pragma unroll
+	for (u32 j = 0; j < 4; j++) {
+		const u32 own = (o[j] > c ? o[j] : c) - 1;
+		const u32 i = g + 4 * lane + j;
+		const u32 row = i - tb[own];
+		w[j] = i < total ? rows[row * 64 + own] : 0;
+	}
+	return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 /*
  * One round.  bpos0: bit position (in inp) of the next token; out0: bytes
- * produced so far.  Returns PAR_STOP with nothing changed, or PAR_OK /
- * PAR_EOB with *bpos_ret / *out_ret advanced (PAR_EOB: the end-of-block
- * symbol was consumed).
+ * produced so far.  Returns PAR_STOP with the decoder's position unchanged,
+ * or PAR_OK / PAR_EOB with *bpos_ret / *out_ret advanced (PAR_EOB: the
+ * end-of-block symbol was consumed).  After PAR_STOP the sequential decoder
+ * takes the same bits; the only case in which the round has already written
+ * output by then is a match distance that reaches back before the stream,
+ * found while its group is executed - the bytes written before it are the
+ * ones the sequential decoder writes again before it reports the error.
  */
 static __device__ u32
 par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
@@ -698,6 +813,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	const u64 byte0 = bpos_abs >> 3;
 	if (byte0 + 64 > in_n)
 		return PAR_STOP;
+	u32 *__restrict__ tokS = tok;	/* [PAR_LANECAP][64]: row k holds every lane's k-th token */
 	/* long pieces need fewer rounds and fewer passes per round (a parse
 	 * falls in step within ~50 bits); when the input left would not fill
 	 * the 64 lanes with them, shorter pieces keep more lanes busy */
@@ -738,18 +854,22 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			eob = false;
 		}
 		while (__ballot(run)) {
+			PROF_SEC_ADD(1, 1);
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, inp);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
 			if (run) {
+				b.buf >>= t.used;
+				b.cnt -= t.used;
 				if (t.kind == K_EOB) {
 					eob = true;
 					run = false;
-					b.buf >>= t.used;
-					b.cnt -= t.used;
 				} else {
-					b.buf >>= t.used;
-					b.cnt -= t.used;
+					/* row ntok of the lane-interleaved list: the 64
+					 * lanes of an iteration write one 256-byte row */
+					if (ntok < PAR_LANECAP)
+						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
+							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
 				}
@@ -777,10 +897,11 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	bool valid = lane <= K;
 	u32 tcnt = valid ? ntok : 0;
 	u32 tbase = wave_scan_incl(tcnt) - tcnt;
-	if (tbase + tcnt > PAR_TOKCAP)
-		valid = false;
 	{
-		const u64 vm = __ballot(valid);
+		u64 vm = __ballot(valid);
+		const u64 over = __ballot(lane <= K && ntok > PAR_LANECAP);
+		if (over)	/* a lane whose row list overflowed, and all after it */
+			vm &= (1ull << __builtin_ctzll(over)) - 1;
 		const u32 nv = __builtin_popcountll(vm);	/* a prefix of lanes */
 		if (nv == 0)
 			return PAR_STOP;
@@ -800,40 +921,15 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	if (end_bits > 8 * in_n)
 		return PAR_STOP;
 
-	/* ---- emit the tokens ---- */
-	{
-		struct par_bits b;
-		bool run = valid, bad = false;
-		u32 k = tbase;
-		u64 opos = out0 + obase;
-		pb_init(&b, inp, start);
-		while (__ballot(run)) {
-			run = run && PB_POS(b) < cend;
-			pb_refill(&b, inp);
-			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
-			if (run) {
-				b.buf >>= t.used;
-				b.cnt -= t.used;
-				if (t.kind == K_EOB) {
-					run = false;
-				} else if (t.kind == K_LEN) {
-					if (t.dist > opos)
-						bad = true;
-					tok[k] = 0x80000000u | t.length | (t.dist << 9);
-					k++;
-					opos += t.length;
-				} else {
-					tok[k] = t.lit;
-					k++;
-					opos++;
-				}
-			}
-		}
-		if (__ballot(bad))
-			return PAR_STOP;
-	}
+	/* Every lane's last parse started at its exact position, so the rows it
+	 * wrote then are its tokens: no further parse.  Token i of the round
+	 * (stream order) is row i - tbase[l] of the lane l whose range holds i;
+	 * the copy phase finds l per group (tok_fetch). */
+	u8 *mk = stage + PAR_STAGE_BYTES;		/* [256] group token -> lane + 1 */
+	u16 *tb = (u16 *)(mk + 256);			/* [64] tbase per lane */
+	const u32 own_cnt = valid ? tcnt : 0;
+	tb[lane] = (u16)tbase;
 	wave_sync();
-	PROF_SEC(1);
 	/* ---- execute the tokens: up to 256 tokens / PAR_GBYTES bytes a group ----
 	 * The copies of a group are resolved per output BYTE, not per token:
 	 * byte b of the group is a literal, or a copy of the byte dist before
@@ -844,18 +940,23 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * doubling takes every byte to its root in log2(chain) steps whatever
 	 * the shape of the dependencies, the roots fetch their values (the LDS
 	 * mirror of the recent output, or the output itself when it is further
-	 * back) and the rest read theirs from their root. */
+	 * back) and the rest read theirs from their root.  The bytes meet in the
+	 * LDS mirror; the output is written from there in whole words once per
+	 * group (flush_ring). */
 	{
 		u32 *tk = (u32 *)stage;			/* [256] the group's tokens */
 		u16 *R = (u16 *)((u32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */
+		gu8 *gout = (gu8 *)outp;
 		u64 gbase = out0;
+		u64 flushed = out0;	/* output below this is in memory */
 		u32 g = 0;		/* a multiple of 4: 16-byte token loads */
+		/* four consecutive tokens per lane; the next group's are requested
+		 * as soon as this group's extent is known, so their trip to the
+		 * scratch runs beside the group's LDS work */
+		uint4 tq_next = tok_fetch(tokS, mk, tb, tbase, own_cnt, 0, total_tok, lane);
 		while (g < total_tok) {
-			/* four consecutive tokens per lane */
 			const u32 ti0 = g + 4 * lane;
-			uint4 tq = make_uint4(0, 0, 0, 0);
-			if (ti0 < total_tok)
-				tq = *(const uint4 *)(tok + ti0);
+			const uint4 tq = tq_next;
 			const u32 tw4[4] = { tq.x, tq.y, tq.z, tq.w };
 			u32 len4[4], lsum = 0;
 #pragma unroll
@@ -869,6 +970,9 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			const bool fits = ti0 < total_tok && incl0 <= PAR_GBYTES;
 			const u32 cnt = __builtin_popcountll(__ballot(fits));
 			const u32 gtot = bcast_lane(incl0, cnt - 1);
+			if (g + 4 * cnt < total_tok)
+				tq_next = tok_fetch(tokS, mk, tb, tbase, own_cnt,
+						    g + 4 * cnt, total_tok, lane);
 			/* byte -> token: every token drops its number at its first
 			 * byte, a running maximum over the bytes spreads it */
 			for (u32 b0 = lane; b0 < gtot; b0 += 64)
@@ -885,6 +989,20 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				}
 			}
 			wave_sync();
+			/* a source `rel` bytes before the group is still in the mirror
+			 * when the group's own bytes have not overwritten it and the
+			 * mirror has been kept that far back */
+			const u32 gb = (u32)gbase;
+			u32 ring_rel = PAR_RW - gtot;
+			if (gbase - ring_lo < ring_rel)
+				ring_rel = (u32)(gbase - ring_lo);
+			/* sources further back come from the output itself: base + a
+			 * non-negative 32-bit lane offset (distances are <= 32768) */
+			const gu8 *gfar = (const gu8 *)((uintptr_t)gout + gbase - 32768);
+			/* a distance that reaches back before the stream: possible only
+			 * in the first 32 KiB */
+			const u32 back_max = gbase < 32768 ? (u32)gbase : 32768u;
+			bool bad = false;
 			/* The slots (64 bytes each) are independent except for the
 			 * running maximum, so the steps below work on SB slots at a
 			 * time: the LDS / HBM reads of a batch are all issued before
@@ -892,8 +1010,12 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			 * slot). */
 			enum { SB = 4 };
 			u32 carry = 0;
+			bool inside_any = false;
+			PROF_SEC(2);
+			PROF_SEC_ADD(6, 1);
 			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-				u32 own[SB], vv[SB];
+				u32 own[SB], vv[SB], fofs[SB];
+				bool far[SB];
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane;
@@ -927,86 +1049,107 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane, tw = own[k];
 					const u32 dist = (tw >> 9) & 0xFFFF;
-					u32 src = bi, v = tw & 0xFF;
-					if (bi < gtot && (tw >> 31)) {
-						if (dist <= bi) {
-							src = bi - dist;
-						} else {
-							const u64 sp = gbase + bi - dist;
-							v = sp >= ring_lo &&
-							    gbase + gtot - sp <= PAR_RW ?
-								win[(u32)sp & (PAR_RW - 1)] : outp[sp];
-						}
+					const bool match = (tw >> 31) != 0;	/* false past gtot */
+					const bool inside = match && dist <= bi;
+					const bool before = match && dist > bi;
+					/* every lane reads the mirror (the index is always
+					 * inside it); only `before` lanes use the byte */
+					const u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
+					const bool toofar = before && dist - bi > back_max;
+					far[k] = before && !toofar && dist - bi > ring_rel;
+					fofs[k] = bi + 32768u - dist;
+					bad |= toofar;
+					vv[k] = before ? wv : tw & 0xFF;
+					own[k] = inside ? bi - dist : bi;
+					inside_any |= inside;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					if (__ballot(far[k])) {
+						if (far[k])
+							vv[k] = gfar[fofs[k]];
 					}
-					own[k] = src;
-					vv[k] = v;
 				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane;
 					if (bi < gtot) {
 						R[bi] = (u16)own[k];
-						if (own[k] == bi) {
-							win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)vv[k];
-							outp[gbase + bi] = (u8)vv[k];
-						}
+						if (own[k] == bi)
+							win[(gb + bi) & (PAR_RW - 1)] = (u8)vv[k];
 					}
 				}
 			}
 			wave_sync();
-			/* pointer doubling to the roots */
-			for (;;) {
-				bool changed = false;
+			PROF_SEC(3);
+			if (__ballot(bad)) {
+				/* Invalid stream.  The sequential decoder takes the
+				 * round's bits again and reports it at the token where
+				 * it belongs; what the earlier groups wrote is what it
+				 * will write again, and the mirror is not used across
+				 * an abandoned round. */
+				return PAR_STOP;
+			}
+			if (__ballot(inside_any)) {
+				/* pointer doubling to the roots */
+				for (;;) {
+					bool changed = false;
+					PROF_SEC_ADD(7, 1);
+					for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
+						u32 r[SB], rr[SB];
+#pragma unroll
+						for (u32 k = 0; k < SB; k++) {
+							const u32 bi = s0 + 64 * k + lane;
+							r[k] = bi < gtot ? R[bi] : 0;
+						}
+#pragma unroll
+						for (u32 k = 0; k < SB; k++)
+							rr[k] = R[r[k]];
+#pragma unroll
+						for (u32 k = 0; k < SB; k++) {
+							const u32 bi = s0 + 64 * k + lane;
+							if (bi < gtot) {
+								changed |= rr[k] != r[k];
+								R[bi] = (u16)rr[k];
+							}
+						}
+					}
+					wave_sync();
+					if (!__ballot(changed))
+						break;
+				}
+				PROF_SEC(4);
+				/* everyone else copies its root's value */
 				for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-					u32 r[SB], rr[SB];
+					u32 r[SB], vv[SB];
 #pragma unroll
 					for (u32 k = 0; k < SB; k++) {
 						const u32 bi = s0 + 64 * k + lane;
-						r[k] = bi < gtot ? R[bi] : 0;
+						r[k] = bi < gtot ? R[bi] : bi;
 					}
 #pragma unroll
 					for (u32 k = 0; k < SB; k++)
-						rr[k] = R[r[k]];
+						vv[k] = win[(gb + r[k]) & (PAR_RW - 1)];
 #pragma unroll
 					for (u32 k = 0; k < SB; k++) {
 						const u32 bi = s0 + 64 * k + lane;
-						if (bi < gtot) {
-							changed |= rr[k] != r[k];
-							R[bi] = (u16)rr[k];
-						}
+						if (bi < gtot && r[k] != bi)
+							win[(gb + bi) & (PAR_RW - 1)] = (u8)vv[k];
 					}
 				}
 				wave_sync();
-				if (!__ballot(changed))
-					break;
 			}
-			/* everyone else copies its root's value */
-			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-				u32 r[SB], vv[SB];
-#pragma unroll
-				for (u32 k = 0; k < SB; k++) {
-					const u32 bi = s0 + 64 * k + lane;
-					r[k] = bi < gtot ? R[bi] : bi;
-				}
-#pragma unroll
-				for (u32 k = 0; k < SB; k++)
-					vv[k] = win[(u32)(gbase + r[k]) & (PAR_RW - 1)];
-#pragma unroll
-				for (u32 k = 0; k < SB; k++) {
-					const u32 bi = s0 + 64 * k + lane;
-					if (bi < gtot && r[k] != bi) {
-						win[(u32)(gbase + bi) & (PAR_RW - 1)] = (u8)vv[k];
-						outp[gbase + bi] = (u8)vv[k];
-					}
-				}
-			}
-			wave_sync();
 			gbase += gtot;
+			flushed = flush_ring(gout, win, flushed, gbase, lane);
+			PROF_SEC(5);
 			g += 4 * cnt;
 		}
+		/* the last bytes (less than a word) */
+		if (flushed + lane < gbase)
+			gout[flushed + lane] = win[(u32)(flushed + lane) & (PAR_RW - 1)];
+		wave_sync();
 	}
-	PROF_SEC(2);
-	PROF_SEC_FLUSH(18);
+	PROF_SEC_FLUSH8(16);
 	*bpos_ret = end_bits;
 	*out_ret = out0 + total_bytes;
 	return has_eob ? PAR_EOB : PAR_OK;
@@ -1717,7 +1860,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 
 /*
  * Wave per stream with sub-block parallel token decoding; persistent grid
- * (each wave owns PAR_TOKCAP words of the token scratch and walks the
+ * (each wave owns PAR_SCRATCH words of the token scratch and walks the
  * streams first, first + gridDim.x, ...).
  */
 #ifndef PAR_WAVES_PER_SIMD
@@ -1737,7 +1880,7 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 			u64 *__restrict__ actual_out)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_TOKCAP;
+	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_SCRATCH;
 
 	/* Which streams share a CU follows from the dispatch order (workgroup i
 	 * goes to XCD i mod 8, then CU by CU), so a batch whose content is
@@ -1768,14 +1911,16 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 	}
 }
 
+/* u32 words of token scratch per wave: the lane-interleaved rows of the
+ * parse and the list in stream order */
 extern "C" size_t lda_inflate_tokcap(void)
 {
-	return PAR_TOKCAP;
+	return PAR_SCRATCH;
 }
 
 extern "C" size_t lda_inflate_window_bytes(void)
 {
-	return PAR_RW + PAR_STAGE_BYTES;	/* output mirror + staged input span */
+	return PAR_RW + PAR_STAGE_BYTES + PAR_MAP_BYTES;	/* output mirror, staged input span / copy scratch, token map */
 }
 
 /* host helper: LDS bytes per stream */

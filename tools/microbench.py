@@ -87,7 +87,10 @@ def read_profile(name, labels):
     for i, v in enumerate(buf):
         if v:
             lab = labels[i] if i < len(labels) else f"slot{i}"
-            print(f"    {lab:16s} {v/1e6:12.1f} Mcyc  {100*v/tot:5.1f}%")
+            if lab.startswith("#"):
+                print(f"    {lab:22s} {v:14d}")
+            else:
+                print(f"    {lab:22s} {v/1e6:12.1f} Mcyc  {100*v/tot:5.1f}%")
 
 
 def bench_inflate(a, fmt="gzip", level=6):
@@ -120,7 +123,7 @@ def bench_inflate(a, fmt="gzip", level=6):
     U = a.chunks * a.size
     C = sum(sizes)
     read_profile("libdeflate_amd_profile_read_inflate",
-                 ["hdr", "tables", "tokens", "-", "dec seg(lane0)", "flush seg(lane0)", "rounds(lane0)", "iterations(wave)", "reg-matches", "pipelined", "slow-matches", "slow-bytes", "#par STOP", "#par rounds", "#par EOB rounds", "#sync passes", "#copy groups", "#copy iterations", "par: sync", "par: emit", "par: copy"])
+                 ["hdr", "tables", "tokens", "-", "dec seg(lane0)", "flush seg(lane0)", "rounds(lane0)", "iterations(wave)", "reg-matches", "pipelined", "slow-matches", "slow-bytes", "#par STOP", "#par rounds", "#par EOB rounds", "-", "par: sync", "#sync iterations", "copy: tokens+marks", "copy: roots", "copy: doubling", "copy: fill", "#copy groups", "#sync passes"])
     print(f"inflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic {(U+C)/t/1e9:.2f} GB/s, "
           f"{t*1e3:.2f} ms, ratio {C/U:.3f}, ok {ok}/{a.chunks}")
 
