@@ -92,6 +92,22 @@ struct shared_lds {
 	u32 dist_tab[32];
 };
 
+/* LDS-resident: pointers into the workgroup's LDS carry the address space,
+ * and the launch's dynamic LDS is the only LDS of these kernels, so it starts
+ * at LDS address 0 and member offsets become instruction immediates */
+#ifdef __HIP_DEVICE_COMPILE__
+#define AS3 __attribute__((address_space(3)))
+#else
+#define AS3	/* the host pass only parses the device code */
+#endif
+typedef AS3 struct stream_lds slds_t;
+typedef AS3 struct shared_lds shlds_t;
+typedef AS3 struct canon16 lcanon_t;
+typedef AS3 u8 lu8;
+typedef AS3 u16 lu16;
+typedef AS3 u32 lu32;
+typedef AS3 u64 lu64;
+
 enum { ST_HDR = 0, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
 
 /* length / offset symbol -> base and extra-bit count, computed instead of
@@ -153,7 +169,7 @@ static __device__ __forceinline__ u64 load_in(const u8 *inp, u64 in_n, u64 pos)
 
 /* canonical bit-serial decode for codewords longer than the table */
 static __device__ u32
-decode_long(const struct canon16 *cn, const u16 *sorted, u64 bits, u32 *len_ret)
+decode_long(const lcanon_t *cn, const lu16 *sorted, u64 bits, u32 *len_ret)
 {
 	u32 code = 0;
 	for (u32 l = 1; l <= 15; l++) {
@@ -173,7 +189,7 @@ decode_long(const struct canon16 *cn, const u16 *sorted, u64 bits, u32 *len_ret)
  * Validity rules of lib/deflate_decompress.c:804-853.  Returns false if the
  * code is invalid.
  */
-static __device__ bool build_precode(u16 *tab, const u8 *plens)
+static __device__ bool build_precode(lu16 *tab, const u8 *plens)
 {
 	u32 cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (u32 s = 0; s < 19; s++)
@@ -222,8 +238,8 @@ static __device__ bool build_precode(u16 *tab, const u8 *plens)
  * (uniformly) when the code is invalid.
  */
 static __device__ bool
-build_table_coop(const u8 *lens, u32 n, u32 tb, bool is_litlen,
-		 struct canon16 *cn, u16 *sorted, u32 lane, u32 *single_ret)
+build_table_coop(const lu8 *lens, u32 n, u32 tb, bool is_litlen,
+		 lcanon_t *cn, lu16 *sorted, u32 lane, u32 *single_ret)
 {
 	u32 c[16];
 #pragma unroll
@@ -303,8 +319,8 @@ static __device__ __forceinline__ u16 lit_entry(u32 sym, u32 len)
 
 /* fill a table: each lane canonically decodes its own indices */
 static __device__ void
-fill_table(u16 *tab, u32 tb, bool is_litlen, const struct canon16 *cn,
-	   const u16 *sorted, u32 single, u32 lane)
+fill_table(lu16 *tab, u32 tb, bool is_litlen, const lcanon_t *cn,
+	   const lu16 *sorted, u32 single, u32 lane)
 {
 	for (u32 e = lane; e < (1u << tb); e += 64) {
 		u16 entry = 0;
@@ -412,7 +428,7 @@ copy_match(u8 *outp, u64 out_pos, u64 out_avail, u32 dist, u32 length)
  * block is fetched from HBM once per 64 bytes consumed.
  */
 static __device__ __forceinline__ void
-ring_fill(u8 *ring, const u8 *inp, u64 in_n, u64 at)
+ring_fill(lu8 *ring, const u8 *inp, u64 in_n, u64 at)
 {
 	u32 slot = (u32)at & 64;
 
@@ -543,9 +559,9 @@ struct par_bits {
 #define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
 static_assert(PAR_SPAN <= 256u * 4 + 2 * 1088u, "the staged input span shares the copy phase's LDS");
 
-static __device__ __forceinline__ u64 pb_load(const u8 *inp, u64 nb)
+static __device__ __forceinline__ u64 pb_load(const lu8 *inp, u64 nb)
 {
-	const u32 *w = (const u32 *)inp;
+	const lu32 *w = (const lu32 *)inp;
 	u32 i = (u32)nb >> 2, sh = (u32)nb & 3;
 	if (i + 2 >= PAR_SPAN / 4)	/* stopped lanes only; keeps reads inside */
 		i = PAR_SPAN / 4 - 3;
@@ -558,7 +574,7 @@ static __device__ __forceinline__ u64 pb_load(const u8 *inp, u64 nb)
  * loaded right after the previous refill moved nb: the LDS round trip runs
  * beside the decode of the token in between instead of in front of the next
  * one (the refill rule itself is decompress_template.h's REFILL_BITS). */
-static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *inp)
+static __device__ __forceinline__ void pb_refill(struct par_bits *b, const lu8 *inp)
 {
 	b->buf |= b->nxt << b->cnt;
 	b->nb += (63 - b->cnt) >> 3;
@@ -566,7 +582,7 @@ static __device__ __forceinline__ void pb_refill(struct par_bits *b, const u8 *i
 	b->nxt = pb_load(inp, b->nb);
 }
 
-static __device__ __forceinline__ void pb_init(struct par_bits *b, const u8 *inp, u64 pos)
+static __device__ __forceinline__ void pb_init(struct par_bits *b, const lu8 *inp, u64 pos)
 {
 	b->nb = pos >> 3;
 	b->buf = 0;
@@ -602,7 +618,7 @@ struct par_long {
 };
 
 static __device__ __forceinline__ void
-par_long_init(struct par_long *pl, const struct canon16 *cn, u32 from)
+par_long_init(struct par_long *pl, const lcanon_t *cn, u32 from)
 {
 	u32 adj[16];
 #pragma unroll
@@ -623,7 +639,7 @@ par_long_init(struct par_long *pl, const struct canon16 *cn, u32 from)
 }
 
 template <u32 FROM, u32 MASK> static __device__ __forceinline__ u32
-par_long_decode(const struct par_long *pl, const u16 *sorted, u64 bits, u32 *len_ret)
+par_long_decode(const struct par_long *pl, const lu16 *sorted, u64 bits, u32 *len_ret)
 {
 	const u32 rev = __brev((u32)bits) >> 16;	/* first code bit on top */
 	u32 acc = pl->acc0;
@@ -638,7 +654,7 @@ par_long_decode(const struct par_long *pl, const u16 *sorted, u64 bits, u32 *len
 }
 
 static __device__ __forceinline__ struct par_token
-par_decode(const struct stream_lds *S, const struct shared_lds *SH,
+par_decode(const slds_t *S, const shlds_t *SH,
 	   const struct par_long *pll, const struct par_long *plo, u64 buf)
 {
 	struct par_token t;
@@ -706,7 +722,6 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 }
 
 typedef __attribute__((address_space(1))) u8 gu8;	/* output bytes in HBM */
-typedef __attribute__((address_space(3))) u8 lu8;	/* LDS */
 
 /*
  * Output positions [flushed, end) are in the LDS mirror and not yet in
@@ -715,7 +730,7 @@ typedef __attribute__((address_space(3))) u8 lu8;	/* LDS */
  * rest, less than a word, waits for the next group or the end of the round.
  */
 static __device__ __forceinline__ u64
-flush_ring(gu8 *gout, const u8 *win, u64 flushed, u64 end, u32 lane)
+flush_ring(gu8 *gout, const lu8 *win, u64 flushed, u64 end, u32 lane)
 {
 	u64 a = (flushed + 3) & ~(u64)3;
 	if (a > end)
@@ -729,7 +744,7 @@ flush_ring(gu8 *gout, const u8 *win, u64 flushed, u64 end, u32 lane)
 	gu8 *dst = gout + a;
 	const u32 a32 = (u32)a;
 	for (u32 w = lane; w < nw; w += 64) {
-		const u32 v = *(const u32 *)(win + ((a32 + 4 * w) & (PAR_RW - 1)));
+		const u32 v = *(const lu32 *)(win + ((a32 + 4 * w) & (PAR_RW - 1)));
 		__builtin_memcpy(dst + 4 * w, &v, 4);
 	}
 	return e;
@@ -743,17 +758,17 @@ flush_ring(gu8 *gout, const u8 *win, u64 flushed, u64 end, u32 lane)
  * the owner of token g).  Words past `total` read as 0.
  */
 static __device__ __forceinline__ uint4
-tok_fetch(const u32 *__restrict__ rows, u8 *mk, const u16 *tb, u32 tbase,
+tok_fetch(const u32 *__restrict__ rows, lu8 *mk, const lu16 *tb, u32 tbase,
 	  u32 cnt, u32 g, u32 total, u32 lane)
 {
-	((u32 *)mk)[lane] = 0;
+	((lu32 *)mk)[lane] = 0;
 	const u64 holds = __ballot(cnt != 0 && tbase <= g && g - tbase < cnt);
 	const u32 first = holds ? (u32)__builtin_ctzll(holds) + 1 : 1;
 	wave_sync();
 	if (cnt != 0 && tbase - g - 1 < 255u)	/* g < tbase < g + 256 */
 		mk[tbase - g] = (u8)(lane + 1);
 	wave_sync();
-	const u32 m4 = ((const u32 *)mk)[lane];
+	const u32 m4 = ((const lu32 *)mk)[lane];
 	u32 o[4];
 	o[0] = m4 & 0xFF;
 	o[1] = (m4 >> 8) & 0xFF;
@@ -801,8 +816,8 @@ tok_fetch(const u32 *__restrict__ rows, u8 *mk, const u16 *tb, u32 tbase,
  */
 static __device__ u32
 par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
-	  const struct stream_lds *S, const struct shared_lds *SH,
-	  u32 *__restrict__ tok, u8 *win, u8 *stage, u64 ring_lo, u32 lane,
+	  const slds_t *S, const shlds_t *SH,
+	  u32 *__restrict__ tok, lu8 *win, lu8 *stage, u64 ring_lo, u32 lane,
 	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret)
 {
 	/* lanes in this round: one PAR_CB-bit chunk each, up to the end of the
@@ -825,12 +840,12 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		const u32 nw = (NL * (cb / 8) + 80) / 8;
 		for (u32 w = lane; w < nw; w += 64) {
 			const u64 pos = byte0 + 8 * w;
-			*(u64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
+			*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
 						  load_in(inp, in_n, pos);
 		}
 		wave_sync();
 	}
-	inp = stage;
+	const lu8 *span = stage;	/* the parse reads the staged copy */
 	const u64 bpos0 = bpos_abs & 7;	/* positions relative to the span */
 	struct par_long pll, plo;
 	par_long_init(&pll, &S->lit, LIT_TB + 1);
@@ -847,7 +862,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
 		bool run = dirty;
-		pb_init(&b, inp, start);
+		pb_init(&b, span, start);
 		if (dirty) {
 			nbytes = 0;
 			ntok = 0;
@@ -856,7 +871,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		while (__ballot(run)) {
 			PROF_SEC_ADD(1, 1);
 			run = run && PB_POS(b) < cend;
-			pb_refill(&b, inp);
+			pb_refill(&b, span);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
 			if (run) {
 				b.buf >>= t.used;
@@ -925,8 +940,8 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * wrote then are its tokens: no further parse.  Token i of the round
 	 * (stream order) is row i - tbase[l] of the lane l whose range holds i;
 	 * the copy phase finds l per group (tok_fetch). */
-	u8 *mk = stage + PAR_STAGE_BYTES;		/* [256] group token -> lane + 1 */
-	u16 *tb = (u16 *)(mk + 256);			/* [64] tbase per lane */
+	lu8 *mk = stage + PAR_STAGE_BYTES;		/* [256] group token -> lane + 1 */
+	lu16 *tb = (lu16 *)(mk + 256);			/* [64] tbase per lane */
 	const u32 own_cnt = valid ? tcnt : 0;
 	tb[lane] = (u16)tbase;
 	wave_sync();
@@ -944,8 +959,8 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * LDS mirror; the output is written from there in whole words once per
 	 * group (flush_ring). */
 	{
-		u32 *tk = (u32 *)stage;			/* [256] the group's tokens */
-		u16 *R = (u16 *)((u32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */
+		lu32 *tk = (lu32 *)stage;			/* [256] the group's tokens */
+		lu16 *R = (lu16 *)((lu32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */
 		gu8 *gout = (gu8 *)outp;
 		u64 gbase = out0;
 		u64 flushed = out0;	/* output below this is in memory */
@@ -1003,81 +1018,99 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			 * in the first 32 KiB */
 			const u32 back_max = gbase < 32768 ? (u32)gbase : 32768u;
 			bool bad = false;
-			/* The slots (64 bytes each) are independent except for the
-			 * running maximum, so the steps below work on SB slots at a
-			 * time: the LDS / HBM reads of a batch are all issued before
-			 * the first is used (one memory latency per batch, not per
-			 * slot). */
+			/* The slots (64 bytes each) are resolved in order, so the
+			 * source of a byte is final in the mirror when its slot is
+			 * reached, unless it lies in the same slot.  The token lookup
+			 * of SB slots is done together (its LDS reads and the reads
+			 * from the output are independent of the mirror); then every
+			 * slot reads its sources, settles the copies inside itself
+			 * (pointer jumping over the 64 lanes, only when there are
+			 * any) and writes its bytes. */
 			enum { SB = 4 };
 			u32 carry = 0;
-			bool inside_any = false;
 			PROF_SEC(2);
 			PROF_SEC_ADD(6, 1);
 			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-				u32 own[SB], vv[SB], fofs[SB];
-				bool far[SB];
+				u32 own[SB], vfar[SB];
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane;
 					own[k] = bi < gtot ? R[bi] : 0;
 				}
+#define DPP_MAX(k, ctrl, rm, bc)                                               \
+	do {                                                                   \
+		u32 t_ = __builtin_amdgcn_update_dpp(0, own[k], ctrl, rm, 0xF, bc); \
+		own[k] = own[k] > t_ ? own[k] : t_;                            \
+	} while (0)
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x111, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x112, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x114, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x118, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x142, 0xA, false);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x143, 0xC, false);
+#undef DPP_MAX
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
-					u32 o = own[k];
-#define DPP_MAX(ctrl, rm, bc)                                                  \
-	do {                                                                   \
-		u32 t_ = __builtin_amdgcn_update_dpp(0, o, ctrl, rm, 0xF, bc);  \
-		o = o > t_ ? o : t_;                                           \
-	} while (0)
-					DPP_MAX(0x111, 0xF, true);
-					DPP_MAX(0x112, 0xF, true);
-					DPP_MAX(0x114, 0xF, true);
-					DPP_MAX(0x118, 0xF, true);
-					DPP_MAX(0x142, 0xA, false);
-					DPP_MAX(0x143, 0xC, false);
-#undef DPP_MAX
-					o = o > carry ? o : carry;
-					carry = bcast_lane(o, 63);
-					own[k] = o;
+					own[k] = own[k] > carry ? own[k] : carry;
+					carry = bcast_lane(own[k], 63);
 				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane;
 					own[k] = bi < gtot ? tk[own[k] - 1] : 0;	/* token word */
 				}
+				/* bytes whose source is older than the mirror */
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane, tw = own[k];
+					const u32 dist = (tw >> 9) & 0xFFFF;
+					const bool before = (tw >> 31) && dist > bi;
+					const bool toofar = before && dist - bi > back_max;
+					const bool far = before && !toofar && dist - bi > ring_rel;
+					bad |= toofar;
+					vfar[k] = 0x100;	/* not a byte: no far source */
+					if (__ballot(far)) {
+						if (far)
+							vfar[k] = gfar[bi + 32768u - dist];
+					}
+				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane, tw = own[k];
 					const u32 dist = (tw >> 9) & 0xFFFF;
 					const bool match = (tw >> 31) != 0;	/* false past gtot */
-					const bool inside = match && dist <= bi;
-					const bool before = match && dist > bi;
+					const bool intra = match && dist <= lane;
 					/* every lane reads the mirror (the index is always
-					 * inside it); only `before` lanes use the byte */
+					 * inside it); matches from outside the slot use it */
 					const u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
-					const bool toofar = before && dist - bi > back_max;
-					far[k] = before && !toofar && dist - bi > ring_rel;
-					fofs[k] = bi + 32768u - dist;
-					bad |= toofar;
-					vv[k] = before ? wv : tw & 0xFF;
-					own[k] = inside ? bi - dist : bi;
-					inside_any |= inside;
-				}
-#pragma unroll
-				for (u32 k = 0; k < SB; k++) {
-					if (__ballot(far[k])) {
-						if (far[k])
-							vv[k] = gfar[fofs[k]];
+					u32 v = match ? wv : tw & 0xFF;
+					v = vfar[k] < 0x100 ? vfar[k] : v;
+					if (__ballot(intra)) {
+						u32 p = intra ? lane - dist : lane;
+						for (;;) {
+							const u32 pp = (u32)__builtin_amdgcn_ds_bpermute(
+									(int)(p << 2), (int)p);
+							const bool ch = pp != p;
+							p = pp;
+							if (!__ballot(ch))
+								break;
+						}
+						v = (u32)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)v);
 					}
-				}
-#pragma unroll
-				for (u32 k = 0; k < SB; k++) {
-					const u32 bi = s0 + 64 * k + lane;
-					if (bi < gtot) {
-						R[bi] = (u16)own[k];
-						if (own[k] == bi)
-							win[(gb + bi) & (PAR_RW - 1)] = (u8)vv[k];
-					}
+					if (bi < gtot)
+						win[(gb + bi) & (PAR_RW - 1)] = (u8)v;
 				}
 			}
 			wave_sync();
@@ -1089,55 +1122,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				 * will write again, and the mirror is not used across
 				 * an abandoned round. */
 				return PAR_STOP;
-			}
-			if (__ballot(inside_any)) {
-				/* pointer doubling to the roots */
-				for (;;) {
-					bool changed = false;
-					PROF_SEC_ADD(7, 1);
-					for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-						u32 r[SB], rr[SB];
-#pragma unroll
-						for (u32 k = 0; k < SB; k++) {
-							const u32 bi = s0 + 64 * k + lane;
-							r[k] = bi < gtot ? R[bi] : 0;
-						}
-#pragma unroll
-						for (u32 k = 0; k < SB; k++)
-							rr[k] = R[r[k]];
-#pragma unroll
-						for (u32 k = 0; k < SB; k++) {
-							const u32 bi = s0 + 64 * k + lane;
-							if (bi < gtot) {
-								changed |= rr[k] != r[k];
-								R[bi] = (u16)rr[k];
-							}
-						}
-					}
-					wave_sync();
-					if (!__ballot(changed))
-						break;
-				}
-				PROF_SEC(4);
-				/* everyone else copies its root's value */
-				for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
-					u32 r[SB], vv[SB];
-#pragma unroll
-					for (u32 k = 0; k < SB; k++) {
-						const u32 bi = s0 + 64 * k + lane;
-						r[k] = bi < gtot ? R[bi] : bi;
-					}
-#pragma unroll
-					for (u32 k = 0; k < SB; k++)
-						vv[k] = win[(gb + r[k]) & (PAR_RW - 1)];
-#pragma unroll
-					for (u32 k = 0; k < SB; k++) {
-						const u32 bi = s0 + 64 * k + lane;
-						if (bi < gtot && r[k] != bi)
-							win[(gb + bi) & (PAR_RW - 1)] = (u8)vv[k];
-					}
-				}
-				wave_sync();
 			}
 			gbase += gtot;
 			flushed = flush_ring(gout, win, flushed, gbase, lane);
@@ -1164,7 +1148,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
  * sequential decoder below, so result codes do not depend on the mode.
  */
 static __device__ __forceinline__ void
-inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
+inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 	      u64 n_chunks, int format, u32 lpw,
 	      const u8 *__restrict__ in_base,
 	      const u64 *__restrict__ in_offsets,
@@ -1176,12 +1160,12 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 	      u64 *__restrict__ actual_in,	/* incl. container header */
 	      u64 *__restrict__ actual_out)
 {
-	struct stream_lds *SL = (struct stream_lds *)lds_raw;
+	slds_t *SL = (slds_t *)lds_raw;
 	const u32 lane = threadIdx.x;
 	const u64 c = blk * lpw + lane;
 	const bool owner = lane < lpw && c < n_chunks;
-	struct stream_lds *S = &SL[lane < lpw ? lane : 0];
-	struct shared_lds *SH = (struct shared_lds *)&SL[lpw];
+	slds_t *S = &SL[lane < lpw ? lane : 0];
+	shlds_t *SH = (shlds_t *)&SL[lpw];
 	if (lane < 32) {
 		u32 b, x;
 		len_sym(lane, &b, &x);
@@ -1421,7 +1405,7 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 			while (need) {
 				u32 who = (u32)__builtin_ctzll(need);
 				need &= need - 1;
-				struct stream_lds *T = &SL[who];
+				slds_t *T = &SL[who];
 				u32 t_nlit = bcast_lane(nlit, who);
 				u32 t_noff = bcast_lane(noff, who);
 				u32 s_lit, s_off;
@@ -1523,7 +1507,7 @@ inflate_block(u64 blk, u8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					ring_lo = o0;
 				u32 pr = par_round(inp0, bcast64(in_n), outp0,
 						   bcast64(out_avail), &SL[0], SH, tok,
-						   (u8 *)(SH + 1), (u8 *)(SH + 1) + PAR_RW,
+						   (lu8 *)(SH + 1), (lu8 *)(SH + 1) + PAR_RW,
 						   ring_lo, lane, bpos0, o0,
 						   &nb, &no);
 				PROF_COUNT(12 + pr, 1);
@@ -1851,7 +1835,7 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			 u64 *__restrict__ actual_in,
 			 u64 *__restrict__ actual_out)
 {
-	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	lu8 *lds_raw = (lu8 *)(uintptr_t)0;
 
 	inflate_block(blockIdx.x, lds_raw, 0, NULL, n_chunks, format, lpw, in_base,
 		      in_offsets, in_nbytes, out_base, out_offsets, out_avail_arr,
@@ -1879,7 +1863,7 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 			u64 *__restrict__ actual_in,
 			u64 *__restrict__ actual_out)
 {
-	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+	lu8 *lds_raw = (lu8 *)(uintptr_t)0;
 	u32 *tok = tokscratch + (size_t)blockIdx.x * PAR_SCRATCH;
 
 	/* Which streams share a CU follows from the dispatch order (workgroup i
