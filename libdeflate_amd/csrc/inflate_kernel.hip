@@ -15,10 +15,10 @@
  * WAVE PER STREAM (lda_inflate_wave_kernel, the default).  Inside a Huffman
  * block the 64 lanes parse 64 consecutive 384-bit pieces of the input at
  * once: a parse started at an arbitrary bit falls in step with the true one
- * within a few dozen bits, so a couple of passes in which every lane restarts
- * where its left neighbour ended give the exact token boundaries; the tokens
- * are then executed byte-parallel ("sub-block parallel token decoding"
- * below).  Headers, stored blocks, the last bytes of a stream and every error
+ * within a few dozen bits, so a few passes in which every lane restarts
+ * where its left neighbour ended give the exact token boundaries and, as a
+ * by-product, the tokens; these are then executed byte-parallel ("sub-block
+ * parallel token decoding" below).  Headers, stored blocks, the last bytes of a stream and every error
  * path run on lane 0 through the sequential code, so result codes are the
  * same in both mappings.
  *
@@ -517,29 +517,46 @@ ring_fill(lu8 *ring, const u8 *inp, u64 in_n, u64 at)
  * bits of the block:
  *
  *   sync   every lane parses from its (guessed) start to the end of its
- *          chunk and reports where its last token ended, how many tokens and
+ *          piece and reports where its last token ended, how many tokens and
  *          output bytes it saw; lane i + 1 then restarts from lane i's end.
  *          Lane 0 starts at a known token boundary, so after k passes lanes
- *          0..k-1 are exact; in practice two or three passes settle all 64;
- *   emit   with exact starts and prefix sums of the counts, every lane
- *          parses once more and writes its tokens (literal byte, or length
- *          and distance) to the wave's token scratch in HBM;
- *   copy   the tokens are executed in groups of up to 64 tokens / 1 KiB of
- *          output, resolved per output byte by pointer doubling (see the
- *          copy phase in par_round); sources come from a 4 KiB LDS mirror
- *          of the recent output.  A wave's vector memory operations reach
- *          its L1 in issue order, so loads see earlier stores of other
- *          lanes without waiting for write acknowledgements; only the
- *          compiler has to be kept from reordering them (wave_sync).
+ *          0..k-1 are exact; measured: three or four passes settle all 64
+ *          (the last ones for two to five lanes).  Every parse writes its
+ *          tokens (literal byte, or length and distance) as it goes, into
+ *          lane-interleaved rows of the wave's scratch in HBM - row k holds
+ *          the k-th token of every lane, one coalesced 256-byte store per
+ *          step - so the tokens of a lane's last parse, the one from its
+ *          exact start, are simply there when the passes end: there is no
+ *          separate emit parse;
+ *   copy   the tokens are executed in groups of up to 256 tokens / 1 KiB of
+ *          output (tok_fetch maps the group's tokens, in stream order, back
+ *          to rows), byte-parallel and 64 bytes at a time in output order
+ *          (see the copy phase in par_round): the bytes meet in a 4 KiB LDS
+ *          mirror of the recent output, which also serves nearly every
+ *          match source, and go to HBM in whole words once per group.  A
+ *          wave's vector memory operations reach its L1 in issue order, so
+ *          loads see earlier stores of other lanes without waiting for write
+ *          acknowledgements; only the compiler has to be kept from
+ *          reordering them (wave_sync).
  *
- * Nothing is written to the output before the round is known to be free of
- * anything the sequential decoder has a rule for: it needs the whole input
- * span plus 64 bytes inside the buffer, the produced bytes inside the output
- * buffer, and every distance inside the bytes already produced - otherwise
- * the round is abandoned and the sequential decoder takes the same bits.
+ * The kernel is bound by VALU issue (a wave64 instruction occupies its SIMD
+ * for four cycles; with four waves per SIMD the measured VALU busy share is
+ * about 85 % while the waves are resident), not by memory or LDS latency:
+ * what pays is fewer instructions per token and per output byte, and that is
+ * what the choices above are for (no second parse, no pointer-doubling passes
+ * over the group, word-wide output stores, address-space-qualified LDS
+ * pointers so that offsets fold into the instructions).
+ *
+ * A round is abandoned, and the sequential decoder takes the same bits, when
+ * it meets anything that decoder has a rule for: it needs the whole input
+ * span plus 64 bytes inside the buffer and the produced bytes inside the
+ * output buffer, and every distance inside the bytes already produced.
  */
 #ifndef PAR_CB
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
+#endif
+#ifndef PAR_PAIR
+#define PAR_PAIR 1
 #endif
 #define PAR_LANECAP (PAR_CB / 2)	/* tokens one lane may find in its piece (2 bits each) */
 #define PAR_SCRATCH (64u * PAR_LANECAP)	/* u32 words per wave */
@@ -548,8 +565,8 @@ enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
 
 struct par_bits {
 	u64 buf;
-	u64 nb;		/* next input byte to load */
 	u64 nxt;	/* the 8 bytes at nb, loaded one token ahead */
+	u32 nb;		/* next input byte to load (offset in the staged span) */
 	u32 cnt;
 };
 
@@ -559,10 +576,10 @@ struct par_bits {
 #define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
 static_assert(PAR_SPAN <= 256u * 4 + 2 * 1088u, "the staged input span shares the copy phase's LDS");
 
-static __device__ __forceinline__ u64 pb_load(const lu8 *inp, u64 nb)
+static __device__ __forceinline__ u64 pb_load(const lu8 *inp, u32 nb)
 {
 	const lu32 *w = (const lu32 *)inp;
-	u32 i = (u32)nb >> 2, sh = (u32)nb & 3;
+	u32 i = nb >> 2, sh = nb & 3;
 	if (i + 2 >= PAR_SPAN / 4)	/* stopped lanes only; keeps reads inside */
 		i = PAR_SPAN / 4 - 3;
 	u32 a = w[i], c = w[i + 1], d = w[i + 2];
@@ -582,15 +599,15 @@ static __device__ __forceinline__ void pb_refill(struct par_bits *b, const lu8 *
 	b->nxt = pb_load(inp, b->nb);
 }
 
-static __device__ __forceinline__ void pb_init(struct par_bits *b, const lu8 *inp, u64 pos)
+static __device__ __forceinline__ void pb_init(struct par_bits *b, const lu8 *inp, u32 pos)
 {
 	b->nb = pos >> 3;
 	b->buf = 0;
 	b->cnt = 0;
 	b->nxt = pb_load(inp, b->nb);
 	pb_refill(b, inp);
-	b->buf >>= (u32)pos & 7;
-	b->cnt -= (u32)pos & 7;
+	b->buf >>= pos & 7;
+	b->cnt -= pos & 7;
 }
 
 #define PB_POS(b) (8 * (b).nb - (b).cnt)
@@ -846,12 +863,12 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		wave_sync();
 	}
 	const lu8 *span = stage;	/* the parse reads the staged copy */
-	const u64 bpos0 = bpos_abs & 7;	/* positions relative to the span */
+	const u32 bpos0 = (u32)bpos_abs & 7;	/* positions relative to the span */
 	struct par_long pll, plo;
 	par_long_init(&pll, &S->lit, LIT_TB + 1);
 	par_long_init(&plo, &S->off, OFF_TB + 1);
-	const u64 cend = bpos0 + (u64)(lane + 1) * cb;
-	u64 start = bpos0 + (u64)lane * cb, end = 0;
+	const u32 cend = bpos0 + (lane + 1) * cb;
+	u32 start = bpos0 + lane * cb, end = 0;
 	u32 nbytes = 0, ntok = 0;
 	bool eob = false, dirty = lane < NL;
 	u32 K = NL - 1;		/* last lane of the round */
@@ -873,9 +890,20 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, span);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
+#if PAR_PAIR
+			/* A literal takes a second one with it when that one starts
+			 * inside the piece and its codeword is in the table: a pass
+			 * lasts as long as its lane with the most tokens, and those
+			 * are the lanes full of literals. */
+			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
+					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+#else
+			const u32 e1 = 0;
+			const bool two = false;
+#endif
 			if (run) {
-				b.buf >>= t.used;
-				b.cnt -= t.used;
+				u32 used = t.used;
 				if (t.kind == K_EOB) {
 					eob = true;
 					run = false;
@@ -887,12 +915,22 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
+					if (two) {
+						if (ntok < PAR_LANECAP)
+							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
+						nbytes++;
+						ntok++;
+						used += e1 & 15;
+					}
 				}
+				b.buf >>= used;
+				b.cnt -= used;
 			}
 		}
 		if (dirty)
 			end = PB_POS(b);
-		u64 ns = shfl_up64(end);
+		/* DPP wave_shr:1 (lane 0 keeps its own value) */
+		u32 ns = __builtin_amdgcn_update_dpp(end, end, 0x138, 0xF, 0xF, false);
 		if (lane == 0)
 			ns = bpos0;
 		dirty = ns != start && lane < NL;
@@ -932,7 +970,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	const u64 total_bytes = bcast_lane(obase + bcnt, K);
 	if (total_bytes > out_avail - out0)
 		return PAR_STOP;
-	const u64 end_bits = readlane64(end, K) - bpos0 + bpos_abs;
+	const u64 end_bits = bcast_lane(end, K) - bpos0 + bpos_abs;
 	if (end_bits > 8 * in_n)
 		return PAR_STOP;
 
@@ -946,18 +984,15 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	tb[lane] = (u16)tbase;
 	wave_sync();
 	/* ---- execute the tokens: up to 256 tokens / PAR_GBYTES bytes a group ----
-	 * The copies of a group are resolved per output BYTE, not per token:
-	 * byte b of the group is a literal, or a copy of the byte dist before
-	 * it; that byte may again be a copy inside the group (every word of a
-	 * table of counters copies three bytes from the word before it).  Each
-	 * byte starts with a pointer to its source inside the group (itself for
-	 * literals and for copies from before the group, the "roots"), pointer
-	 * doubling takes every byte to its root in log2(chain) steps whatever
-	 * the shape of the dependencies, the roots fetch their values (the LDS
-	 * mirror of the recent output, or the output itself when it is further
-	 * back) and the rest read theirs from their root.  The bytes meet in the
-	 * LDS mirror; the output is written from there in whole words once per
-	 * group (flush_ring). */
+	 * The copies of a group are resolved per output BYTE, not per token, 64
+	 * bytes (a slot) at a time and in output order: byte b is a literal, or
+	 * a copy of the byte dist before it.  That byte is final - in the LDS
+	 * mirror of the recent output, or in the output itself when it is further
+	 * back than the mirror reaches - unless it lies in the same slot; copies
+	 * inside a slot (runs, short periods) are settled by pointer jumping over
+	 * the 64 lanes, whatever the shape of the dependencies.  The bytes meet
+	 * in the mirror; the output is written from there in whole words once
+	 * per group (flush_ring). */
 	{
 		lu32 *tk = (lu32 *)stage;			/* [256] the group's tokens */
 		lu16 *R = (lu16 *)((lu32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */

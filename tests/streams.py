@@ -363,3 +363,62 @@ def gzip_optional_field_streams():
         s = bytes(h) + body + struct.pack("<II", zlib.crc32(data), len(data))
         out.append((s, data))
     return out
+
+
+def parallel_round_streams():
+    """Long raw DEFLATE streams aimed at the wave-per-stream rounds:
+    -> list of (name, stream, expected).
+      huff2 / huff3   Huffman-only coding of 2- and 3-symbol data: 1- and
+                      2-bit literals, more tokens per 384-bit piece than a
+                      lane may record (the round is clipped or abandoned);
+      periods         stretches of period p between stretches of noise, p
+                      from 1 to 200: long matches whose distance is below,
+                      at and above the 64-byte slot size (copies inside a
+                      slot, across slots, runs);
+      far             matches that reach 5..30 KiB back, past the LDS mirror."""
+    import random
+    import zlib
+    out = []
+    rng = random.Random(0x0E110031)
+    for nsym in (2, 3):
+        data = bytes(rng.choice(b"ab" if nsym == 2 else b"abc") for _ in range(60000))
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        out.append((f"huff{nsym}", co.compress(data) + co.flush(), data))
+    parts = []
+    for p in (1, 2, 3, 5, 7, 31, 63, 64, 65, 127, 200) * 3:
+        unit = bytes(rng.randrange(256) for _ in range(p))
+        parts.append((unit * (2500 // p + 1))[:rng.randrange(900, 2500)])
+        parts.append(bytes(rng.randrange(256) for _ in range(rng.randrange(300, 700))))
+    data = b"".join(parts)
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    out.append(("periods", co.compress(data) + co.flush(), data))
+    base = bytes(rng.randrange(256) for _ in range(30000))
+    pieces = [base]
+    for i in range(400):
+        at = rng.randrange(0, 30000 - 300)
+        pieces.append(base[at:at + rng.randrange(8, 200)])
+        pieces.append(bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40))))
+    data = b"".join(pieces)
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    out.append(("far", co.compress(data) + co.flush(), data))
+    return out
+
+
+def bad_distance_streams():
+    """A dynamic-Huffman stream long enough for a parallel round whose first
+    kilobytes hold a match reaching back before the start of the output:
+    -> list of streams (all invalid).  Built by compressing with a preset
+    dictionary and dropping the dictionary (the distances into it dangle)."""
+    import random
+    import zlib
+    rng = random.Random(0x0E110032)
+    out = []
+    for at in (0, 700, 5000):
+        words = [bytes(rng.randrange(97, 123) for _ in range(rng.randrange(3, 9)))
+                 for _ in range(300)]
+        text = b" ".join(rng.choice(words) for _ in range(12000))
+        zdict = text[20000:52768] if at == 0 else bytes(rng.randrange(256) for _ in range(32768))
+        body = text[:at] + zdict[1000:1400] + text[at:]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=zdict)
+        out.append(co.compress(body) + co.flush())
+    return out

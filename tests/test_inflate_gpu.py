@@ -280,6 +280,27 @@ def test_stored_block_then_short_match(dec, oracle, monkeypatch):
             assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
 
 
+def test_parallel_round_corner_streams(dec, oracle, monkeypatch):
+    """Streams aimed at the wave-per-stream rounds (more tokens in a piece
+    than a lane records, copies inside a 64-byte slot, sources older than the
+    LDS mirror, a distance reaching back before the stream that only the copy
+    phase sees), in both mappings and with short output buffers."""
+    cases = []
+    for name, s, want in streams.parallel_round_streams():
+        cases.append(("deflate", s, len(want), True, name))
+        cases.append(("deflate", s, len(want), False, name + "/exact"))
+        cases.append(("deflate", s, len(want) + 100, True, name + "/room"))
+        cases.append(("deflate", s, len(want) - 1, True, name + "/short"))
+        cases.append(("deflate", s[:len(s) * 2 // 3], len(want), True, name + "/cut"))
+    for i, s in enumerate(streams.bad_distance_streams()):
+        cases.append(("deflate", s, 200000, True, f"baddist{i}"))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        _run_cases(dec, oracle, cases)
+        for name, s, want in streams.parallel_round_streams():
+            assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, name)
+
+
 def test_gzip_optional_header_fields(dec, oracle):
     """Valid members with FEXTRA / FNAME / FCOMMENT / FHCRC are decoded, not
     just rejected consistently (lib/gzip_decompress.c:69-100)."""

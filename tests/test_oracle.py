@@ -177,3 +177,23 @@ def test_stored_then_match_and_gzip_fields(oracle, ref):
         bad = s[:3] + bytes([s[3] | 0x20]) + s[4:]
         assert oracle.decompress_ex("gzip", bad, len(want))[0] == \
             ref.decompress_ex("gzip", bad, len(want))[0] == 1
+
+
+def test_parallel_round_corner_streams(oracle, ref):
+    """The long streams aimed at the GPU's parallel rounds: the oracle agrees
+    with the reference (and zlib) on them, valid and invalid alike."""
+    import zlib
+    for name, s, want in streams.parallel_round_streams():
+        assert zlib.decompress(s, -15) == want, name
+        for chk in (oracle, ref):
+            assert chk.decompress_ex("deflate", s, len(want)) == (0, len(s), len(want), want), name
+        cut = s[:len(s) * 2 // 3]
+        assert oracle.decompress_ex("deflate", cut, len(want))[0] == \
+            ref.decompress_ex("deflate", cut, len(want))[0] != 0
+    n_bad = 0
+    for s in streams.bad_distance_streams():
+        o = oracle.decompress_ex("deflate", s, 200000)
+        r = ref.decompress_ex("deflate", s, 200000)
+        assert o[:3] == r[:3]
+        n_bad += o[0] == 1
+    assert n_bad >= 2
