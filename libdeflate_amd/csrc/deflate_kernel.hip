@@ -84,12 +84,11 @@
 #define HASH3_BITS 12
 #endif
 /*
- * The matches of the current block live in HBM (8 bytes each, one list per
- * workgroup): nothing of a block has to stay in LDS until the block is
- * written, so a block can be as long as a whole 64 KiB buffer, like the
- * reference's for homogeneous data.  Blocks end where the content changes
- * (the observation classes of lib/deflate_compress.c:2092-2218, evaluated per
- * tile, see "block end?") or once they reach MAX_BLOCK_LEN.
+ * Blocks end where the content changes (the observation classes of
+ * lib/deflate_compress.c:2092-2218, evaluated per tile, see "block end?") or
+ * once they reach MAX_BLOCK_LEN: the tokens of the current block live in HBM
+ * (see TOK_MATCH below), so a block can be as long as a whole 64 KiB buffer,
+ * like the reference's for homogeneous data.
  */
 #define MAX_BLOCK_LEN 65536u
 /*

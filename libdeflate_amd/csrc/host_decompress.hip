@@ -191,8 +191,9 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		size_t grid = (size_t)c->num_cus * per_cu;
 		if (grid > n)
 			grid = n;
-		/* token scratch of every wave, then the counter the waves take
-		 * their second and later streams from */
+		/* token rows of every wave (lda_inflate_tokcap() words: one row
+		 * of 64 tokens per parse step of a round), then the counter the
+		 * waves take their second and later streams from */
 		const size_t tok_bytes = grid * lda_inflate_tokcap() * 4;
 		uint32_t *tok = (uint32_t *)d->tokens.reserve(tok_bytes + 16);
 		if (!tok)

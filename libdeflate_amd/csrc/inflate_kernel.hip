@@ -879,6 +879,10 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
 		bool run = dirty;
+		/* the first pass is a guess for every lane but lane 0: its tokens
+		 * are not written (every other lane parses again in the second
+		 * pass, see below) */
+		const bool keep = pass != 0 || lane == 0;
 		pb_init(&b, span, start);
 		if (dirty) {
 			nbytes = 0;
@@ -910,13 +914,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				} else {
 					/* row ntok of the lane-interleaved list: the 64
 					 * lanes of an iteration write one 256-byte row */
-					if (ntok < PAR_LANECAP)
+					if (keep && ntok < PAR_LANECAP)
 						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
 					if (two) {
-						if (ntok < PAR_LANECAP)
+						if (keep && ntok < PAR_LANECAP)
 							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
 						nbytes++;
 						ntok++;
@@ -933,7 +937,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		u32 ns = __builtin_amdgcn_update_dpp(end, end, 0x138, 0xF, 0xF, false);
 		if (lane == 0)
 			ns = bpos0;
-		dirty = ns != start && lane < NL;
+		dirty = (ns != start || (pass == 0 && lane != 0)) && lane < NL;
 		start = ns;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;

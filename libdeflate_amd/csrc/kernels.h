@@ -79,7 +79,7 @@ extern "C" size_t lda_deflate_small_lds_bytes(void);
 extern "C" size_t lda_deflate_small_max(void);
 extern "C" size_t lda_deflate_tile(void);	/* positions per tile (dictionary granularity) */
 extern "C" size_t lda_deflate_lds_bytes(void);
-extern "C" size_t lda_deflate_seq_words(void);	/* u64 match-list entries per workgroup */
+extern "C" size_t lda_deflate_seq_words(void);	/* u64 words of HBM scratch per workgroup (token list, saved histograms) */
 
 extern "C" size_t lda_inflate_lds_per_stream(void);
 extern "C" size_t lda_inflate_lds_shared(void);
