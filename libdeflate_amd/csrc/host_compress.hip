@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -164,9 +165,11 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		if (rc != LIBDEFLATE_AMD_OK)
 			return rc;
 	}
-	static bool attr_set[16];
-	size_t lds = small ? lda_deflate_small_lds_bytes() : lda_deflate_lds_bytes();
-	if (!attr_set[ctx->device]) {
+	/* once per device (setting it again is harmless, so a race between two
+	 * first calls only repeats it) */
+	static std::atomic<bool> attr_set[16];
+	const size_t lds = small ? lda_deflate_small_lds_bytes() : lda_deflate_lds_bytes();
+	if (!attr_set[ctx->device].load(std::memory_order_acquire)) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_deflate_small_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -174,12 +177,12 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_deflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)lds), LIBDEFLATE_AMD_NO_DEVICE);
+				(int)lda_deflate_lds_bytes()), LIBDEFLATE_AMD_NO_DEVICE);
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_deflate_opt_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)lds), LIBDEFLATE_AMD_NO_DEVICE);
-		attr_set[ctx->device] = true;
+				(int)lda_deflate_lds_bytes()), LIBDEFLATE_AMD_NO_DEVICE);
+		attr_set[ctx->device].store(true, std::memory_order_release);
 	}
 	const level_cfg &lv = k_levels[c->level];
 	hipLaunchKernelGGL(small ? lda_deflate_small_kernel :

@@ -231,12 +231,21 @@ DeviceCtx *device_ctx()
 	}
 	static uint32_t tab[LDA_CRC_TABLE_WORDS], xpow[LDA_CRC_XPOW_WORDS];
 	gen_crc_tables(tab, xpow);
-	LDA_HIP_TRY(hipMalloc((void **)&c->d_crc_tables, sizeof(tab)), nullptr);
-	LDA_HIP_TRY(hipMalloc((void **)&c->d_crc_xpow8, sizeof(xpow)), nullptr);
-	LDA_HIP_TRY(hipMemcpy(c->d_crc_tables, tab, sizeof(tab),
-			      hipMemcpyHostToDevice), nullptr);
-	LDA_HIP_TRY(hipMemcpy(c->d_crc_xpow8, xpow, sizeof(xpow),
-			      hipMemcpyHostToDevice), nullptr);
+	/* one allocation for both tables: a failure half way leaves nothing
+	 * behind, and the next call tries again from the start */
+	uint32_t *d_tab = nullptr;
+	LDA_HIP_TRY(hipMalloc((void **)&d_tab, sizeof(tab) + sizeof(xpow)), nullptr);
+	hipError_t ce = hipMemcpy(d_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+	if (ce == hipSuccess)
+		ce = hipMemcpy(d_tab + LDA_CRC_TABLE_WORDS, xpow, sizeof(xpow),
+			       hipMemcpyHostToDevice);
+	if (ce != hipSuccess) {
+		(void)hipFree(d_tab);
+		set_error("hipMemcpy(CRC tables): %s", hipGetErrorString(ce));
+		return nullptr;
+	}
+	c->d_crc_tables = d_tab;
+	c->d_crc_xpow8 = d_tab + LDA_CRC_TABLE_WORDS;
 	c->num_cus = prop.multiProcessorCount;
 	c->device = dev;
 	return c;

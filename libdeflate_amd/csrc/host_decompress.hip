@@ -8,6 +8,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <new>
 #include <string.h>
 #include <vector>
@@ -174,15 +175,15 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 	bool par = true;
 	if (const char *e = getenv("LDA_INFLATE_PAR"))
 		par = atoi(e) != 0;
-	static bool attr_set[16];
-	if (!attr_set[c->device]) {
+	static std::atomic<bool> attr_set[16];
+	if (!attr_set[c->device].load(std::memory_order_acquire)) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_inflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)(lda_inflate_lds_per_stream() * 64 +
 				      lda_inflate_lds_shared())),
 			    LIBDEFLATE_AMD_NO_DEVICE);
-		attr_set[c->device] = true;
+		attr_set[c->device].store(true, std::memory_order_release);
 	}
 	if (par) {
 		size_t per_cu = 16;

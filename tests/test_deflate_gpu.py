@@ -7,6 +7,7 @@ test_litrunlen_overflow.c, test_trailing_bytes.c):
   - size <= compress_bound, container bytes/footers exact,
   - returns 0 exactly when the output does not fit,
   - ratio tracks the reference's at the same level (reported, loose gate)."""
+import os
 import zlib
 
 import numpy as np
@@ -497,3 +498,31 @@ def test_small_buffer_kernel(level, oracle):
     got = o_n.cpu().numpy()
     assert got[3] == 0 and (np.delete(got, 3) > 0).all()
     c.close()
+
+
+def test_first_call_small_batch_then_large():
+    """A process whose FIRST compress call is a batch of small buffers (the
+    256-thread kernel) must still be able to launch the 1024-thread kernels
+    afterwards: the per-device LDS limits of all three kernels are set on the
+    first call, each to its own size.  Needs a fresh process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, zlib
+sys.path.insert(0, %r)
+from tests import datagen
+from libdeflate_amd import api
+c = api.Compressor(6)
+small = [datagen.chunk(i, 3000, 0x0E110080, datagen.MIX4K) for i in range(16)]
+for d, z in zip(small, c.compress_batch_host("zlib", small)):
+    assert zlib.decompress(z) == d
+big = [datagen.chunk(i, 65536, 0x0E110081) for i in range(8)]
+for d, z in zip(big, c.compress_batch_host("zlib", big)):
+    assert z is not None and zlib.decompress(z) == d
+c12 = api.Compressor(12)
+for d, z in zip(big[:2], c12.compress_batch_host("zlib", big[:2])):
+    assert z is not None and zlib.decompress(z) == d
+print("ok")
+''' % os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
