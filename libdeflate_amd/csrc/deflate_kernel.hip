@@ -1272,7 +1272,7 @@ match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
  *             parse is repeated, and so on until the parse visits nothing
  *             new (or a round limit).  At the fixed point the result IS a
  *             serial lazy parse with full-depth searches at what it visits.
- * Measured on the 64 KiB mix (CPU model of this scheme, scratch/sim_mf.c):
+ * Measured on the 64 KiB mix (CPU model of this scheme, tools/models/sim_mf.c):
  * 3.9 chain steps per position instead of 15.0 at level 6 on text, output
  * 0.03 % smaller than the serial parse after two rounds.
  */
