@@ -1125,29 +1125,45 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 							vfar[k] = gfar[bi + 32768u - dist];
 					}
 				}
+				/* copies inside a slot: where each lane's byte finally comes
+				 * from.  That depends on the tokens alone, so the SB slots'
+				 * pointer chains are jumped together (their latencies
+				 * overlap) before the slots' bytes are settled in order. */
+				u32 root[SB];
+				bool any_intra = false;
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 tw = own[k], dist = (tw >> 9) & 0xFFFF;
+					const bool intra = (tw >> 31) && dist <= lane;
+					root[k] = intra ? lane - dist : lane;
+					any_intra |= intra;
+				}
+				if (__ballot(any_intra)) {
+					for (;;) {
+						bool ch = false;
+#pragma unroll
+						for (u32 k = 0; k < SB; k++) {
+							const u32 pp = (u32)__builtin_amdgcn_ds_bpermute(
+									(int)(root[k] << 2), (int)root[k]);
+							ch |= pp != root[k];
+							root[k] = pp;
+						}
+						if (!__ballot(ch))
+							break;
+					}
+				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane, tw = own[k];
 					const u32 dist = (tw >> 9) & 0xFFFF;
 					const bool match = (tw >> 31) != 0;	/* false past gtot */
-					const bool intra = match && dist <= lane;
 					/* every lane reads the mirror (the index is always
 					 * inside it); matches from outside the slot use it */
 					const u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
 					u32 v = match ? wv : tw & 0xFF;
 					v = vfar[k] < 0x100 ? vfar[k] : v;
-					if (__ballot(intra)) {
-						u32 p = intra ? lane - dist : lane;
-						for (;;) {
-							const u32 pp = (u32)__builtin_amdgcn_ds_bpermute(
-									(int)(p << 2), (int)p);
-							const bool ch = pp != p;
-							p = pp;
-							if (!__ballot(ch))
-								break;
-						}
-						v = (u32)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)v);
-					}
+					if (__ballot(root[k] != lane))
+						v = (u32)__builtin_amdgcn_ds_bpermute((int)(root[k] << 2), (int)v);
 					if (bi < gtot)
 						win[(gb + bi) & (PAR_RW - 1)] = (u8)v;
 				}
