@@ -57,7 +57,8 @@ def blocks(data):
     bits = Bits(data); pos = 0
     while True:
         final = bits.get(pos, 1); typ = bits.get(pos + 1, 2); pos += 3
-        assert typ == 2, typ
+        if typ != 2:
+            return    # stored / static block: not modelled
         nlit = 257 + bits.get(pos, 5); noff = 1 + bits.get(pos + 5, 5); npre = 4 + bits.get(pos + 10, 4); pos += 14
         perm = [16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15]
         pl = [0] * 19
