@@ -270,41 +270,54 @@ def roundtrip_config(torch, dist, world, rank, dev, stream, api, shard, chunks,
 
 def end_to_end(torch, dev, stream, api, tensors):
     """The headline batch from pinned host memory and back: H2D of the input,
-    compress, D2H of the output slots; H2D of the slots, decompress, D2H of
-    the output (SURVEY.md 8(d) "(ii) end-to-end"; the reference times from
-    host buffers, programs/test_util.c:143-164)."""
+    compress, device-side compaction, D2H of the compressed bytes; H2D of the
+    compressed bytes, decompress, D2H of the output (SURVEY.md 8(d) "(ii)
+    end-to-end"; the reference times from host buffers,
+    programs/test_util.c:143-164)."""
     data, in_off, in_n, comp, c_off, c_av, c_n, out, res, comp_c, dec = tensors
+    n = in_off.numel()
     h_in = torch.empty(data.numel(), dtype=torch.uint8).pin_memory()
     h_in.copy_(data)
     h_comp = torch.empty(comp.numel(), dtype=torch.uint8).pin_memory()
+    h_off = torch.empty(n + 1, dtype=torch.int64).pin_memory()
     h_out = torch.empty(out.numel(), dtype=torch.uint8).pin_memory()
+    d_packed = torch.empty(comp.numel(), dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
     best_c = best_d = None
+    total = 0
     for it in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         data.copy_(h_in, non_blocking=True)
         comp_c.compress_batch(FMT, data, in_off, in_n, comp, c_off, c_av, c_n,
                               stream=stream)
-        h_comp.copy_(comp, non_blocking=True)
+        packed, poff = api.compact_batch(comp, c_off, c_n, stream=stream)
+        h_off.copy_(poff, non_blocking=True)
+        torch.cuda.synchronize()        # the host needs the total to size its copy
+        total = int(h_off[n])
+        h_comp[:total].copy_(packed[:total], non_blocking=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        comp.copy_(h_comp, non_blocking=True)
-        dec.decompress_batch(FMT, comp, c_off, c_n, out, in_off, in_n, res,
-                             stream=stream)
+        d_packed[:total].copy_(h_comp[:total], non_blocking=True)
+        d_off.copy_(h_off, non_blocking=True)
+        sizes = d_off[1:] - d_off[:-1]
+        dec.decompress_batch(FMT, d_packed, d_off[:n].contiguous(), sizes, out, in_off,
+                             in_n, res, stream=stream)
         h_out.copy_(out, non_blocking=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if it:
             best_c = min(best_c or 1e9, t1 - t0)
             best_d = min(best_d or 1e9, t2 - t1)
-    assert torch.equal(h_out, h_in)
+    assert torch.equal(h_out, h_in) and bool((res == 0).all())
     U = data.numel()
     return {"compress_MBps": round(U / best_c / 1e6, 1),
             "decompress_MBps": round(U / best_d / 1e6, 1),
             "roundtrip_MBps": round(U / (best_c + best_d) / 1e6, 1),
-            "note": "pinned host -> HBM -> pinned host, whole slot array copied "
-                    "back (H2D U + kernels + D2H slots; H2D slots + kernels + D2H U), "
-                    "best of 2 after a warm-up; one GPU"}
+            "compressed_bytes": total,
+            "note": "pinned host -> HBM -> pinned host: H2D U + compress + device "
+                    "compaction + D2H C; H2D C + decompress + D2H U; best of 2 "
+                    "after a warm-up; one GPU"}
 
 
 def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
