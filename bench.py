@@ -89,6 +89,27 @@ def pmc_static():
     return traffic, valu, src
 
 
+def inflate_static(t_dec):
+    """The same for the decompress kernel (profiles/*pmc_inflate*.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_inflate*.json")))
+    if not files:
+        return {}
+    k = json.load(open(files[-1])).get("lda_inflate_wave_kernel", {})
+    out = {"traffic_source": os.path.relpath(files[-1], ROOT) +
+           " (static: PMC passes of tools/prof_pmc.sh, not this run)"}
+    if "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
+        out["traffic"] = int(2 * k["FETCH_SIZE_per_launch"] * 1024 +
+                             k["WRITE_SIZE_per_launch"] * 1024)
+    if k.get("SQ_INSTS_VALU_per_launch"):
+        v = k["SQ_INSTS_VALU_per_launch"]
+        out["issue"] = {"valu_wave_insts_per_launch": int(v),
+                        "simd_issue_frac": round(v * 4 / (1024 * 2.4e9 * t_dec), 3),
+                        "note": "of the kernel's duration; while its waves are resident "
+                                "(SQ_WAVE_CYCLES) the VALU is busy nearly all the time"}
+    return out
+
+
 def usable_cores():
     """Cores this process may actually run on: the affinity mask, cut by a
     cgroup CPU quota if there is one (a container often shows the machine's
@@ -531,11 +552,11 @@ def main():
                 "avg_launch_ms": round(t_comp * 1e3, 3),
                 "note": "HIP events on the launch stream around the compress "
                         "call; U + C with the CRC-32 pass counted as part of it",
-                "inflate_kernel": {
+                "inflate_kernel": dict({
                     "kernel": "lda_inflate_wave_kernel",
                     "achieved": round((U + C) / t_dec / 1e9, 2),
                     "frac": round((U + C) / t_dec / 1e9 / HBM_PEAK_GBS, 5),
-                    "avg_launch_ms": round(t_dec * 1e3, 3)},
+                    "avg_launch_ms": round(t_dec * 1e3, 3)}, **inflate_static(t_dec)),
             },
         }
         if e2e:
