@@ -125,14 +125,8 @@
 #ifndef S6_ALWAYS_FLUSH
 #define S6_ALWAYS_FLUSH 0
 #endif
-#ifndef INS_SPLIT
-#define INS_SPLIT 64u		/* groups of the next tile inserted beside round A, the rest beside the first parse (64 = all beside round A: splitting measured 1.5 % slower, round A itself is what that phase waits for) */
-#endif
 #ifndef S3_HALF
 #define S3_HALF 1		/* 0: the lazy rule's look-ahead positions are not searched deeper */
-#endif
-#ifndef S3_RULE_FIRST
-#define S3_RULE_FIRST 0		/* round 1 from a parse (0) or from a local rule (1, 2) */
 #endif
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
@@ -175,10 +169,10 @@ struct deflate_lds {
 	u32 obs[1][10];		/* block-split observations of the block before this tile */
 	u32 vars[24];
 	u64 pm[TILE / 64];	/* parse: token starts of the tile, one bit per position */
-	u64 nh[TILE / 64 + 2];	/* positions the parse consulted as look-ahead */
 	u64 lit1[TILE / 64];	/* step of the position is 1 (a literal) */
 	u64 lit2[TILE / 64];	/* step is 2 (two literals, lazy2 deferral) */
 	u32 qn[4];		/* round B: item counts of three generations in rotation */
+	u32 gbase[TILE / 64];	/* emit: first token-list index of each group of 64 positions */
 };
 
 /* LDS-resident: every pointer into the block carries the address space, and
@@ -203,7 +197,8 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
-	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT
+	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT,
+	V_CTR2, V_PFLAG
 };
 
 /* depth classes of the progressive search (done[]): what a position has been
@@ -1139,13 +1134,11 @@ static __device__ __forceinline__ void lds_wait8(u32 *o)
  * the current tile, the phase with the most independent work per wave.
  */
 static __device__ __forceinline__ void
-insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 g_lo, u32 g_hi, u32 lane)
+insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 lane)
 {
-	u32 ngroups = (tend - t + 63) / 64;
+	const u32 ngroups = (tend - t + 63) / 64;
 
-	if (ngroups > g_hi)
-		ngroups = g_hi;
-	for (u32 g0 = g_lo; g0 < ngroups; g0 += 8) {
+	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
 		u32 o[8], sh[8];
 #pragma unroll
 		for (u32 k = 0; k < 8; k++) {
@@ -1254,6 +1247,30 @@ match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 	return ev ? len : 0;
 }
 
+/* stage the input bytes [loaded, want) into the ring (whole workgroup; the
+ * first 32 bytes of the ring are mirrored past its end for ld32 / ld64) */
+static __device__ __forceinline__ void
+stage_input(lds_t *L, const u8 *__restrict__ inp, u32 loaded, u32 want,
+	    bool aligned_in, u32 tid)
+{
+	if (aligned_in) {
+		const u32 from = loaded & ~15u;
+		for (u32 p = from + tid * 16; p < want; p += NT * 16) {
+			uint4 v = *(const uint4 *)(inp + p);
+			*(uint4 *)&L->in[p & RMASK] = v;
+			if ((p & RMASK) < 32)
+				*(uint4 *)&L->in[RING + (p & RMASK)] = v;
+		}
+	} else {
+		for (u32 p = loaded + tid; p < want; p += NT) {
+			u8 b = inp[p];
+			L->in[p & RMASK] = b;
+			if ((p & RMASK) < 32)
+				L->in[RING + (p & RMASK)] = b;
+		}
+	}
+}
+
 /* ---------------- progressive search ---------------- */
 
 /*
@@ -1277,8 +1294,9 @@ match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
  * 0.03 % smaller than the serial parse after two rounds.
  */
 static __device__ __forceinline__ void
-round_a(lds_t *L, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lo_pos,
-	u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3, u32 tid)
+round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
+	u32 lo_pos, u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3,
+	u32 tid)
 {
 	const u32 lane = tid & 63;
 
@@ -1326,7 +1344,7 @@ round_a(lds_t *L, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lo_pos
 			if (bd)
 				m = 3 | (bd << 16);
 		}
-		L->M[4 + i] = m;
+		Mo[4 + i] = m;
 		/* a chain that ended inside the shallow pass has been searched in full */
 		const u32 dn = (p - c16) & 0xFFFF;
 		L->done[4 + i] = (u8)(act && dn > dprev && dn <= dmaxp && best < nic ?
@@ -1359,16 +1377,6 @@ stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
 	}
 }
 
-/* the step of tile position q after stage_steps() */
-static __device__ __forceinline__ u32 step_of(const lds_t *L, u32 q)
-{
-	if ((L->lit1[q >> 6] >> (q & 63)) & 1)
-		return 1;
-	if ((L->lit2[q >> 6] >> (q & 63)) & 1)
-		return 2;
-	return L->M[4 + q] & 0xFFFF;
-}
-
 /*
  * Part 2, one wave: lane l walks the positions [64 l, 64 l + 64) by
  * p -> p + step(p) (a run of literals in one go, through the bitmap), first
@@ -1377,11 +1385,11 @@ static __device__ __forceinline__ u32 step_of(const lds_t *L, u32 q)
  * of the lane before it really arrives, until it meets its own earlier
  * path; repeated until no lane's arrival point changes (lane 0 starts at the
  * true entry, so lane k is exact after k passes at the latest; measured 2-3
- * passes).  Result: pm[l] = token starts in lane l's 64 positions, V_PEXIT =
+ * passes).  Result: pm[l] = token starts in lane l's 64 positions; returns
  * where the path leaves [0, limit).  entry >= 0.
  */
-static __device__ __forceinline__ void
-parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit)
+static __device__ __forceinline__ s32
+parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out)
 {
 	const s32 seg_lo = 64 * (s32)lane;
 	const s32 hi = seg_lo + 64 < limit ? seg_lo + 64 : limit;
@@ -1445,8 +1453,138 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit)
 	}
 	if (lane < TILE / 64)
 		L->pm[lane] = mask;
-	if (lane == 63)
-		L->vars[V_PEXIT] = (u32)ex;
+	*mask_out = mask;
+	return (s32)__builtin_amdgcn_readlane((int)ex, 63);
+}
+
+/* the carried-in idx 2, 3 (the last two positions of the tile before, which
+ * its parse deferred) can only be the entry itself */
+static __device__ __forceinline__ u32
+entry_skip(const lds_t *L, s32 entry, u32 lim_idx, u32 mode, u32 nice)
+{
+	u32 e = (u32)(entry + 4);
+
+	for (u32 pre = 0; pre < 2; pre++)
+		if (e < 4 && e < lim_idx)
+			e += token_step(L->M[e], L->M[e + 1], L->M[e + 2], mode, nice);
+	return e;
+}
+
+/*
+ * The final parse of a tile (ONE wave): the tokens that start in the deferred
+ * positions idx 2, 3 are appended by lane 0, parse_tile() finds the path, and
+ * a wave scan over the per-group token counts (one token per token start, two
+ * where the step is "two literals") leaves in gbase[g] where the tokens of
+ * group g go in the block's token list - after that the groups can be emitted
+ * in any order by any wave (emit_groups()).
+ */
+static __device__ __forceinline__ void
+parse_and_base(lds_t *L, u32 *__restrict__ tokg, u32 t, s32 limit, u32 mode,
+	       u32 nice, u32 lane)
+{
+	const s32 entry = (s32)L->vars[V_ENTRY];
+	const u32 lim_idx = (u32)(limit + 4);
+	const u32 seq0 = L->vars[V_NSEQ];
+	u32 e = (u32)(entry + 4), npre = 0;
+
+	for (u32 pre = 0; pre < 2; pre++) {	/* idx 2, 3 */
+		if (e < 4 && e < lim_idx) {
+			const u32 mm = L->M[e];
+			const u32 st = token_step(mm, L->M[e + 1], L->M[e + 2], mode, nice);
+			const u32 l0 = mm & 0xFFFF;
+			const bool ism = st == l0 && l0;
+			const u32 pos = (u32)((s32)t + (s32)e - 4);
+			if (lane == 0) {
+				if (ism) {
+					u32 sl, xb, xv;
+					tokg[seq0 + npre] = TOK_MATCH | (l0 - 3) |
+							    (((mm >> 16) - 1) << 8);
+					length_code(l0, &sl, &xb, &xv);
+					atomicAdd((u32 *)&L->freq[257 + sl], 1u);
+					dist_code(mm >> 16, &sl, &xb, &xv);
+					atomicAdd((u32 *)&L->freq[288 + sl], 1u);
+				} else {
+					const u32 b0 = L->in[pos & RMASK];
+					tokg[seq0 + npre] = b0;
+					atomicAdd((u32 *)&L->freq[b0], 1u);
+					if (st == 2) {
+						const u32 b1 = L->in[(pos + 1) & RMASK];
+						tokg[seq0 + npre + 1] = b1;
+						atomicAdd((u32 *)&L->freq[b1], 1u);
+					}
+				}
+			}
+			npre += !ism && st == 2 ? 2 : 1;
+			e += st;
+		}
+	}
+	u64 mask;
+	const s32 px = parse_tile(L, lane, (s32)e - 4, limit, &mask);
+	const u64 two = mask & L->lit2[lane];
+	const u32 cnt = (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(two);
+	const u32 incl = wave_scan_incl(cnt);
+	L->gbase[lane] = seq0 + npre + incl - cnt;
+	if (lane == 63) {
+		L->vars[V_NSEQ] = seq0 + npre + incl;
+		/* where the path leaves the tile */
+		L->vars[V_WALKPOS_LO] = (u32)((s32)t + px);
+		L->vars[V_ENTRY] = (u32)(px - (s32)TILE);
+	}
+}
+
+/*
+ * Emit: the lanes on the path classify their token, count it for the block's
+ * Huffman codes and append it to the block's token list in position order
+ * (ballot ranks inside the group, gbase[] across groups).  Groups of 64
+ * positions are claimed from a counter (V_CTR2, zero on entry) by whatever
+ * waves call this.
+ */
+static __device__ __forceinline__ void
+emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
+{
+	const u64 lt = (1ull << lane) - 1;
+
+#pragma unroll 1
+	for (;;) {
+		u32 g = 0;
+		if (lane == 0)
+			g = atomicAdd((u32 *)&L->vars[V_CTR2], 1u);
+		g = bcast_first(g);
+		if (g >= TILE / 64)
+			break;
+		const u64 pmk = L->pm[g];
+		if (!pmk)
+			continue;
+		const u64 two = pmk & L->lit2[g];
+		if ((pmk >> lane) & 1) {
+			const u32 q = 64 * g + lane, idx = q + 4;
+			const u32 m0 = L->M[idx];
+			const u32 l0 = m0 & 0xFFFF;
+			const u32 st = (L->lit1[g] >> lane) & 1 ? 1 : (two >> lane) & 1 ? 2 : l0;
+			const u32 pos = t + q;
+			const u32 at = L->gbase[g] + (u32)__builtin_popcountll(pmk & lt) +
+				       (u32)__builtin_popcountll(two & lt);
+			if (st == l0 && l0) {
+				u32 sl, xb, xv;
+				tokg[at] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
+				length_code(l0, &sl, &xb, &xv);
+				atomicAdd((u32 *)&L->freq[257 + sl], 1u);
+				dist_code(m0 >> 16, &sl, &xb, &xv);
+				atomicAdd((u32 *)&L->freq[288 + sl], 1u);
+			} else {
+				const u32 b0 = L->in[pos & RMASK];
+				tokg[at] = b0;
+				atomicAdd((u32 *)&L->freq[b0], 1u);
+				if (st == 2) {
+					const u32 b1 = L->in[(pos + 1) & RMASK];
+					tokg[at + 1] = b1;
+					atomicAdd((u32 *)&L->freq[b1], 1u);
+				}
+			}
+		}
+	}
+	/* the token list is read back by other waves at the end of the block */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
 /*
@@ -1457,104 +1595,13 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit)
  * Builds the worklist W[] (position | class << 12; search_queue() has the
  * layout), returns its length (at most WQ_CAP: what does not fit is asked
  * for again by the next parse).
- * Whole workgroup, three barriers.
+ * Whole workgroup, two barriers.
  */
 static __device__ __forceinline__ u32
-build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
+build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
 
-	if (by_rule) {
-		if (tid < TILE / 64 + 2)
-			L->nh[tid] = 0;
-		__syncthreads();
-	}
-	if (by_rule && S3_RULE_FIRST == 1) {
-		/* Before the first parse: a position INSIDE a match run (one byte
-		 * shorter than its predecessor's match, same distance) is where a
-		 * parse hardly ever starts a token; everything else - the first
-		 * position of every run, every literal - may well be one (pm), and
-		 * the position after the start of a run is what the lazy rule will
-		 * look at (nh).  Saves a parse; the set is larger than what that
-		 * parse would have visited. */
-#pragma unroll
-		for (u32 k = 0; k < TILE / NT; k++) {
-			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-			const u32 m = L->M[4 + q], mp = L->M[3 + q];
-			const u32 l = m & 0xFFFF, lp = mp & 0xFFFF;
-			const bool inside = lp >= 4 && l + 1 == lp && (m >> 16) == (mp >> 16);
-			const u64 b = __ballot(!inside);
-			const u64 bl = __ballot(!inside && l >= 3 && l < nice && mode >= 1);
-			if (lane == 0) {
-				L->pm[g] = b;
-				if (bl) {
-					atomicOr((unsigned long long *)&L->nh[g], bl << 1);
-					if (bl >> 63)
-						atomicOr((unsigned long long *)&L->nh[g + 1], bl >> 63);
-				}
-			}
-		}
-	} else if (by_rule) {
-		/* Before the first parse: where can a token start?  With the
-		 * matches of the shallow pass, a position whose own match does not
-		 * reach beyond what the matches before it already cover is where
-		 * a parse hardly ever starts one.  What remains - the positions
-		 * that extend the covered range, and the literals outside it - is
-		 * searched deeply (pm), and the position after the start of such a
-		 * match is what the lazy rule will look at (nh).  reach(q) = q +
-		 * len(q); P(q) = max(entry, max of reach over r < q): an exclusive
-		 * prefix maximum over the tile (DPP scan per 64, the wave's four
-		 * groups in sequence, the waves through LDS).  Saves a parse. */
-		u32 rq[TILE / NT], ex[TILE / NT], run = 0;
-#pragma unroll
-		for (u32 k = 0; k < TILE / NT; k++) {
-			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-			const u32 l = L->M[4 + q] & 0xFFFF;
-			rq[k] = q + l;
-			u32 v = rq[k];
-			u32 o;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); v = o > v ? o : v;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); v = o > v ? o : v;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); v = o > v ? o : v;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); v = o > v ? o : v;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = o > v ? o : v;
-			o = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = o > v ? o : v;
-			/* exclusive: the inclusive maximum of the lane before */
-			u32 e = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
-			e = lane ? e : 0;
-			ex[k] = e > run ? e : run;
-			const u32 tot = (u32)__builtin_amdgcn_readlane((int)v, 63);
-			run = tot > run ? tot : run;
-		}
-		if (lane == 0)
-			L->scan[0][wave] = run;
-		__syncthreads();
-		const s32 ent = (s32)L->vars[V_ENTRY];
-		u32 pre = ent > 0 ? (u32)ent : 0;
-		for (u32 w = 0; w < wave; w++) {
-			const u32 c = L->scan[0][w];
-			pre = c > pre ? c : pre;
-		}
-#pragma unroll
-		for (u32 k = 0; k < TILE / NT; k++) {
-			const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-			const u32 P = ex[k] > pre ? ex[k] : pre;
-			const u32 l = rq[k] - q;
-			const bool cand = l >= 3 ? rq[k] > P : q >= P;
-			const u64 b = __ballot(cand);
-			const u64 bl = __ballot(cand && l >= 3 && l < nice && mode >= 1);
-			if (lane == 0) {
-				L->pm[g] = b;
-				if (bl) {
-					atomicOr((unsigned long long *)&L->nh[g], bl << 1);
-					if (bl >> 63)
-						atomicOr((unsigned long long *)&L->nh[g + 1], bl >> 63);
-				}
-			}
-		}
-	}
-	if (by_rule)
-		__syncthreads();
 	/* parse-based: the positions the lazy rule looked at are the one (lazy2:
 	 * two) after a token start that holds a match shorter than the nice
 	 * length.  A wave owns four consecutive groups of 64, so the bits that
@@ -1562,7 +1609,7 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 	 * the group before the wave's first is recomputed from that group's last
 	 * two positions. */
 	u64 spill = 0;
-	if (!by_rule && mode >= 1 && S3_HALF && wave) {
+	if (mode >= 1 && S3_HALF && wave) {
 		const u32 g0 = wave * (TILE / NT), q1 = 64 * g0 - 1;
 		const u64 pmask = L->pm[g0 - 1];
 		const u32 l1 = L->M[4 + q1] & 0xFFFF, l2 = L->M[4 + q1 - 1] & 0xFFFF;
@@ -1580,16 +1627,11 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
 		const u64 tmask = L->pm[g];
-		u64 hmask;
-		if (by_rule) {
-			hmask = L->nh[g];
-		} else {
-			const u32 l0 = L->M[4 + q] & 0xFFFF;
-			const u64 b = mode >= 1 && S3_HALF ?
-				__ballot(((tmask >> lane) & 1) && l0 >= 3 && l0 < nice) : 0;
-			hmask = (b << 1) | (mode >= 2 ? b << 2 : 0) | spill;
-			spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
-		}
+		const u32 l0 = L->M[4 + q] & 0xFFFF;
+		const u64 b = mode >= 1 && S3_HALF ?
+			__ballot(((tmask >> lane) & 1) && l0 >= 3 && l0 < nice) : 0;
+		const u64 hmask = (b << 1) | (mode >= 2 ? b << 2 : 0) | spill;
+		spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
 		want[k] = ((tmask >> lane) & 1) ? DC_FULL :
 			  ((hmask >> lane) & 1) ? DC_HALF : DC_SHALLOW;
 		const bool add = want[k] > L->done[4 + q] &&
@@ -1646,7 +1688,7 @@ build_worklist(lds_t *L, AS3 u32 *W, bool by_rule, u32 mode, u32 nice, u32 tid)
  * Whole workgroup; V_CTR must be 0 on entry (barrier in between).
  */
 static __device__ __forceinline__ void
-search_items(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
+search_items(lds_t *L, AS3 u32 *Mo, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	     u32 nice, const u16 *W, u32 cnt_items, u32 nwaves, u32 tid)
 {
 	const u32 lane = tid & 63;
@@ -1678,7 +1720,7 @@ search_items(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 			cbase = bcast_first(cbase);
 			if (fin) {
 				if (my_i < TILE && (!W || best > best0))
-					L->M[4 + my_i] = best >= 4 && best >= min_len ?
+					Mo[4 + my_i] = best >= 4 && best >= min_len ?
 						(best | (bestd << 16)) : 0;
 				fin = false;
 				my_i = 0xFFFFFFFFu;
@@ -1697,7 +1739,7 @@ search_items(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 						bestd = 0;
 						if (W) {
 							dep = (item >> 12) == DC_FULL ? depth : half;
-							u32 m = L->M[4 + my_i], l0 = m & 0xFFFF;
+							u32 m = Mo[4 + my_i], l0 = m & 0xFFFF;
 							if (l0 >= 4) {
 								best = l0;
 								bestd = m >> 16;
@@ -2018,6 +2060,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		if (tid == 0) {
 			L->vars[V_NSEQ] = 0;
 			L->vars[V_ENTRY] = 0;
+			L->vars[V_PFLAG] = 0;
 		}
 		os.sg = (u64)(0 - ((uintptr_t)os.out & 15));
 		os.bits = 0;
@@ -2069,11 +2112,43 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		if (num_tiles == 0)
 			num_tiles = 1;
 
-		for (u32 tile = 0; tile < num_tiles && !overflow; tile++) {
-			const u32 t = tile * TILE;
+		const bool ra_all = depth <= 4;	/* a search of a few steps is done in full by the first pass */
+		const bool optm = OPT && mode == 3;
+		const u32 rounds = optm || ra_all ? 0 : S3_ROUNDS;
+		const u32 dlim3 = mode ? 8192u : 4096u;
+		const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
+		const u32 ra_class = ra_all ? DC_FULL :
+				     ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW;
+		bool mx_pending = false;	/* the next tile's search results wait in MX */
+		u32 ml_cur = 3, ml_nxt = 3;	/* minimum match length of tile cur / nxt */
+		u32 carryv = 0;			/* M[TILE + tid] of the tile before (tid < 4) */
+
+		/*
+		 * The schedule.  Iteration `it` FINISHES tile cur = it - 1 (deep
+		 * search of what a first parse visits, final parse, tokens, block
+		 * end) and PREPARES the tiles after it: the shallow search of tile
+		 * nxt = it and the chain insertion of tile it + 1 run in the same
+		 * phase ("phase X") as the final parse and the token emission of
+		 * tile cur - the parse is one wave's serial walk and the emission
+		 * starts when it ends, the insertion is one wave's serial instruction
+		 * stream, and the shallow search is what fills the other waves'
+		 * issue slots meanwhile.  The search results of tile nxt land in MX
+		 * (the LDS of the round-B lists and the bit staging area, both idle
+		 * in that phase) and move to M[] at the top of the next iteration.
+		 * Iteration 0 has no cur: it inserts tile 0 and runs phase X for
+		 * tile 0 alone; dictionary tiles (segment mode) are only inserted.
+		 */
+		for (u32 it = 0; it <= num_tiles && !overflow; it++) {
+			const bool have_cur = it >= 1;
+			const u32 tile = it - 1;	/* cur (meaningless in iteration 0) */
+			const u32 t = have_cur ? tile * TILE : 0;
 			const u32 tend = t + TILE < n ? t + TILE : n;
-			const bool last_tile = tile + 1 == num_tiles;
-			const bool prime = t < dict_len;	/* dictionary tile (whole tiles) */
+			const bool last_tile = it == num_tiles;
+			const bool cur_real = have_cur && t >= dict_len;	/* not a dictionary tile */
+			const u32 tn = it * TILE;	/* nxt */
+			const u32 tnend = tn + TILE < n ? tn + TILE : n;
+			const bool nxt_real = it < num_tiles && tn >= dict_len;
+			const bool have_ins = it + 1 < num_tiles;
 			/* the thread index is made opaque once per tile: otherwise every
 			 * per-lane address in this loop body is computed before the loop
 			 * and kept alive (in scratch) across it */
@@ -2082,395 +2157,293 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			const u32 tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
 
 			PROF_MARK(0);
-			/* ---- S0: stage input up to the end of the NEXT tile + LOOKAHEAD
-			 * (the next tile is inserted into the chains while this one
-			 * is searched) ---- */
-			const u32 tend2 = t + 2 * TILE < n ? t + 2 * TILE : n;
-			u32 want = tend2 + LOOKAHEAD < n ? tend2 + LOOKAHEAD : n;
-			if (aligned_in) {
-				u32 from = loaded & ~15u;
-				for (u32 p = from + tid * 16; p < want; p += NT * 16) {
-					uint4 v = *(const uint4 *)(inp + p);
-					*(uint4 *)&L->in[p & RMASK] = v;
-					if ((p & RMASK) < 32)
-						*(uint4 *)&L->in[RING + (p & RMASK)] = v;
-				}
-			} else {
-				for (u32 p = loaded + tid; p < want; p += NT) {
-					u8 b = inp[p];
-					L->in[p & RMASK] = b;
-					if ((p & RMASK) < 32)
-						L->in[RING + (p & RMASK)] = b;
-				}
-			}
-			loaded = want;
-			if (tid < 4)
-				L->M[TILE + 4 + tid] = 0;
-			if (tid == 0)
-				L->vars[V_CTR] = 0;
-			__syncthreads();
-			if (!prime && !stored_only) {
-				/* minimum match length from the distinct bytes of this
-				 * tile's input (calculate_min_match_len,
-				 * deflate_compress.c:2329-2353, which the reference applies
-				 * to the first 4096 bytes and then refreshes per block from
-				 * the literals used; with blocks as long as a buffer the
-				 * per-tile estimate is what follows content changes) */
-				u32 *seen = L->M + 16;
-				for (u32 i = tid; i < 256; i += NT)
-					seen[i] = 0;
-				__syncthreads();
-				u32 lim = want - t < 4096 ? want - t : 4096;
-				for (u32 i = tid; i < lim; i += NT)
-					seen[L->in[(t + i) & RMASK]] = 1;
-				__syncthreads();
-				u32 c1 = tid < 256 ? seen[tid] : 0, tot1;
-				(void)block_scan(L, c1, &tot1);
-				if (tid == 0)
-					L->vars[V_MINLEN] = n - dict_len < 512 ? 3 :
-							    choose_min_len(tot1, depth);
-				__syncthreads();
-			} else if (tile == 0 && tid == 0) {
-				L->vars[V_MINLEN] = 3;	/* dictionary tiles: not used */
-			}
-
-			PROF_MARK(1);
-			if (!stored_only) {
-				/* ---- S1 + S2: the NEXT tile joins the chains (one wave,
-				 * insert_tile()) beside the search of this one; the first
-				 * tile of a buffer has to be inserted up front ---- */
-				/* a search of a few steps is done in full by the first pass */
-				const bool ra_all = depth <= 4;
-				const bool use3 = true;
-				u16 *c3cur = c3g + (tile & 1) * (TILE + 8);
-				u16 *c3nxt = c3g + ((tile + 1) & 1) * (TILE + 8);
-				if (tile == 0) {
-					if (wave == NWAVES - 1)
-						insert_tile(L, t, tend, n, 0, TILE / 64, lane);
-					if (wave == NWAVES - 2 && use3) {
-						insert_tile3(L, c3cur, t, tend, n, lane);
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					}
-					__syncthreads();
-				}
-				if (prime) {	/* dictionary tile: nothing to search or emit */
-					if (wave == NWAVES - 1 && !last_tile)
-						insert_tile(L, tend, tend2, n, 0, TILE / 64, lane);
-					if (wave == NWAVES - 2 && !last_tile && use3) {
-						insert_tile3(L, c3nxt, tend, tend2, n, lane);
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					}
-					__syncthreads();
+			if (stored_only) {
+				if (!have_cur)
 					continue;
+				walkpos = tend;
+			} else {
+				AS3 u32 *const MX = (AS3 u32 *)L->nxtB;
+#ifdef LDA_SMALL
+				const u32 lo_cur = 0, lo_nxt = 0;	/* the whole buffer is resident */
+#else
+				const s32 lo_s = (s32)(t + 2 * TILE + LOOKAHEAD) - (s32)RING;
+				const u32 lo_cur = lo_s > 0 ? (u32)lo_s : 0;
+				const s32 lo_n = (s32)(tn + 2 * TILE + LOOKAHEAD) - (s32)RING;
+				const u32 lo_nxt = lo_n > 0 ? (u32)lo_n : 0;
+#endif
+				u16 *c3nxt = c3g + (it & 1) * (TILE + 8);
+				u16 *c3ins = c3g + ((it + 1) & 1) * (TILE + 8);
+				const s32 limit = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
+
+				if (cur_real) {
+					/* ---- tile cur: its shallow results into M[] ---- */
+					if (mx_pending)
+						for (u32 i = tid; i < TILE; i += NT)
+							L->M[4 + i] = MX[4 + i];
+					if (tid < 4) {
+						L->M[tid] = carryv;
+						L->M[TILE + 4 + tid] = 0;
+					}
+					mx_pending = false;
+					ml_cur = ml_nxt;
+					/* the block as it is before this tile's tokens: if the tile
+					 * turns out to be of different content, the block ends in
+					 * front of it (see "block end?") */
+					for (u32 i = tid; i < 320; i += NT)
+						fsave[i] = L->freq[i];
+					if (tid == 0) {
+						L->vars[V_NSEQ_PRE] = L->vars[V_NSEQ];
+						L->vars[V_WPOS_PRE] = walkpos;
+					}
+					__syncthreads();
+					PROF_MARK(6);
+				}
+				if (cur_real && !optm) {
+					/* ---- S3 round B: a parse over the results so far, then
+					 * the positions it visits are searched deeper
+					 * ("progressive search") ---- */
+					for (u32 r = 0; r < rounds; r++) {
+						stage_steps(L, limit, mode, nice, tid);
+						__syncthreads();
+						if (wave == 0) {
+							u64 mk;
+							const u32 e = entry_skip(L, (s32)L->vars[V_ENTRY],
+										 (u32)(limit + 4), mode, nice);
+							(void)parse_tile(L, lane, (s32)e - 4, limit, &mk);
+						}
+						__syncthreads();
+						PROF_MARK(12);
+						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice, tid);
+						if (wc == 0)
+							break;
+						search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
+							     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
+						PROF_MARK(3);
+					}
+					/* steps of the final parse (it runs in phase X) */
+					stage_steps(L, limit, mode, nice, tid);
+					__syncthreads();
+				}
+				if (cur_real && optm) {
+					/* levels 10-12 (mode 3): min-cost parse, see opt_parse_wave().
+					 * A block's first tile is parsed lazily as a dry run (stage 0),
+					 * rolled back, and parsed again with prices from that run
+					 * (stage 1; level 11 and up once more with the prices of stage
+					 * 1); later tiles take their prices from the block so far.
+					 * Parse and emission run here, before phase X: the price
+					 * tables and the chosen lengths use the LDS of MX. */
+					const bool opt_first = walkpos == block_start;
+					const u32 opt_last = level >= 11 ? 2 : 1;
+					u32 opt_stage = 0;
+					const u32 ent0 = L->vars[V_ENTRY], nseq0 = L->vars[V_NSEQ];
+					if (opt_first) {
+						for (u32 i = tid; i < TILE + 8; i += NT)
+							msave[i] = L->M[i];
+						if (tid == 0)
+							L->vars[V_FIT] = 0;
+					} else {
+						/* a tile the block's statistics do not describe keeps
+						 * the lazy parse (stage 0, final) */
+						const u32 fit = opt_build_costs(L, tid, false, true, t, tend - t, bsave);
+						opt_stage = fit ? 0 : 1;
+						if (tid == 0) {
+							L->vars[V_FIT] = fit;
+							if (c == 0) {
+								DBG(tile, 6, 100 + fit);
+								DBG(tile, 7, L->vars[V_TMP3]);
+							}
+						}
+					}
+					for (;;) {
+						/* opaque again: see the top of the tile loop */
+						u32 tid_opaque2 = threadIdx.x;
+						asm volatile("" : "+v"(tid_opaque2));
+						const u32 tid = tid_opaque2, lane = tid & 63, wave = tid >> 6;
+						const u32 s4mode = opt_stage ? 0 : 2;
+						if (opt_stage) {
+							const s32 ent = (s32)ent0;
+							const s32 pend = (s32)(tend - t);
+							s32 lo = (s32)(OPT_SEG * wave), hi = lo + OPT_SEG;
+							if (wave == 0 && ent < 0)
+								lo = ent;
+							if (hi > limit)
+								hi = limit;
+							s32 e = hi + OPT_WARM;
+							if (e > pend)
+								e = pend;
+							if (lo < hi)
+								opt_parse_wave(L, L->nxtA, t, lo, hi, e, lane);
+							__syncthreads();
+							for (s32 i = (s32)tid + (ent < 0 ? ent : 0); i < limit; i += NT) {
+								u32 c = L->nxtA[i + 4], m = L->M[i + 4];
+								L->M[i + 4] = c >= 3 ? c | (m & 0xFFFF0000u) : 0;
+							}
+							__syncthreads();
+						}
+						stage_steps(L, limit, s4mode, nice, tid);
+						if (tid == 0)
+							L->vars[V_CTR2] = 0;
+						__syncthreads();
+						if (wave == 0)
+							parse_and_base(L, tokg, t, limit, s4mode, nice, lane);
+						__syncthreads();
+						PROF_MARK(12);
+						emit_groups(L, tokg, t, lane);
+						__syncthreads();
+						PROF_MARK(5);
+						if (!opt_first || opt_stage == opt_last)
+							break;
+						/* prices from this parse, then undo it */
+						opt_build_costs(L, tid, opt_stage == 0, false, t, tend - t, bsave);
+						for (u32 i = tid; i < 320; i += NT)
+							L->freq[i] = 0;
+						for (u32 i = tid; i < TILE + 8; i += NT)
+							L->M[i] = msave[i];
+						if (tid == 0) {
+							L->vars[V_ENTRY] = ent0;
+							L->vars[V_NSEQ] = nseq0;
+						}
+						__syncthreads();
+						opt_stage++;
+					}
+				}
+
+				/* ---- S0: input up to the end of tile it + 1 (+ LOOKAHEAD): what
+				 * the shallow search of tile nxt reads and what the insertion
+				 * of tile it + 1 hashes ---- */
+				{
+					const u32 want0 = (it + 2) * TILE + LOOKAHEAD;
+					const u32 want = want0 < n ? want0 : n;
+					stage_input(L, inp, loaded, want, aligned_in, tid);
+					loaded = want > loaded ? want : loaded;
+					if (tid == 0) {
+						L->vars[V_CTR] = 0;
+						L->vars[V_CTR2] = 0;
+					}
+					/* minimum match length from the distinct bytes of tile
+					 * nxt's input (calculate_min_match_len,
+					 * deflate_compress.c:2329-2353, which the reference applies
+					 * to the first 4096 bytes and then refreshes per block from
+					 * the literals used; with blocks as long as a buffer the
+					 * per-tile estimate is what follows content changes) */
+					if (nxt_real) {
+						AS3 u32 *seen = (AS3 u32 *)L->nxtA + 16;
+						for (u32 i = tid; i < 256; i += NT)
+							seen[i] = 0;
+						__syncthreads();
+						const u32 lim = want - tn < 4096 ? want - tn : 4096;
+						for (u32 i = tid; i < lim; i += NT)
+							seen[L->in[(tn + i) & RMASK]] = 1;
+						__syncthreads();
+						if (wave == 0) {
+							const u32 c1 = wave_sum(seen[lane] + seen[lane + 64] +
+										seen[lane + 128] + seen[lane + 192]);
+							if (lane == 0)
+								L->vars[V_MINLEN] = n - dict_len < 512 ? 3 :
+										    choose_min_len(c1, depth);
+						}
+					}
+					__syncthreads();
+					if (nxt_real)
+						ml_nxt = L->vars[V_MINLEN];
+				}
+				PROF_MARK(1);
+				if (it == 0) {
+					/* the first tile joins the chains up front */
+					if (wave == NWAVES - 1)
+						insert_tile(L, 0, tnend, n, lane);
+					if (wave == NWAVES - 2) {
+						insert_tile3(L, c3nxt, 0, tnend, n, lane);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					}
+					__syncthreads();
+					PROF_MARK(2);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				PROF_MARK(2);
-				/* ---- S3: search (see "progressive search") ---- */
-				const u32 min_len = L->vars[V_MINLEN];
-				const u32 dlim3 = mode ? 8192u : 4096u;
-#ifdef LDA_SMALL
-				const u32 lo_pos = 0;	/* the whole buffer is resident */
-#else
-				s32 lo_s = (s32)(t + 2 * TILE + LOOKAHEAD) - (s32)RING;
-				const u32 lo_pos = lo_s > 0 ? (u32)lo_s : 0;
-#endif
-				const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
-				if (wave == NWAVES - 1) {
-					/* the next tile's chain insertion: one wave's serial
-					 * instruction stream, the longest item of this phase -
-					 * it gets the issue slots of its SIMD first */
-					__builtin_amdgcn_s_setprio(3);
-					if (!last_tile)
-						insert_tile(L, tend, tend2, n, 0, INS_SPLIT, lane);
-					__builtin_amdgcn_s_setprio(0);
-				} else if (wave == NWAVES - 2) {
-					__builtin_amdgcn_s_setprio(2);
-					if (!last_tile && use3) {
-						insert_tile3(L, c3nxt, tend, tend2, n, lane);
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					}
-					__builtin_amdgcn_s_setprio(0);
-				}
-				if (OPT && mode == 3) {
-					if (wave < NWAVES - 2)
-					/* the min-cost parse prices every position: all of
-					 * them are searched to the full depth */
-					search_items(L, t, n, lo_pos, min_len, depth, nice,
-						     NULL, TILE, NWAVES - 2, tid);
-				} else {
-					/* (V_CTR was zeroed at the top of the tile) */
-					round_a(L, c3cur, t, tend, n, lo_pos, min_len, ra_depth,
-						ra_all ? DC_FULL :
-						ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW,
-						nice, dlim3, tid);
-				}
-				if (OPT && mode == 3) {
-					__syncthreads();
-					PROF_MARK(16);
-					/* length-3 matches for the positions left without a match */
-					if (min_len <= 3) {
-						for (u32 i = tid; i < TILE; i += NT) {
-							u32 p = t + i, b3 = 0;
-							if (p + 3 <= n && L->M[4 + i] == 0) {
-								u32 bd = find_len3(L, p, ld32(L->in, p),
-										   c3cur[4 + i], p - lo_pos,
-										   dlim3, &b3);
-								if (bd)
-									L->M[4 + i] = 3 | (bd << 16);
-							}
-						}
-					}
-				}
-				__syncthreads();
 
-				PROF_MARK(4);
-				/* the block as it is before this tile's tokens: if the tile
-				 * turns out to be of different content, the block ends in
-				 * front of it (see "block end?") */
-				for (u32 i = tid; i < 320; i += NT)
-					fsave[i] = L->freq[i];
-				if (tid == 0) {
-					L->vars[V_NSEQ_PRE] = L->vars[V_NSEQ];
-					L->vars[V_WPOS_PRE] = walkpos;
-				}
-				/* levels 10-12 (mode 3): min-cost parse, see opt_parse_wave().
-				 * A block's first tile is parsed lazily as a dry run (stage 0),
-				 * rolled back, and parsed again with prices from that run
-				 * (stage 1; level 11 and up once more with the prices of stage
-				 * 1); later tiles take their prices from the block so far. */
-				const bool opt = OPT && mode == 3;
-				const bool opt_first = opt && walkpos == block_start;
-				const u32 opt_last = level >= 11 ? 2 : 1;
-				u32 opt_stage = 0;
-				const u32 ent0 = L->vars[V_ENTRY], nseq0 = L->vars[V_NSEQ];
-				if (opt_first) {
-					for (u32 i = tid; i < TILE + 8; i += NT)
-						msave[i] = L->M[i];
-					if (tid == 0)
-						L->vars[V_FIT] = 0;
-				} else if (opt) {
-					/* a tile the block's statistics do not describe keeps
-					 * the lazy parse (stage 0, final) */
-					const u32 fit = opt_build_costs(L, tid, false, true, t, tend - t, bsave);
-					opt_stage = fit ? 0 : 1;
-					if (tid == 0) {
-						L->vars[V_FIT] = fit;
-						if (c == 0) {
-							DBG(tile, 6, 100 + fit);
-							DBG(tile, 7, L->vars[V_TMP3]);
-						}
-					}
-				}
-				bool ins_done = false;	/* second half of the next tile's insertion */
-				for (;;) {
-				/* opaque again: see the top of the tile loop */
-				u32 tid_opaque2 = threadIdx.x;
-				asm volatile("" : "+v"(tid_opaque2));
-				const u32 tid = tid_opaque2, lane = tid & 63, wave = tid >> 6;
-				const u32 s4mode = opt ? (opt_stage ? 0 : 2) : mode;
-				if (opt && opt_stage) {
-					const s32 ent = (s32)ent0;
-					const s32 lim = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
-					const s32 pend = (s32)(tend - t);
-					s32 lo = (s32)(OPT_SEG * wave), hi = lo + OPT_SEG;
-					if (wave == 0 && ent < 0)
-						lo = ent;
-					if (hi > lim)
-						hi = lim;
-					s32 e = hi + OPT_WARM;
-					if (e > pend)
-						e = pend;
-					if (lo < hi)
-						opt_parse_wave(L, L->nxtA, t, lo, hi, e, lane);
-					__syncthreads();
-					for (s32 i = (s32)tid + (ent < 0 ? ent : 0); i < lim; i += NT) {
-						u32 c = L->nxtA[i + 4], m = L->M[i + 4];
-						L->M[i + 4] = c >= 3 ? c | (m & 0xFFFF0000u) : 0;
-					}
-					__syncthreads();
-				}
-				/* ---- S4: token choice ----
-				 * step(p) is a pure function of M[p..p+2]; the chosen
-				 * tokens are the positions reachable from the entry point
-				 * by p -> p + step(p); idx = p + 4.  One wave finds the path
-				 * (parse_tile()); between parses the positions the path
-				 * visits are searched deeper, until it visits nothing new
-				 * ("progressive search"). */
-				const s32 entry = (s32)L->vars[V_ENTRY];
-				const s32 limit = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
-				const u32 lim_idx = (u32)(limit + 4);
-				const u32 rounds = opt || ra_all ? 0 : S3_ROUNDS;
-				for (u32 r = 0;; r++) {
-					if (S3_RULE_FIRST && r == 0 && rounds) {
-						/* round 1 takes its positions from a local rule
-						 * instead of a parse */
-						const u32 wc0 = build_worklist(L, (AS3 u32 *)L->nxtB, true,
-									       s4mode, nice, tid);
-						if (wc0)
-							search_queue(L, t, n, lo_pos, min_len, depth, nice,
-								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA,
-								     wc0, tid);
-						PROF_MARK(3);
-						continue;
-					}
-					/* the carried-in idx 2, 3 can only be the entry itself */
-					u32 e = (u32)(entry + 4);
-					for (u32 pre = 0; pre < 2; pre++)
-						if (e < 4 && e < lim_idx)
-							e += token_step(L->M[e], L->M[e + 1], L->M[e + 2],
-									s4mode, nice);
-					stage_steps(L, limit, s4mode, nice, tid);
-					__syncthreads();
-					if (wave == 0)
-						parse_tile(L, lane, (s32)e - 4, limit);
-					if (wave == NWAVES - 1 && !ins_done && !last_tile)
-						insert_tile(L, tend, tend2, n, INS_SPLIT, TILE / 64, lane);
-					ins_done = true;
-					__syncthreads();
-					PROF_MARK(12);
-					if (r >= rounds)
-						break;
-					const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, false, s4mode, nice, tid);
-					if (wc == 0)
-						break;
-					search_queue(L, t, n, lo_pos, min_len, depth, nice,
-						     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
-					PROF_MARK(3);
-				}
+				/* ---- phase X ---- */
 				{
-					enum { SEG = TILE / NWAVES, SL = SEG / 64 };
-					/* wave w owns idx [4 + SEG w, 4 + SEG (w + 1)) */
-					const u32 seg_lo = 4 + SEG * wave;
-					u32 e = (u32)(entry + 4);
-					const u32 seq0 = L->vars[V_NSEQ];
-					u32 npre = 0;
-					for (u32 pre = 0; pre < 2; pre++) {	/* idx 2, 3 */
-						if (e < 4 && e < lim_idx) {
-							u32 mm = L->M[e];
-							u32 st = token_step(mm, L->M[e + 1], L->M[e + 2],
-									    s4mode, nice);
-							u32 l0 = mm & 0xFFFF;
-							bool ism = st == l0 && l0;
-							u32 pos = (u32)((s32)t + (s32)e - 4);
-							if (tid == 0) {
-								if (ism) {
-									u32 sl, xb, xv;
-									tokg[seq0 + npre] = TOK_MATCH | (l0 - 3) |
-											    (((mm >> 16) - 1) << 8);
-									length_code(l0, &sl, &xb, &xv);
-									atomicAdd((u32 *)&L->freq[257 + sl], 1u);
-									dist_code(mm >> 16, &sl, &xb, &xv);
-									atomicAdd((u32 *)&L->freq[288 + sl], 1u);
-								} else {
-									u32 b0 = L->in[pos & RMASK];
-									tokg[seq0 + npre] = b0;
-									atomicAdd((u32 *)&L->freq[b0], 1u);
-									if (st == 2) {
-										u32 b1 = L->in[(pos + 1) & RMASK];
-										tokg[seq0 + npre + 1] = b1;
-										atomicAdd((u32 *)&L->freq[b1], 1u);
-									}
-								}
-							}
-							npre += !ism && st == 2 ? 2 : 1;
-							e += st;
+					const bool do_p2 = cur_real && !optm;
+					AS3 u32 *const Mo = cur_real ? MX : (AS3 u32 *)L->M;
+					if (wave == NWAVES - 1) {
+						/* the chain insertion of tile it + 1: one wave's serial
+						 * instruction stream, the longest item of this phase -
+						 * it gets the issue slots of its SIMD first */
+						__builtin_amdgcn_s_setprio(3);
+						if (have_ins)
+							insert_tile(L, tnend, tnend + TILE < n ? tnend + TILE : n,
+								    n, lane);
+						__builtin_amdgcn_s_setprio(0);
+					} else if (wave == NWAVES - 2) {
+						__builtin_amdgcn_s_setprio(2);
+						if (have_ins) {
+							insert_tile3(L, c3ins, tnend,
+								     tnend + TILE < n ? tnend + TILE : n, n, lane);
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						}
+						__builtin_amdgcn_s_setprio(0);
+					} else if (wave == 0 && do_p2) {
+						/* ---- S4: the final parse of tile cur ----
+						 * step(p) is a pure function of M[p..p+2]; the chosen
+						 * tokens are the positions reachable from the entry
+						 * point by p -> p + step(p); idx = p + 4 */
+						__builtin_amdgcn_s_setprio(3);
+						parse_and_base(L, tokg, t, limit, mode, nice, lane);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0)
+							*(volatile AS3 u32 *)&L->vars[V_PFLAG] = it;
+						__builtin_amdgcn_s_setprio(0);
+					}
+					/* ---- S3 round A: tile nxt ---- */
+					if (nxt_real) {
+						if (optm) {
+							/* the min-cost parse prices every position: all of
+							 * them are searched to the full depth */
+							if (wave < NWAVES - 2)
+								search_items(L, Mo, tn, n, lo_nxt, ml_nxt, depth, nice,
+									     NULL, TILE, NWAVES - 2, tid);
+						} else {
+							round_a(L, Mo, c3nxt, tn, tnend, n, lo_nxt, ml_nxt, ra_depth,
+								ra_class, nice, dlim3, tid);
 						}
 					}
-					/* emit: the lanes on the path classify their token,
-					 * count it for the block's Huffman codes and append it
-					 * to the block's token list in position order (ballot
-					 * ranks inside the wave, one workgroup scan across
-					 * waves) */
-					/* tokens of this wave's positions: one per token start,
-					 * two where the step is "two literals" */
-					u32 cw = 0;
-#pragma unroll
-					for (u32 k = 0; k < SL; k++) {
-						const u64 pmk = L->pm[SL * wave + k];
-						cw += (u32)__builtin_popcountll(pmk) +
-						      (u32)__builtin_popcountll(pmk & L->lit2[SL * wave + k]);
-					}
-					u32 *sc = L->scan[tog];
-					tog ^= 1;
-					if (lane == 0)
-						sc[wave] = cw;
-					if (tid == 0) {
-						/* where the path leaves the tile */
-						const s32 px = (s32)L->vars[V_PEXIT];
-						L->vars[V_WALKPOS_LO] = (u32)((s32)t + px);
-						L->vars[V_ENTRY] = (u32)(px - (s32)TILE);
+					if (do_p2) {
+						/* ---- the tokens of tile cur, as soon as its parse is
+						 * through ---- */
+						while (*(volatile AS3 u32 *)&L->vars[V_PFLAG] != it)
+							__builtin_amdgcn_s_sleep(4);
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						emit_groups(L, tokg, t, lane);
 					}
 					__syncthreads();
-					u32 base = seq0 + npre, tot = 0;
-#pragma unroll
-					for (u32 w = 0; w < NWAVES; w++) {
-						u32 c = sc[w];
-						if (w < wave)
-							base += c;
-						tot += c;
-					}
-					const u64 lt = (1ull << lane) - 1;
-#pragma unroll 4
-					for (u32 k = 0; k < SL; k++) {
-						const u32 idx = seg_lo + lane + 64 * k;
-						const u64 pmk = L->pm[SL * wave + k];
-						const u64 two = pmk & L->lit2[SL * wave + k];
-						if ((pmk >> lane) & 1) {
-							const u32 m0 = L->M[idx];
-							const u32 st = step_of(L, idx - 4);
-							const u32 l0 = m0 & 0xFFFF;
-							const u32 pos = t + idx - 4;
-							const u32 at = base + (u32)__builtin_popcountll(pmk & lt) +
-								       (u32)__builtin_popcountll(two & lt);
-							if (st == l0 && l0) {
-								u32 sl, xb, xv;
-								tokg[at] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
-								length_code(l0, &sl, &xb, &xv);
-								atomicAdd((u32 *)&L->freq[257 + sl], 1u);
-								dist_code(m0 >> 16, &sl, &xb, &xv);
-								atomicAdd((u32 *)&L->freq[288 + sl], 1u);
-							} else {
-								const u32 b0 = L->in[pos & RMASK];
-								tokg[at] = b0;
-								atomicAdd((u32 *)&L->freq[b0], 1u);
-								if (st == 2) {
-									const u32 b1 = L->in[(pos + 1) & RMASK];
-									tokg[at + 1] = b1;
-									atomicAdd((u32 *)&L->freq[b1], 1u);
+					if (optm && nxt_real) {
+						PROF_MARK(16);
+						/* length-3 matches for the positions left without a match */
+						if (ml_nxt <= 3) {
+							for (u32 i = tid; i < TILE; i += NT) {
+								u32 p = tn + i, b3 = 0;
+								if (p + 3 <= n && Mo[4 + i] == 0) {
+									u32 bd = find_len3(L, p, ld32(L->in, p),
+											   c3nxt[4 + i], p - lo_nxt,
+											   dlim3, &b3);
+									if (bd)
+										Mo[4 + i] = 3 | (bd << 16);
 								}
 							}
 						}
-						base += (u32)__builtin_popcountll(pmk) + (u32)__builtin_popcountll(two);
+						__syncthreads();
 					}
-					if (tid == 0)
-						L->vars[V_NSEQ] = seq0 + npre + tot;
-					/* the token list is read back by other waves at the
-					 * end of the block */
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					mx_pending = cur_real && nxt_real;
 				}
-				__syncthreads();
-				if (!opt_first || opt_stage == opt_last)
-					break;
-				/* prices from this parse, then undo it */
-				opt_build_costs(L, tid, opt_stage == 0, false, t, tend - t, bsave);
-				for (u32 i = tid; i < 320; i += NT)
-					L->freq[i] = 0;
-				for (u32 i = tid; i < TILE + 8; i += NT)
-					L->M[i] = msave[i];
-				if (tid == 0) {
-					L->vars[V_ENTRY] = ent0;
-					L->vars[V_NSEQ] = nseq0;
-				}
-				__syncthreads();
-				opt_stage++;
-				}
-				walkpos = L->vars[V_WALKPOS_LO];
-				PROF_MARK(5);
+				PROF_MARK(4);
+				if (!cur_real)
+					continue;	/* iteration 0, dictionary tiles: nothing to emit */
 
-				/* carry the last 4 match entries to the front for the
-				 * positions the walk deferred */
+				walkpos = L->vars[V_WALKPOS_LO];
+				/* the last 4 match entries go to the front of the next tile's,
+				 * for the positions the walk deferred */
 				if (tid < 4)
-					L->M[tid] = L->M[TILE + tid];
+					carryv = L->M[TILE + tid];
 				/* block split observations (see "block end?" below), by the
 				 * last wave while the others wait at the barrier */
 				if (wave == NWAVES - 1) {
@@ -2527,14 +2500,9 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						DBG(tile, 5, onow[8] + onow[9]);
 					}
 				}
-			} else {
-				if (prime)
-					continue;
-				walkpos = tend;
 			}
 			__syncthreads();
 
-			PROF_MARK(6);
 			/* ---- block end? ----
 			 * The reference ends a block when the kind of symbols changes
 			 * (lib/deflate_compress.c:2092-2218): ten observation classes
@@ -2576,6 +2544,13 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			/* ---- S5: codes, costs, block type ---- */
 			u32 btype = 0;	/* 0 stored, 1 static, 2 dynamic */
 			if (!stored_only) {
+				/* the block-end tables and the bit staging area are MX's
+				 * LDS: the next tile's search results wait in HBM meanwhile */
+				if (mx_pending) {
+					const AS3 u32 *MXs = (const AS3 u32 *)L->nxtB;
+					for (u32 i = tid; i < TILE; i += NT)
+						msave[4 + i] = MXs[4 + i];
+				}
 				if (tid == 0)
 					L->freq[256]++;
 				__syncthreads();
@@ -2977,17 +2952,6 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * (M is reused as tile scratch) */
 			stg_save(L, &os);
 			PROF_MARK(8);
-			if (!stored_only) {
-				/* recalculate_min_match_len (deflate_compress.c:2359-2378):
-				 * literals used more than total/1024 times in this block */
-				u32 lf = tid < 256 ? L->freq[tid] : 0, lit_total;
-				(void)block_scan(L, lf, &lit_total);
-				u32 usedf = (tid < 256 && lf > (lit_total >> 10)) ? 1 : 0, nused;
-				(void)block_scan(L, usedf, &nused);
-				if (tid == 0)
-					L->vars[V_MINLEN] = choose_min_len(nused, depth);
-				__syncthreads();
-			}
 			if (OPT && mode == 3 && tid < 256)
 				bsave[tid] = 0;	/* the previous tile's bytes are added by the next one */
 			if (retro) {
@@ -3015,12 +2979,14 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (tid == 0)
 					L->vars[V_NSEQ] = 0;
 			}
-			/* restore what S1..S4 expect in M[0..3]: the deferred
-			 * entries were consumed only if the walk passed them; the
-			 * encode pass clobbered them, so re-derive from nothing:
-			 * deferred positions are re-evaluated as "no match" */
-			if (tid < 4)
-				L->M[tid] = 0;
+			/* the positions the walk deferred into the next tile are
+			 * re-evaluated as "no match" after a block end */
+			carryv = 0;
+			if (mx_pending) {
+				for (u32 i = tid; i < TILE; i += NT)
+					L->M[4 + i] = msave[4 + i];
+				mx_pending = false;
+			}
 			block_start = bend;
 			__syncthreads();
 		}
