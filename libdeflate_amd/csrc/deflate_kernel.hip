@@ -128,6 +128,9 @@
 #ifndef S3_HALF
 #define S3_HALF 1		/* 0: the lazy rule's look-ahead positions are not searched deeper */
 #endif
+#ifndef P1_PASSES
+#define P1_PASSES 0xFFFFFFFFu	/* passes of the first (worklist) parse */
+#endif
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
 #endif
@@ -135,6 +138,12 @@
 #define WQ_CAP 2048u		/* round B items per round; the rest waits for the next round */
 #endif
 #define WQ_SEG (WQ_CAP / NWAVES)
+#ifndef GEN_GROW
+#define GEN_GROW 1		/* round B: generation g walks (g + 1) quanta */
+#endif
+#ifndef WQ_LIMIT
+#define WQ_LIMIT WQ_CAP		/* items taken per round (<= WQ_CAP) */
+#endif
 /* nxtA / nxtB: two scratch arrays of NXT_ELEMS u16 (round B lists of WQ_CAP
  * u32 each, the bit staging area, block-end tables) */
 #define NXT_ELEMS (2 * WQ_CAP + 8)
@@ -146,7 +155,7 @@ struct deflate_lds {
 	u8 in[RING + 32];
 	u16 prev[RING];
 	u16 head[1u << HASH_BITS];
-	u16 head3[1u << HASH3_BITS];	/* last position per 3-byte hash (no chain) */
+	u16 head3[(1u << HASH3_BITS) + 2];	/* last position per 3-byte hash (no chain); + a dummy slot */
 	u32 M[TILE + 8];	/* tile scratch: best length | distance << 16 per position; block end: Huffman scratch */
 	u8 done[TILE + 8];	/* search depth class a position has had: DC_* */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
@@ -1138,26 +1147,34 @@ insert_tile(lds_t *L, u32 t, u32 tend, u32 n, u32 lane)
 {
 	const u32 ngroups = (tend - t + 63) / 64;
 
+	/* Nothing in a batch is conditional: the input words of all 8 groups are
+	 * read first (any position is a valid ring address), then the 8
+	 * exchanges go out back to back (a lane without a position exchanges
+	 * nothing: mask 0), one wait, then the 8 prev[] entries - written for
+	 * every lane of the tile's groups: a slot past the buffer's end is never
+	 * read, and what it aliases in the ring lies before every window.  (With
+	 * the loads inside per-group conditionals every group waited for its own
+	 * LDS round trip: 340 cycles per group instead of 100.) */
 	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
-		u32 o[8], sh[8];
+		u32 o[8], sh[8], wv[8];
+#pragma unroll
+		for (u32 k = 0; k < 8; k++)
+			wv[k] = ld32(L->in, t + (g0 + k) * 64 + lane);
 #pragma unroll
 		for (u32 k = 0; k < 8; k++) {
 			const u32 p = t + (g0 + k) * 64 + lane;
-			const u32 h = hash4(ld32(L->in, p));
+			const u32 h = hash4(wv[k]);
 			const bool ok = g0 + k < ngroups && p + 4 <= n;
 			sh[k] = (h & 1) << 4;
-			/* a lane without a position exchanges nothing (mask 0) */
 			o[k] = lds_mskor_rtn(HEAD_OFF + ((h >> 1) << 2),
 					     ok ? 0xFFFFu << sh[k] : 0,
 					     ok ? (p & 0xFFFF) << sh[k] : 0);
-			sh[k] |= ok ? 0x100 : 0;
 		}
 		lds_wait8(o);
 #pragma unroll
 		for (u32 k = 0; k < 8; k++) {
 			const u32 i = (g0 + k) * 64 + lane;
-			if (sh[k] & 0x100)
-				L->prev[(t + i) & RMASK] = (u16)(o[k] >> (sh[k] & 31));
+			L->prev[(t + i) & RMASK] = (u16)(o[k] >> sh[k]);
 		}
 	}
 }
@@ -1167,27 +1184,28 @@ static __device__ __forceinline__ void
 insert_tile3(lds_t *L, u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lane)
 {
 	const u32 ngroups = (tend - t + 63) / 64;
+	AS3 u16 *const h3tab = (AS3 u16 *)L->head3;
 
+	/* branch-free like insert_tile(): a lane without a position reads and
+	 * rewrites a dummy slot behind the table */
 	for (u32 g0 = 0; g0 < ngroups; g0 += 8) {
-		u32 h3[8], v[8];
+		u32 wv[8], v[8];
+#pragma unroll
+		for (u32 k = 0; k < 8; k++)
+			wv[k] = ld32(L->in, t + (g0 + k) * 64 + lane);
 #pragma unroll
 		for (u32 k = 0; k < 8; k++) {
 			const u32 p = t + (g0 + k) * 64 + lane;
-			h3[k] = g0 + k < ngroups && p + 3 <= n ?
-				hash3(ld32(L->in, p)) : 0xFFFFFFFFu;
-		}
-#pragma unroll
-		for (u32 k = 0; k < 8; k++) {
-			v[k] = 0x8000;
-			if (h3[k] != 0xFFFFFFFFu) {
-				v[k] = L->head3[h3[k]];
-				L->head3[h3[k]] = (u16)(t + (g0 + k) * 64 + lane);
-			}
+			const bool ok = g0 + k < ngroups && p + 3 <= n;
+			const u32 slot = ok ? hash3(wv[k]) : (1u << HASH3_BITS);
+			/* (in program order: a later group sees this group's entries) */
+			v[k] = h3tab[slot];
+			h3tab[slot] = (u16)p;
+			v[k] = ok ? v[k] : 0x8000;
 		}
 #pragma unroll
 		for (u32 k = 0; k < 8; k++)
-			if (h3[k] != 0xFFFFFFFFu)
-				c3[4 + (g0 + k) * 64 + lane] = (u16)v[k];
+			c3[4 + (g0 + k) * 64 + lane] = (u16)v[k];
 	}
 }
 
@@ -1389,7 +1407,7 @@ stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
  * where the path leaves [0, limit).  entry >= 0.
  */
 static __device__ __forceinline__ s32
-parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out)
+parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass = 0xFFFFFFFFu)
 {
 	const s32 seg_lo = 64 * (s32)lane;
 	const s32 hi = seg_lo + 64 < limit ? seg_lo + 64 : limit;
@@ -1437,7 +1455,7 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out)
 		s32 pe = (s32)__builtin_amdgcn_update_dpp((u32)ex, (u32)ex, 0x138, 0xF, 0xF, false);
 		const s32 e = lane == 0 ? entry : pe;
 		const bool redo = e != ein;
-		if (!__ballot(redo))
+		if (!__ballot(redo) || --max_pass == 0)
 			break;
 		nm = 0;
 		if (redo) {
@@ -1598,7 +1616,7 @@ emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
  * Whole workgroup, two barriers.
  */
 static __device__ __forceinline__ u32
-build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 tid)
+build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
 
@@ -1619,10 +1637,12 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 tid)
 			spill |= 1;
 	}
 	/* ranks by a scan, not by atomics: which items fall under the cap must
-	 * not depend on timing */
+	 * not depend on timing.  The token starts come first in the list, the
+	 * look-ahead positions after them: what a limit cuts off is the
+	 * look-ahead of the tile's last positions. */
 	u32 want[TILE / NT];
-	u64 bal[TILE / NT];
-	u32 cw = 0;
+	u64 balf[TILE / NT], balh[TILE / NT];
+	u32 cwf = 0, cwh = 0;
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
@@ -1634,36 +1654,46 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 tid)
 		spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
 		want[k] = ((tmask >> lane) & 1) ? DC_FULL :
 			  ((hmask >> lane) & 1) ? DC_HALF : DC_SHALLOW;
-		const bool add = want[k] > L->done[4 + q] &&
-				 (L->M[4 + q] & 0xFFFF) < nice;
-		bal[k] = __ballot(add);
-		cw += (u32)__builtin_popcountll(bal[k]);
+		const bool add = want[k] > L->done[4 + q] && l0 < nice;
+		balf[k] = __ballot(add && want[k] == DC_FULL);
+		balh[k] = __ballot(add && want[k] != DC_FULL);
+		cwf += (u32)__builtin_popcountll(balf[k]);
+		cwh += (u32)__builtin_popcountll(balh[k]);
 	}
 	if (lane == 0)
-		L->scan[0][wave] = cw;
+		L->scan[0][wave] = cwf | (cwh << 16);
 	__syncthreads();
-	u32 base = 0, wc = 0;
+	u32 basef = 0, baseh = 0, wcf = 0, wch = 0;
 #pragma unroll
 	for (u32 w = 0; w < NWAVES; w++) {
 		const u32 c = L->scan[0][w];
-		if (w < wave)
-			base += c;
-		wc += c;
+		if (w < wave) {
+			basef += c & 0xFFFF;
+			baseh += c >> 16;
+		}
+		wcf += c & 0xFFFF;
+		wch += c >> 16;
 	}
+	baseh += wcf;
+	const u32 wc = wcf + wch;
+	const u64 ltm = (1ull << lane) - 1;
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-		const u32 j = base + (u32)__builtin_popcountll(bal[k] & ((1ull << lane) - 1));
-		if (((bal[k] >> lane) & 1) && j < WQ_CAP) {
+		const bool isf = (balf[k] >> lane) & 1, ish = (balh[k] >> lane) & 1;
+		const u32 j = isf ? basef + (u32)__builtin_popcountll(balf[k] & ltm) :
+				    baseh + (u32)__builtin_popcountll(balh[k] & ltm);
+		if ((isf || ish) && j < limit) {
 			W[j] = q | (want[k] << 12);
 			L->done[4 + q] = (u8)want[k];
 		}
-		base += (u32)__builtin_popcountll(bal[k]);
+		basef += (u32)__builtin_popcountll(balf[k]);
+		baseh += (u32)__builtin_popcountll(balh[k]);
 	}
 	if (tid == 0)
 		L->qn[0] = 0;
 	__syncthreads();
-	return wc < WQ_CAP ? wc : WQ_CAP;
+	return wc < limit ? wc : limit;
 }
 
 /*
@@ -1861,6 +1891,11 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 		PROF_COUNT(19, ncur);
 		AS3 u32 *cur_l = gen & 1 ? WB : WA, *nxt_l = gen & 1 ? WA : WB;
 		AS3 u32 *ctr = &L->qn[gen % 3];
+		/* the survivors of a generation are the deep chains: later
+		 * generations walk longer before they repack (GEN_GROW) */
+		const u32 npass_g = GEN_GROW ? npass * (gen + 1) : npass;
+		const u32 qg = 8 * npass_g;
+		const u32 before = GEN_GROW ? quantum * (gen * (gen + 1) / 2) : quantum * gen;
 		if (tid == 0)
 			L->qn[(gen + 1) % 3] = 0;
 		for (u32 base = 64 * wave; base < ncur; base += 64 * NWAVES) {
@@ -1868,8 +1903,8 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 			const u32 e = have ? cur_l[base + lane] : 0;
 			const u32 i = e & 0xFFF, p = t + i;
 			const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
-			u32 dep = quantum * gen < cdepth ? cdepth - quantum * gen : 0;
-			dep = dep < quantum ? dep : quantum;
+			u32 dep = before < cdepth ? cdepth - before : 0;
+			dep = dep < qg ? dep : qg;
 			const u32 cur = ld32(L->in, p);
 			const u64 nxt8 = ld64(L->in, p + 4);
 			const u32 maxlen = n - p < 258 ? n - p : 258;
@@ -1884,7 +1919,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 			u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
 			bool act = have && p + 4 <= n && best < nic && dep;
 			bool ended = false;
-			for (u32 ps = 0; ps < npass; ps++) {
+			for (u32 ps = 0; ps < npass_g; ps++) {
 				u32 cnt = 0;
 				u64 qh = 0;
 #pragma unroll
@@ -1926,7 +1961,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 				}
 				if (best >= nic)
 					act = false;
-				if (npass > 1) {
+				if (npass_g > 1) {
 					if (!__ballot(act && !ended && dep))
 						break;
 					boff = best - 3;
@@ -1935,7 +1970,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 			}
 			if (best > best0)
 				L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
-			const bool surv = act && !ended && quantum * (gen + 1) < cdepth;
+			const bool surv = act && !ended && before + qg < cdepth;
 			const u64 b = __ballot(surv);
 			u32 at = 0;
 			if (lane == 0 && b)
@@ -2119,6 +2154,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
 		const u32 ra_class = ra_all ? DC_FULL :
 				     ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW;
+		/* one batch of 64 per wave: the lazy levels' first generation of
+		 * round B is one round of batches (what is cut off: look-ahead
+		 * positions at the end of a tile, +0.0x % size); lazy2 has twice the
+		 * look-ahead positions and keeps them all */
+		const u32 wq_limit = mode == 1 && depth < 100 && WQ_LIMIT > 64 * NWAVES ?
+				     64 * NWAVES : WQ_LIMIT;
 		bool mx_pending = false;	/* the next tile's search results wait in MX */
 		u32 ml_cur = 3, ml_nxt = 3;	/* minimum match length of tile cur / nxt */
 		u32 carryv = 0;			/* M[TILE + tid] of the tile before (tid < 4) */
@@ -2158,7 +2199,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 
 			PROF_MARK(0);
 			if (stored_only) {
-				if (!have_cur)
+				if (!cur_real)	/* iteration 0, dictionary tiles */
 					continue;
 				walkpos = tend;
 			} else {
@@ -2209,11 +2250,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							u64 mk;
 							const u32 e = entry_skip(L, (s32)L->vars[V_ENTRY],
 										 (u32)(limit + 4), mode, nice);
-							(void)parse_tile(L, lane, (s32)e - 4, limit, &mk);
+							(void)parse_tile(L, lane, (s32)e - 4, limit, &mk, P1_PASSES);
 						}
 						__syncthreads();
 						PROF_MARK(12);
-						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice, tid);
+						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice, wq_limit, tid);
 						if (wc == 0)
 							break;
 						search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
@@ -2365,6 +2406,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				{
 					const bool do_p2 = cur_real && !optm;
 					AS3 u32 *const Mo = cur_real ? MX : (AS3 u32 *)L->M;
+					PROF_WDECL;
+					PROF_W0();
 					if (wave == NWAVES - 1) {
 						/* the chain insertion of tile it + 1: one wave's serial
 						 * instruction stream, the longest item of this phase -
@@ -2374,6 +2417,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							insert_tile(L, tnend, tnend + TILE < n ? tnend + TILE : n,
 								    n, lane);
 						__builtin_amdgcn_s_setprio(0);
+						PROF_W(24);
 					} else if (wave == NWAVES - 2) {
 						__builtin_amdgcn_s_setprio(2);
 						if (have_ins) {
@@ -2382,6 +2426,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						}
 						__builtin_amdgcn_s_setprio(0);
+						PROF_W(25);
 					} else if (wave == 0 && do_p2) {
 						/* ---- S4: the final parse of tile cur ----
 						 * step(p) is a pure function of M[p..p+2]; the chosen
@@ -2393,6 +2438,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						if (lane == 0)
 							*(volatile AS3 u32 *)&L->vars[V_PFLAG] = it;
 						__builtin_amdgcn_s_setprio(0);
+						PROF_W(26);
 					}
 					/* ---- S3 round A: tile nxt ---- */
 					if (nxt_real) {
@@ -2407,15 +2453,25 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 								ra_class, nice, dlim3, tid);
 						}
 					}
+					if (wave == 1)
+						PROF_W(27);
 					if (do_p2) {
 						/* ---- the tokens of tile cur, as soon as its parse is
 						 * through ---- */
 						while (*(volatile AS3 u32 *)&L->vars[V_PFLAG] != it)
 							__builtin_amdgcn_s_sleep(4);
 						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						if (wave == 1)
+							PROF_W(28);
 						emit_groups(L, tokg, t, lane);
+						if (wave == 1)
+							PROF_W(29);
 					}
 					__syncthreads();
+					if (wave == 1)
+						PROF_W(30);
+					if (wave == 0)
+						PROF_W(31);
 					if (optm && nxt_real) {
 						PROF_MARK(16);
 						/* length-3 matches for the positions left without a match */
@@ -2502,6 +2558,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				}
 			}
 			__syncthreads();
+			PROF_MARK(32);
 
 			/* ---- block end? ----
 			 * The reference ends a block when the kind of symbols changes

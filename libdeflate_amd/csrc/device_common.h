@@ -138,7 +138,7 @@ static __device__ __forceinline__ void wave_sync(void)
  * thread 0 of each workgroup accumulates s_memtime deltas per phase.
  */
 #ifdef LDA_PROFILE
-#define LDA_PROF_SLOTS 24
+#define LDA_PROF_SLOTS 40
 static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 /* exported reader for this translation unit's counters (reads and resets) */
 #define LDA_PROF_DEFINE_READER(name)                                          \
@@ -155,6 +155,13 @@ static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 #define PROF_MARK(slot) do { if (threadIdx.x == 0) { \
 		unsigned long long n_ = __builtin_readcyclecounter(); \
 		atomicAdd(&lda_prof[slot], n_ - prof_t_); prof_t_ = n_; } } while (0)
+/* section timers of any wave (its lane 0): PROF_W0 starts, PROF_W adds the
+ * time since the last PROF_W0 / PROF_W of this wave to a slot */
+#define PROF_WDECL unsigned long long prof_w_ = 0
+#define PROF_W0() do { prof_w_ = __builtin_readcyclecounter(); } while (0)
+#define PROF_W(slot) do { unsigned long long n_ = __builtin_readcyclecounter(); \
+		if ((threadIdx.x & 63) == 0) atomicAdd(&lda_prof[slot], n_ - prof_w_); \
+		prof_w_ = n_; } while (0)
 #ifdef LDA_PROFILE_COUNTS	/* event counters distort the phase times */
 #define PROF_COUNT(slot, v) do { unsigned long long v_ = (v); if (threadIdx.x == 0) \
 		atomicAdd(&lda_prof[slot], v_); } while (0)
@@ -183,6 +190,9 @@ static __device__ unsigned long long lda_prof[LDA_PROF_SLOTS];	/* per TU */
 #define PROF_SEC_FLUSH8(base) do { } while (0)
 #define PROF_SEC_ADD(i, v) do { } while (0)
 #define PROF_DECL
+#define PROF_WDECL
+#define PROF_W0() do { } while (0)
+#define PROF_W(slot) do { } while (0)
 #define PROF_START() do { } while (0)
 #define PROF_MARK(slot) do { } while (0)
 #define LDA_PROF_DEFINE_READER(name)

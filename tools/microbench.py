@@ -63,11 +63,14 @@ def main():
         bench_deflate(a, fmt=a.fmt, level=a.level)
 
 
-PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist", "S3 round A",
+PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist", "phase X",
                   "S4 emit", "hist", "S5 codes", "S6 tokens+save", "S6 header", "S5 rank sort", "S5 two trees",
                   "S4 parse", "mc: setup", "mc: merge", "mc: depths",
                   "#RB generations", "mc: clamp+lens", "#RB rounds", "#RB item-generations",
-                  "#w0 chain steps", "#w0 evaluate rounds", "S5 precode tree"]
+                  "#w0 chain steps", "#w0 evaluate rounds", "S5 precode tree", "S5 precode items",
+                  "X: insert (wave N-1)", "X: insert3 (wave N-2)", "X: final parse (wave 0)",
+                  "X: round A (wave 1)", "X: wait parse (wave 1)", "X: emit (wave 1)",
+                  "X: barrier (wave 1)", "X: wave 0 after parse", "split stats"]
 
 
 def read_profile(name, labels):
@@ -78,7 +81,7 @@ def read_profile(name, labels):
         fn = getattr(lib, name)
     except AttributeError:
         return
-    buf = (ctypes.c_ulonglong * 24)()
+    buf = (ctypes.c_ulonglong * 40)()
     fn(buf)
     tot = sum(buf)
     if not tot:
