@@ -157,7 +157,9 @@ struct deflate_lds {
 	u16 head[1u << HASH_BITS];
 	u16 head3[(1u << HASH3_BITS) + 2];	/* last position per 3-byte hash (no chain); + a dummy slot */
 	u32 M[TILE + 8];	/* tile scratch: best length | distance << 16 per position; block end: Huffman scratch */
-	u8 done[TILE + 8];	/* search depth class a position has had: DC_* */
+	u64 dhalf[TILE / 64];	/* search depth class a position has had (DC_*), as two */
+	u64 dfull[TILE / 64];	/* bitmaps: class >= DC_HALF, class == DC_FULL */
+	u8 seen8[256];		/* distinct bytes of a tile (minimum match length) */
 	u32 freq[320];		/* litlen 0..287, offset 288..319 */
 	union {
 		struct {	/* live only while a block is being finished */
@@ -377,6 +379,16 @@ static __device__ u32 choose_min_len(u32 used_literals, u32 depth)
 			m = cap;
 	}
 	return m;
+}
+
+/* buffers under 512 bytes: 3, as the reference; without the 3-byte table
+ * (level 1) never under 4 */
+static __device__ __forceinline__ u32
+min_len_policy(u32 distinct, u32 nbytes, u32 depth, bool use3)
+{
+	const u32 ml = nbytes < 512 ? 3 : choose_min_len(distinct, depth);
+
+	return use3 || ml > 4 ? ml : 4;
 }
 
 static __device__ u32
@@ -1265,6 +1277,35 @@ match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 	return ev ? len : 0;
 }
 
+/*
+ * Minimum match length from the distinct bytes of a tile's input
+ * (calculate_min_match_len, lib/deflate_compress.c:2329-2353, which the
+ * reference applies to the first 4096 bytes and then refreshes per block from
+ * the literals used; with blocks as long as a buffer the per-tile estimate is
+ * what follows content changes).  ONE wave: it runs beside the other waves'
+ * work, a tile ahead.  t0 is a tile start (16-byte aligned in the ring).
+ */
+static __device__ __forceinline__ u32
+wave_distinct_bytes(lds_t *L, u32 t0, u32 lim, u32 lane)
+{
+	AS3 u32 *const s32p = (AS3 u32 *)L->seen8;
+
+	s32p[lane] = 0;
+	wave_sync();
+#pragma unroll
+	for (u32 j = 0; j < TILE / 1024; j++) {
+		const u32 off = (TILE / 64) * lane + 16 * j;
+		const uint4 v = *(const AS3 uint4 *)&L->in[(t0 + off) & RMASK];
+		const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (u32 i = 0; i < 16; i++)
+			if (off + i < lim)
+				L->seen8[(w[i >> 2] >> (8 * (i & 3))) & 0xFF] = 1;
+	}
+	wave_sync();
+	return wave_sum((u32)__builtin_popcount(s32p[lane] & 0x01010101u));
+}
+
 /* stage the input bytes [loaded, want) into the ring (whole workgroup; the
  * first 32 bytes of the ring are mirrored past its end for ld32 / ld64) */
 static __device__ __forceinline__ void
@@ -1365,8 +1406,14 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		Mo[4 + i] = m;
 		/* a chain that ended inside the shallow pass has been searched in full */
 		const u32 dn = (p - c16) & 0xFFFF;
-		L->done[4 + i] = (u8)(act && dn > dprev && dn <= dmaxp && best < nic ?
-				      done_class : DC_FULL);
+		const u32 dcl = act && dn > dprev && dn <= dmaxp && best < nic ?
+				done_class : DC_FULL;
+		/* every lane stores the same words: a second `if (lane == 0)` at
+		 * the end of this loop's body gets threaded into the one at its
+		 * top by the compiler, lane 0 then runs a round ahead of the other
+		 * lanes and the wave hangs in the counter's read-first-lane */
+		L->dhalf[g] = __ballot(dcl >= DC_HALF);
+		L->dfull[g] = __ballot(dcl == DC_FULL);
 	}
 }
 
@@ -1654,7 +1701,9 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 		spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
 		want[k] = ((tmask >> lane) & 1) ? DC_FULL :
 			  ((hmask >> lane) & 1) ? DC_HALF : DC_SHALLOW;
-		const bool add = want[k] > L->done[4 + q] && l0 < nice;
+		const u64 dh = L->dhalf[g], df = L->dfull[g];
+		const u32 had = ((dh >> lane) & 1) + ((df >> lane) & 1);
+		const bool add = want[k] > had && l0 < nice;
 		balf[k] = __ballot(add && want[k] == DC_FULL);
 		balh[k] = __ballot(add && want[k] != DC_FULL);
 		cwf += (u32)__builtin_popcountll(balf[k]);
@@ -1683,9 +1732,15 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 		const bool isf = (balf[k] >> lane) & 1, ish = (balh[k] >> lane) & 1;
 		const u32 j = isf ? basef + (u32)__builtin_popcountll(balf[k] & ltm) :
 				    baseh + (u32)__builtin_popcountll(balh[k] & ltm);
-		if ((isf || ish) && j < limit) {
+		const bool take = (isf || ish) && j < limit;
+		if (take)
 			W[j] = q | (want[k] << 12);
-			L->done[4 + q] = (u8)want[k];
+		{	/* the items taken have their class from now on */
+			const u64 th = __ballot(take), tf = __ballot(take && isf);
+			if (lane == 0 && th) {
+				L->dhalf[g] |= th;
+				L->dfull[g] |= tf;
+			}
 		}
 		basef += (u32)__builtin_popcountll(balf[k]);
 		baseh += (u32)__builtin_popcountll(balh[k]);
@@ -2160,6 +2215,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		 * look-ahead positions and keeps them all */
 		const u32 wq_limit = mode == 1 && depth < 100 && WQ_LIMIT > 64 * NWAVES ?
 				     64 * NWAVES : WQ_LIMIT;
+		/* level 1: matches of 4 bytes and up like the reference's
+		 * (lib/ht_matchfinder.h:50-55: HT_MATCHFINDER_MIN_MATCH_LEN 4), so no
+		 * 3-byte table; one block per 64 KiB without split statistics
+		 * (deflate_compress_fastest(), lib/deflate_compress.c:2451-2523, ends
+		 * blocks by length only) */
+		const bool use3 = level >= 2;
 		bool mx_pending = false;	/* the next tile's search results wait in MX */
 		u32 ml_cur = 3, ml_nxt = 3;	/* minimum match length of tile cur / nxt */
 		u32 carryv = 0;			/* M[TILE + tid] of the tile before (tid < 4) */
@@ -2361,43 +2422,29 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_CTR] = 0;
 						L->vars[V_CTR2] = 0;
 					}
-					/* minimum match length from the distinct bytes of tile
-					 * nxt's input (calculate_min_match_len,
-					 * deflate_compress.c:2329-2353, which the reference applies
-					 * to the first 4096 bytes and then refreshes per block from
-					 * the literals used; with blocks as long as a buffer the
-					 * per-tile estimate is what follows content changes) */
-					if (nxt_real) {
-						AS3 u32 *seen = (AS3 u32 *)L->nxtA + 16;
-						for (u32 i = tid; i < 256; i += NT)
-							seen[i] = 0;
-						__syncthreads();
-						const u32 lim = want - tn < 4096 ? want - tn : 4096;
-						for (u32 i = tid; i < lim; i += NT)
-							seen[L->in[(tn + i) & RMASK]] = 1;
-						__syncthreads();
-						if (wave == 0) {
-							const u32 c1 = wave_sum(seen[lane] + seen[lane + 64] +
-										seen[lane + 128] + seen[lane + 192]);
-							if (lane == 0)
-								L->vars[V_MINLEN] = n - dict_len < 512 ? 3 :
-										    choose_min_len(c1, depth);
-						}
-					}
-					__syncthreads();
-					if (nxt_real)
+					/* (the minimum match length of tile nxt was estimated a
+					 * tile ahead, beside phase X) */
+					if (nxt_real && it)
 						ml_nxt = L->vars[V_MINLEN];
+					__syncthreads();
 				}
 				PROF_MARK(1);
 				if (it == 0) {
 					/* the first tile joins the chains up front */
 					if (wave == NWAVES - 1)
 						insert_tile(L, 0, tnend, n, lane);
-					if (wave == NWAVES - 2) {
+					if (wave == NWAVES - 2 && use3) {
 						insert_tile3(L, c3nxt, 0, tnend, n, lane);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					}
+					if (wave == NWAVES - 3 && nxt_real) {
+						const u32 nd = wave_distinct_bytes(L, 0, loaded < TILE ? loaded : TILE, lane);
+						if (lane == 0)
+							L->vars[V_MINLEN] = min_len_policy(nd, n - dict_len, depth, use3);
+					}
 					__syncthreads();
+					if (nxt_real)
+						ml_nxt = L->vars[V_MINLEN];
 					PROF_MARK(2);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2420,12 +2467,19 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						PROF_W(24);
 					} else if (wave == NWAVES - 2) {
 						__builtin_amdgcn_s_setprio(2);
-						if (have_ins) {
+						if (have_ins && use3) {
 							insert_tile3(L, c3ins, tnend,
 								     tnend + TILE < n ? tnend + TILE : n, n, lane);
 							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						}
 						__builtin_amdgcn_s_setprio(0);
+						/* the minimum match length of the tile after nxt */
+						if (have_ins && tnend >= dict_len) {
+							const u32 nd = wave_distinct_bytes(L, tnend,
+								loaded - tnend < TILE ? loaded - tnend : TILE, lane);
+							if (lane == 0)
+								L->vars[V_MINLEN] = min_len_policy(nd, n - dict_len, depth, use3);
+						}
 						PROF_W(25);
 					} else if (wave == 0 && do_p2) {
 						/* ---- S4: the final parse of tile cur ----
@@ -2502,7 +2556,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					carryv = L->M[TILE + tid];
 				/* block split observations (see "block end?" below), by the
 				 * last wave while the others wait at the barrier */
-				if (wave == NWAVES - 1) {
+				if (!use3) {
+					if (tid == 0)
+						L->vars[V_SPLIT] = 0;
+				} else if (wave == NWAVES - 1) {
 					/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
 					 * matches: length slots 0..5 (3..8) / 6..28 */
 					u32 onow[10];
