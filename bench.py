@@ -214,7 +214,8 @@ class Timer:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device=coll_device(dist, self.dev))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, last
@@ -224,10 +225,16 @@ class Timer:
         return float(np.mean([e[a].elapsed_time(e[b]) for e in self.ev])) / 1e3
 
 
+def coll_device(dist, dev):
+    """Where a collective's tensors live: the GPU under RCCL ("nccl"), the
+    host under gloo (the 2-ranks-on-one-GPU test of the N > 1 control flow)."""
+    return "cpu" if dist.get_backend() == "gloo" else dev
+
+
 def all_sum(torch, dist, dev, *vals):
     if not dist:
         return vals
-    t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+    t = torch.tensor(list(vals), dtype=torch.float64, device=coll_device(dist, dev))
     dist.all_reduce(t)
     return tuple(float(x) for x in t.tolist())
 
@@ -357,6 +364,8 @@ def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
     del r["tensors"]
     torch.cuda.empty_cache()
     return {"workload": workload, "scaling": scaling, "n_gpus": world,
+            "chunks_total": int(round(U / len(chunks[0]))),
+            "verdicts": {"chunks": int(r["verdict"][0]), "failed": int(r["verdict"][1])},
             "steps": steps, "ms_per_step": round(ms, 3),
             "roundtrip_MBps": round(U / (ms / 1e3) / 1e6, 1),
             "compress_MBps": round(U / tc / 1e6, 1),
@@ -430,6 +439,8 @@ def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, step
                      "chunks compressed by the reference at level 6, contiguous "
                      "shard per rank",
          "scaling": "strong", "n_gpus": world, "steps": steps,
+         "streams_total": int(round(U / CHUNK)),
+         "verdicts": {"chunks": int(verdict[0]), "failed": int(verdict[1])},
          "ms_per_step": round(ms, 3),
          "decompress_MBps": round(U / (ms / 1e3) / 1e6, 1),
          "kernel_ms": round(td * 1e3, 3),
@@ -457,6 +468,14 @@ def main():
                     help="configs[3] stream count (total over all ranks)")
     ap.add_argument("--blocks", type=int, default=1 << 20,
                     help="configs[4] 4 KiB block count (total over all ranks)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the verdict gather: nccl "
+                         "(= RCCL over xGMI, the default) or gloo (collectives on "
+                         "host tensors: lets N ranks share one GPU in the test "
+                         "of the N > 1 control flow)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses cuda:0 (with --backend gloo: the "
+                         "multi-rank path on a single-GPU box)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -466,12 +485,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.one_device:
+        assert a.backend == "gloo" or world == 1, "RCCL needs one GPU per rank"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from libdeflate_amd import api, shard
     from tests import datagen

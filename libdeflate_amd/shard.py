@@ -9,10 +9,23 @@ final gather to the root, over RCCL (torch.distributed backend "nccl") on
 GPUs, gloo in the CPU tests:
 
   gather_verdicts   fixed-size per-chunk metadata (compressed size, status)
-  gather_payload    the variable-length compressed bytes, as one padded
-                    all_gather of each rank's compacted segment
+  gather_payload    the variable-length compressed bytes: every rank sends its
+                    compacted segment to the root, point to point (grouped
+                    send / recv: xGMI is point-to-point, and only the root
+                    needs the bytes)
+
+Under gloo the collectives run on host copies of the tensors, so that the
+same control flow can be exercised by several ranks sharing one GPU.
 """
 import torch
+
+
+def _coll(t, dist):
+    """The tensor a collective works on: `t` itself under RCCL, a host copy
+    under gloo."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return t.cpu()
+    return t
 
 
 def partition(n_chunks, world, rank):
@@ -29,6 +42,7 @@ def gather_verdicts(sizes, results, dist, world):
     packed = torch.stack([sizes, results.to(torch.int64)], dim=1).contiguous()
     if dist is None or world == 1:
         return packed.shape[0], int((packed[:, 1] != 0).sum())
+    packed = _coll(packed, dist)
     rank = dist.get_rank()
     # shards may differ by one chunk: pad to the largest, first row = count
     cnt = torch.tensor([packed.shape[0]], dtype=torch.int64, device=packed.device)
@@ -62,19 +76,27 @@ def compact(payload, offsets, sizes):
 
 def gather_payload(segment, dist, world):
     """All ranks contribute one compacted uint8 segment; rank 0 gets the list
-    of segments in rank order (others get None).  Lengths travel first, the
-    bytes as one padded all_gather (xGMI is point-to-point: a single large
-    transfer per peer beats many small ones)."""
+    of segments in rank order (others get None).  The lengths are gathered
+    first; then every other rank sends its bytes to the root and the root
+    posts the matching receives (one transfer per peer, nothing travels to a
+    rank that does not need it - SURVEY.md 8(e): grouped ncclSend/ncclRecv)."""
     if dist is None or world == 1:
         return [segment]
+    segment = _coll(segment.contiguous(), dist)
+    rank = dist.get_rank()
     n = torch.tensor([segment.numel()], dtype=torch.int64, device=segment.device)
-    lens = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(lens, n)
-    maxlen = int(max(int(x.item()) for x in lens))
-    pad = torch.zeros(maxlen, dtype=torch.uint8, device=segment.device)
-    pad[:segment.numel()] = segment
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    if dist.get_rank() != 0:
+    lens = [torch.zeros_like(n) for _ in range(world)] if rank == 0 else None
+    dist.gather(n, lens, dst=0)
+    if rank != 0:
+        if segment.numel():
+            dist.send(segment, dst=0)
         return None
-    return [b[:int(l.item())] for b, l in zip(bufs, lens)]
+    out, reqs = [segment], []
+    for r in range(1, world):
+        buf = torch.empty(int(lens[r].item()), dtype=torch.uint8, device=segment.device)
+        out.append(buf)
+        if buf.numel():
+            reqs.append(dist.irecv(buf, src=r))
+    for q in reqs:
+        q.wait()
+    return out
