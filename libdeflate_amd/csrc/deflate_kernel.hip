@@ -182,6 +182,9 @@ struct deflate_lds {
 	u64 pm[TILE / 64];	/* parse: token starts of the tile, one bit per position */
 	u64 lit1[TILE / 64];	/* step of the position is 1 (a literal) */
 	u64 lit2[TILE / 64];	/* step is 2 (two literals, lazy2 deferral) */
+	u64 pmA[TILE / 64];	/* the same three for the FIRST parse of the next tile */
+	u64 lit1A[TILE / 64];	/* (the one that finds what round B searches), which */
+	u64 lit2A[TILE / 64];	/* runs beside the final parse of the current tile */
 	u32 qn[4];		/* round B: item counts of three generations in rotation */
 	u32 gbase[TILE / 64];	/* emit: first token-list index of each group of 64 positions */
 };
@@ -209,7 +212,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
 	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT,
-	V_CTR2, V_PFLAG
+	V_CTR2, V_PFLAG, V_RADONE, V_CTR3, V_STDONE
 };
 
 /* depth classes of the progressive search (done[]): what a position has been
@@ -735,12 +738,16 @@ opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo_, s32 hi_, s32 e_, u32 lan
 				mn += oc << 9;
 				best = mn < best ? mn : best;
 			}
-			{	/* ch[lane sl] = chosen length (lane select through m0: one
-				 * SGPR operand per VALU instruction); the s_nop covers the
+			{	/* ch[lane sl] = chosen length.  v_writelane_b32 takes one
+				 * SGPR, so the lane select travels in m0 - saved and put back
+				 * inside the statement (m0 is a reserved register: it may not
+				 * simply be declared clobbered); the s_nop covers the
 				 * lane-select hazard the compiler cannot see in the asm */
 				const u32 cl = best & 511;
-				asm("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0"
-				    : "+v"(ch) : "s"(cl), "s"(sl) : "m0");
+				u32 m0save;
+				asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\t"
+				    "v_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+				    : "+v"(ch), "=&s"(m0save) : "s"(cl), "s"(sl));
 			}
 			/* slide: every cost moves one lane up, c(p+2) enters at lane 0
 			 * (wave_ror:1; every lane has a source, 'old' is unused) */
@@ -1099,7 +1106,7 @@ static __device__ __forceinline__ void stg_save(lds_t *L, struct outstate *os)
  * Masked exchange of one u16 half of an LDS dword, returning the old dword
  * (ds_mskor_rtn_b32: MEM = (MEM & ~mask) | val).  Lanes of ONE instruction
  * that hit the same address are served in ascending lane order on gfx950
- * (measured: tools/hwtest_lds_order.hip, run by tests/test_abi_gpu.py), and a
+ * (measured: tools/hwtest_lds_order.hip, run by tests/test_hw_gpu.py), and a
  * wave's LDS instructions execute in issue order.  So when the lanes of a
  * wave are consecutive positions, "exchange my position into head[hash]"
  * returns to every lane what a serial insertion loop would have found there:
@@ -1278,6 +1285,83 @@ match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 }
 
 /*
+ * The same for TWO candidates of one position, the loads of each stage issued
+ * together: half the LDS round trips of two calls (the shallow search measures
+ * the two nearest chain members of every position, and a wave's time there is
+ * the sum of its dependent LDS waits).  Same results as two match_length().
+ */
+static __device__ __forceinline__ void
+match_length2(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 cur,
+	      u64 nxt8, u32 maxlen, u32 lane, u32 *len1o, u32 *len2o)
+{
+	const u32 a1 = ld32(L->in, cp1), a2 = ld32(L->in, cp2);
+	const u64 x1 = nxt8 ^ ld64(L->in, cp1 + 4), x2 = nxt8 ^ ld64(L->in, cp2 + 4);
+	u32 len1 = 4 + ((u32)__builtin_ctzll(x1 | (1ull << 63)) >> 3);
+	u32 len2 = 4 + ((u32)__builtin_ctzll(x2 | (1ull << 63)) >> 3);
+	ev1 = ev1 && a1 == cur;
+	ev2 = ev2 && a2 == cur;
+	bool m1 = ev1 && x1 == 0 && 12 < maxlen, m2 = ev2 && x2 == 0 && 12 < maxlen;
+	if (__ballot(m1 || m2)) {
+		const u64 pw = ld64(L->in, p + 12);
+		const u64 y1 = pw ^ ld64(L->in, cp1 + 12), y2 = pw ^ ld64(L->in, cp2 + 12);
+		if (m1) {
+			len1 = 12 + ((u32)__builtin_ctzll(y1 | (1ull << 63)) >> 3);
+			m1 = y1 == 0 && 20 < maxlen;
+		}
+		if (m2) {
+			len2 = 12 + ((u32)__builtin_ctzll(y2 | (1ull << 63)) >> 3);
+			m2 = y2 == 0 && 20 < maxlen;
+		}
+		if (__ballot(m1 || m2)) {
+			const u64 pz = ld64(L->in, p + 20);
+			const u64 z1 = pz ^ ld64(L->in, cp1 + 20), z2 = pz ^ ld64(L->in, cp2 + 20);
+			if (m1) {
+				len1 = 20 + ((u32)__builtin_ctzll(z1 | (1ull << 63)) >> 3);
+				m1 = z1 == 0 && 28 < maxlen;
+			}
+			if (m2) {
+				len2 = 20 + ((u32)__builtin_ctzll(z2 | (1ull << 63)) >> 3);
+				m2 = z2 == 0 && 28 < maxlen;
+			}
+		}
+	}
+#pragma unroll
+	for (u32 c = 0; c < 2; c++) {
+		const u32 cp = c ? cp2 : cp1;
+		for (u64 mm = __ballot(c ? m2 : m1); mm; mm &= mm - 1) {
+			u32 src = (u32)__builtin_ctzll(mm);
+			u32 bp = bcast_lane(p, src);
+			u32 bc = bcast_lane(cp, src);
+			u32 bmax = bcast_lane(maxlen, src);
+			u32 off = 28 + 4 * lane;
+			u32 x4 = off < bmax ?
+				(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
+			u64 ne = __ballot(x4 != 0);
+			u32 tot = bmax;	/* 28 + 256 >= 258 */
+			if (ne) {
+				u32 kk = (u32)__builtin_ctzll(ne);
+				u32 xk = bcast_lane(x4, kk);
+				u32 o = 28 + 4 * kk;
+				if (o < bmax)
+					tot = o + ((u32)__builtin_ctz(xk) >> 3);
+			}
+			if (lane == src) {
+				if (c)
+					len2 = tot;
+				else
+					len1 = tot;
+			}
+		}
+	}
+	if (len1 > maxlen)
+		len1 = maxlen;
+	if (len2 > maxlen)
+		len2 = maxlen;
+	*len1o = ev1 ? len1 : 0;
+	*len2o = ev2 ? len2 : 0;
+}
+
+/*
  * Minimum match length from the distinct bytes of a tile's input
  * (calculate_min_match_len, lib/deflate_compress.c:2329-2353, which the
  * reference applies to the first 4096 bytes and then refreshes per block from
@@ -1361,14 +1445,22 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 
 	/* groups of 64 positions are taken from a counter: the two waves that
 	 * insert the next tile meanwhile join in when they are done */
+	bool had = false;
 #pragma unroll 1
 	for (;;) {
 		u32 g = 0;
-		if (lane == 0)
+		/* (one lane-0 section per round: see the note at the end of the
+		 * body.  The group finished in the round before is counted here:
+		 * its LDS writes are complete - the fence at the end of the body) */
+		if (lane == 0) {
+			if (had)
+				atomicAdd((u32 *)&L->vars[V_RADONE], 1u);
 			g = atomicAdd((u32 *)&L->vars[V_CTR], 1u);
+		}
 		g = bcast_first(g);
 		if (g >= TILE / 64)
 			break;
+		had = true;
 		const u32 i = 64 * g + lane, p = t + i;
 		const u32 c3v = min_len <= 3 ? c3[4 + i] : 0;
 		bool act = p < tend && p + 4 <= n;
@@ -1380,6 +1472,34 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		u32 c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
 		u32 best = 3, bestd = 0, dprev = 0;
 
+		if (ra_depth == 2) {
+			/* the usual case: both chain links first, then both candidates
+			 * measured side by side (match_length2()); the same results as
+			 * two rounds of the loop below */
+			const u32 d1 = (p - c16) & 0xFFFF;
+			const bool act1 = act && d1 > 0 && d1 <= dmaxp && 3 < nic;
+			const u32 cp1 = p - d1;
+			const u32 c2 = LDS16(PREV_OFF + 2 * (cp1 & RMASK));
+			const u32 d2 = (p - c2) & 0xFFFF;
+			const bool ch2 = act1 && d2 > d1 && d2 <= dmaxp;
+			const u32 cp2 = p - d2;
+			const u32 c3n = LDS16(PREV_OFF + 2 * (cp2 & RMASK));
+			u32 len1, len2;
+			match_length2(L, act1, ch2, p, cp1, cp2, cur, nxt8, maxlen, lane,
+				      &len1, &len2);
+			if (len1 > best) {
+				best = len1;
+				bestd = d1;
+			}
+			const bool act2 = ch2 && best < nic;
+			if (act2 && len2 > best) {
+				best = len2;
+				bestd = d2;
+			}
+			act = act2;
+			c16 = c3n;
+			dprev = d2;
+		} else
 		for (u32 s = 0; s < ra_depth; s++) {
 			u32 d = (p - c16) & 0xFFFF;
 			act = act && d > dprev && d <= dmaxp && best < nic;
@@ -1414,6 +1534,7 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		 * lanes and the wave hangs in the counter's read-first-lane */
 		L->dhalf[g] = __ballot(dcl >= DC_HALF);
 		L->dfull[g] = __ballot(dcl == DC_FULL);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	}
 }
 
@@ -1442,6 +1563,46 @@ stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
 	}
 }
 
+/* the same for groups of 64 positions claimed from a counter (V_CTR3), into
+ * the bitmaps of the next tile's first parse; the groups done are counted in
+ * V_STDONE.  Ms = the tile's search results (complete: the step of a group's
+ * last positions reads the first entries of the next group). */
+static __device__ __forceinline__ void
+stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, u32 lane)
+{
+	bool had = false;
+
+#pragma unroll 1
+	for (;;) {
+		u32 g = 0;
+		if (lane == 0) {
+			if (had)
+				atomicAdd((u32 *)&L->vars[V_STDONE], 1u);
+			g = atomicAdd((u32 *)&L->vars[V_CTR3], 1u);
+		}
+		g = bcast_first(g);
+		if (g >= TILE / 64)
+			break;
+		had = true;
+		const u32 q = 64 * g + lane, idx = q + 4;
+		u32 st = 1;
+		if ((s32)q < limit)
+			st = token_step(Ms[idx], Ms[idx + 1], Ms[idx + 2], mode, nice);
+		/* (every lane stores the same words: no second lane-0 section) */
+		L->lit1A[g] = __ballot(st == 1);
+		L->lit2A[g] = __ballot(st == 2);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	}
+}
+
+/* wait until an LDS word written by other waves reaches a value */
+static __device__ __forceinline__ void wait_lds_eq(lds_t *L, u32 idx, u32 val)
+{
+	while (*(volatile AS3 u32 *)&L->vars[idx] != val)
+		__builtin_amdgcn_s_sleep(2);
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 /*
  * Part 2, one wave: lane l walks the positions [64 l, 64 l + 64) by
  * p -> p + step(p) (a run of literals in one go, through the bitmap), first
@@ -1454,12 +1615,13 @@ stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
  * where the path leaves [0, limit).  entry >= 0.
  */
 static __device__ __forceinline__ s32
-parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass = 0xFFFFFFFFu)
+parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u64 *pmp,
+	   u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass = 0xFFFFFFFFu)
 {
 	const s32 seg_lo = 64 * (s32)lane;
 	const s32 hi = seg_lo + 64 < limit ? seg_lo + 64 : limit;
-	const u64 lit = lane < TILE / 64 ? L->lit1[lane] : 0;
-	const u64 two = lane < TILE / 64 ? L->lit2[lane] : 0;
+	const u64 lit = lane < TILE / 64 ? lit1p[lane] : 0;
+	const u64 two = lane < TILE / 64 ? lit2p[lane] : 0;
 	s32 ein = lane == 0 ? entry : seg_lo;
 	s32 q = ein, ex = ein;
 	u64 mask = 0, nm = 0;
@@ -1481,7 +1643,7 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass
 				if (q < hi) {
 					const u32 r2 = (u32)(q - seg_lo);
 					add |= 1ull << r2;
-					q += (two >> r2) & 1 ? 2 : (s32)(L->M[4 + q] & 0xFFFF);
+					q += (two >> r2) & 1 ? 2 : (s32)(Ms[4 + q] & 0xFFFF);
 				}
 				const u64 hit = add & mask;
 				if (hit) {	/* met my earlier path */
@@ -1517,7 +1679,7 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass
 		}
 	}
 	if (lane < TILE / 64)
-		L->pm[lane] = mask;
+		pmp[lane] = mask;
 	*mask_out = mask;
 	return (s32)__builtin_amdgcn_readlane((int)ex, 63);
 }
@@ -1525,13 +1687,13 @@ parse_tile(lds_t *L, u32 lane, s32 entry, s32 limit, u64 *mask_out, u32 max_pass
 /* the carried-in idx 2, 3 (the last two positions of the tile before, which
  * its parse deferred) can only be the entry itself */
 static __device__ __forceinline__ u32
-entry_skip(const lds_t *L, s32 entry, u32 lim_idx, u32 mode, u32 nice)
+entry_skip(const AS3 u32 *Ms, s32 entry, u32 lim_idx, u32 mode, u32 nice)
 {
 	u32 e = (u32)(entry + 4);
 
 	for (u32 pre = 0; pre < 2; pre++)
 		if (e < 4 && e < lim_idx)
-			e += token_step(L->M[e], L->M[e + 1], L->M[e + 2], mode, nice);
+			e += token_step(Ms[e], Ms[e + 1], Ms[e + 2], mode, nice);
 	return e;
 }
 
@@ -1584,7 +1746,9 @@ parse_and_base(lds_t *L, u32 *__restrict__ tokg, u32 t, s32 limit, u32 mode,
 		}
 	}
 	u64 mask;
-	const s32 px = parse_tile(L, lane, (s32)e - 4, limit, &mask);
+	const s32 px = parse_tile((const AS3 u32 *)L->M, (const AS3 u64 *)L->lit1,
+				  (const AS3 u64 *)L->lit2, (AS3 u64 *)L->pm, lane,
+				  (s32)e - 4, limit, &mask);
 	const u64 two = mask & L->lit2[lane];
 	const u32 cnt = (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(two);
 	const u32 incl = wave_scan_incl(cnt);
@@ -1676,7 +1840,7 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 	u64 spill = 0;
 	if (mode >= 1 && S3_HALF && wave) {
 		const u32 g0 = wave * (TILE / NT), q1 = 64 * g0 - 1;
-		const u64 pmask = L->pm[g0 - 1];
+		const u64 pmask = L->pmA[g0 - 1];
 		const u32 l1 = L->M[4 + q1] & 0xFFFF, l2 = L->M[4 + q1 - 1] & 0xFFFF;
 		if ((pmask >> 63) && l1 >= 3 && l1 < nice)
 			spill = mode >= 2 ? 3 : 1;
@@ -1693,7 +1857,7 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-		const u64 tmask = L->pm[g];
+		const u64 tmask = L->pmA[g];
 		const u32 l0 = L->M[4 + q] & 0xFFFF;
 		const u64 b = mode >= 1 && S3_HALF ?
 			__ballot(((tmask >> lane) & 1) && l0 >= 3 && l0 < nice) : 0;
@@ -2301,25 +2465,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					PROF_MARK(6);
 				}
 				if (cur_real && !optm) {
-					/* ---- S3 round B: a parse over the results so far, then
-					 * the positions it visits are searched deeper
-					 * ("progressive search") ---- */
-					for (u32 r = 0; r < rounds; r++) {
-						stage_steps(L, limit, mode, nice, tid);
-						__syncthreads();
-						if (wave == 0) {
-							u64 mk;
-							const u32 e = entry_skip(L, (s32)L->vars[V_ENTRY],
-										 (u32)(limit + 4), mode, nice);
-							(void)parse_tile(L, lane, (s32)e - 4, limit, &mk, P1_PASSES);
-						}
-						__syncthreads();
-						PROF_MARK(12);
-						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice, wq_limit, tid);
-						if (wc == 0)
-							break;
-						search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
-							     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
+					/* ---- S3 round B: the positions the first parse visited
+					 * (pmA: it ran beside phase X of the iteration before) are
+					 * searched deeper ("progressive search") ---- */
+					if (rounds) {
+						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice,
+									      wq_limit, tid);
+						if (wc)
+							search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
+								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
 						PROF_MARK(3);
 					}
 					/* steps of the final parse (it runs in phase X) */
@@ -2421,6 +2575,17 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					if (tid == 0) {
 						L->vars[V_CTR] = 0;
 						L->vars[V_CTR2] = 0;
+						L->vars[V_CTR3] = 0;
+						L->vars[V_RADONE] = 0;
+						L->vars[V_STDONE] = 0;
+					}
+					/* what the first parse of tile nxt reads around its search
+					 * results: the entries its predecessor's walk deferred, and
+					 * no matches past the end */
+					if (tid < 4 && nxt_real) {
+						AS3 u32 *const Mo = cur_real ? MX : (AS3 u32 *)L->M;
+						Mo[tid] = cur_real ? L->M[TILE + tid] : 0;
+						Mo[TILE + 4 + tid] = 0;
 					}
 					/* (the minimum match length of tile nxt was estimated a
 					 * tile ahead, beside phase X) */
@@ -2509,6 +2674,28 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					}
 					if (wave == 1)
 						PROF_W(27);
+					if (nxt_real && rounds) {
+						/* ---- the first parse of tile nxt: steps by all waves as
+						 * soon as every group of round A is through, the walk by
+						 * wave 0 (its entry point is where the final parse of
+						 * tile cur, which it ran itself, left) ---- */
+						const s32 lim_n = it + 1 == num_tiles ? (s32)(tnend - tn) : (s32)TILE - 2;
+						wait_lds_eq(L, V_RADONE, TILE / 64);
+						stage_steps_claimed(L, Mo, lim_n, mode, nice, lane);
+						if (wave == 0) {
+							u64 mk;
+							wait_lds_eq(L, V_STDONE, TILE / 64);
+							const u32 e = entry_skip(Mo, (s32)L->vars[V_ENTRY],
+										 (u32)(lim_n + 4), mode, nice);
+							(void)parse_tile(Mo, (const AS3 u64 *)L->lit1A,
+									 (const AS3 u64 *)L->lit2A, (AS3 u64 *)L->pmA,
+									 lane, (s32)e - 4, lim_n, &mk, P1_PASSES);
+						}
+						if (wave == 1)
+							PROF_W(33);
+						if (wave == 0)
+							PROF_W(34);
+					}
 					if (do_p2) {
 						/* ---- the tokens of tile cur, as soon as its parse is
 						 * through ---- */

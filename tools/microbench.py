@@ -70,7 +70,8 @@ PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist",
                   "#w0 chain steps", "#w0 evaluate rounds", "S5 precode tree", "S5 precode items",
                   "X: insert (wave N-1)", "X: insert3 (wave N-2)", "X: final parse (wave 0)",
                   "X: round A (wave 1)", "X: wait parse (wave 1)", "X: emit (wave 1)",
-                  "X: barrier (wave 1)", "X: wave 0 after parse", "split stats"]
+                  "X: barrier (wave 1)", "X: wave 0 after parse", "split stats",
+                  "X: steps of first parse (wave 1)", "X: wave 0 until first parse done"]
 
 
 def read_profile(name, labels):
