@@ -296,42 +296,104 @@ def roundtrip_config(torch, dist, world, rank, dev, stream, api, shard, chunks,
     return r
 
 
-def end_to_end(torch, dev, stream, api, tensors):
-    """The headline batch from pinned host memory and back: H2D of the input,
-    compress, device-side compaction, D2H of the compressed bytes; H2D of the
-    compressed bytes, decompress, D2H of the output (SURVEY.md 8(d) "(ii)
-    end-to-end"; the reference times from host buffers,
-    programs/test_util.c:143-164)."""
+def end_to_end(torch, dev, stream, api, tensors, slices=8):
+    """The headline batch from pinned host memory and back, PCIe overlapped
+    with compute (SURVEY.md 8(d) "(ii) end-to-end"; the reference times from
+    host buffers, programs/test_util.c:143-164).  The batch is cut into
+    `slices`: H2D of slice k + 1 (copy stream) runs beside the kernels and the
+    device-side compaction of slice k (compute stream) and the D2H of slice
+    k - 1 (second copy stream).  The host never waits in the middle of the
+    pipeline for something that is not already done: the D2H of a slice is
+    sized by its compacted total, read back by an async copy whose event has
+    long fired when the host looks at it (the next slice is already
+    enqueued).  Decompress direction alike: H2D of the compressed bytes of
+    slice k + 1, inflate of slice k, D2H of the output of slice k - 1 - with
+    one decompressor object and stream per slice, because a slice of streams
+    is latency-bound (one wave per stream) and the slices run side by side."""
     data, in_off, in_n, comp, c_off, c_av, c_n, out, res, comp_c, dec = tensors
     n = in_off.numel()
+    size = data.numel() // n
+    bound = comp.numel() // n
+    while n % slices:
+        slices //= 2
+    m = n // slices
     h_in = torch.empty(data.numel(), dtype=torch.uint8).pin_memory()
     h_in.copy_(data)
     h_comp = torch.empty(comp.numel(), dtype=torch.uint8).pin_memory()
-    h_off = torch.empty(n + 1, dtype=torch.int64).pin_memory()
+    h_sizes = torch.empty(n, dtype=torch.int64).pin_memory()
+    h_tot = torch.zeros(slices, dtype=torch.int64).pin_memory()
     h_out = torch.empty(out.numel(), dtype=torch.uint8).pin_memory()
     d_packed = torch.empty(comp.numel(), dtype=torch.uint8, device=dev)
-    d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    d_off = torch.empty(n, dtype=torch.int64, device=dev)
+    d_sz = torch.empty(n, dtype=torch.int64, device=dev)
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_dec = [torch.cuda.Stream(device=dev) for _ in range(slices)]
+    decs = [dec] + [api.Decompressor() for _ in range(slices - 1)]
+    rel_off = torch.arange(m, dtype=torch.int64, device=dev) * bound
     best_c = best_d = None
     total = 0
     for it in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        data.copy_(h_in, non_blocking=True)
-        comp_c.compress_batch(FMT, data, in_off, in_n, comp, c_off, c_av, c_n,
-                              stream=stream)
-        packed, poff = api.compact_batch(comp, c_off, c_n, stream=stream)
-        h_off.copy_(poff, non_blocking=True)
-        torch.cuda.synchronize()        # the host needs the total to size its copy
-        total = int(h_off[n])
-        h_comp[:total].copy_(packed[:total], non_blocking=True)
+        # ---- compress: host -> device -> host ----
+        ev_in = [torch.cuda.Event() for _ in range(slices)]
+        ev_k = [torch.cuda.Event() for _ in range(slices)]
+        keep = []
+        with torch.cuda.stream(s_in):
+            for k in range(slices):
+                data[k * m * size:(k + 1) * m * size].copy_(
+                    h_in[k * m * size:(k + 1) * m * size], non_blocking=True)
+                ev_in[k].record(s_in)
+        at = 0
+
+        def drain(j, at):
+            ev_k[j].synchronize()               # fired long ago, except for the last slice
+            tot = int(h_tot[j])
+            with torch.cuda.stream(s_out):
+                h_comp[at:at + tot].copy_(keep[j][0][:tot], non_blocking=True)
+            return at + tot
+
+        for k in range(slices):
+            stream.wait_event(ev_in[k])
+            sl = slice(k * m, (k + 1) * m)
+            comp_c.compress_batch(FMT, data, in_off[sl], in_n[sl], comp, c_off[sl],
+                                  c_av[sl], c_n[sl], stream=stream, max_chunk=size)
+            packed, poff = api.compact_batch(comp[k * m * bound:(k + 1) * m * bound],
+                                             rel_off, c_n[sl], stream=stream)
+            keep.append((packed, poff))
+            h_tot[k:k + 1].copy_(poff[m:m + 1], non_blocking=True)
+            h_sizes[sl].copy_(c_n[sl], non_blocking=True)
+            ev_k[k].record(stream)
+            s_out.wait_event(ev_k[k])
+            if k:
+                at = drain(k - 1, at)
+        at = drain(slices - 1, at)
         torch.cuda.synchronize()
+        total = at
         t1 = time.perf_counter()
-        d_packed[:total].copy_(h_comp[:total], non_blocking=True)
-        d_off.copy_(h_off, non_blocking=True)
-        sizes = d_off[1:] - d_off[:-1]
-        dec.decompress_batch(FMT, d_packed, d_off[:n].contiguous(), sizes, out, in_off,
-                             in_n, res, stream=stream)
-        h_out.copy_(out, non_blocking=True)
+        # ---- decompress: host -> device -> host ----
+        h_offs = torch.cumsum(h_sizes, 0) - h_sizes        # host-side index of the packed bytes
+        ev_in = [torch.cuda.Event() for _ in range(slices)]
+        ev_k = [torch.cuda.Event() for _ in range(slices)]
+        with torch.cuda.stream(s_in):
+            d_off.copy_(h_offs.pin_memory(), non_blocking=True)
+            d_sz.copy_(h_sizes, non_blocking=True)
+            for k in range(slices):
+                lo = int(h_offs[k * m])
+                hi = int(h_offs[(k + 1) * m]) if k + 1 < slices else total
+                d_packed[lo:hi].copy_(h_comp[lo:hi], non_blocking=True)
+                ev_in[k].record(s_in)
+        for k in range(slices):
+            # a slice of streams is latency-bound (one wave per stream), so the
+            # slices run side by side: one decompressor object + stream each
+            sk = s_dec[k]
+            sk.wait_event(ev_in[k])
+            sl = slice(k * m, (k + 1) * m)
+            decs[k].decompress_batch(FMT, d_packed, d_off[sl], d_sz[sl], out, in_off[sl],
+                                     in_n[sl], res[sl], stream=sk)
+            with torch.cuda.stream(sk):
+                h_out[k * m * size:(k + 1) * m * size].copy_(
+                    out[k * m * size:(k + 1) * m * size], non_blocking=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if it:
@@ -342,10 +404,11 @@ def end_to_end(torch, dev, stream, api, tensors):
     return {"compress_MBps": round(U / best_c / 1e6, 1),
             "decompress_MBps": round(U / best_d / 1e6, 1),
             "roundtrip_MBps": round(U / (best_c + best_d) / 1e6, 1),
-            "compressed_bytes": total,
-            "note": "pinned host -> HBM -> pinned host: H2D U + compress + device "
-                    "compaction + D2H C; H2D C + decompress + D2H U; best of 2 "
-                    "after a warm-up; one GPU"}
+            "compressed_bytes": total, "slices": slices,
+            "note": "pinned host -> HBM -> pinned host, the batch in slices: H2D of "
+                    "slice k + 1 beside the kernels (+ device compaction) of slice k "
+                    "beside the D2H of slice k - 1, three streams, no host wait inside "
+                    "the pipeline; best of 2 after a warm-up; one GPU"}
 
 
 def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
