@@ -285,6 +285,20 @@ static __device__ u32
 find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 	  u32 dlim, u32 *best);
 
+/* bit `lane` of a wave-uniform 64-bit mask: the mask IS a lane predicate, one
+ * v_cndmask instead of a 64-bit shift per lane */
+static __device__ __forceinline__ bool lane_bit(u64 uniform_mask)
+{
+	return __builtin_amdgcn_inverse_ballot_w64(uniform_mask);
+}
+
+/* number of set bits of a wave-uniform mask below this lane */
+static __device__ __forceinline__ u32 rank_below(u64 uniform_mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((u32)(uniform_mask >> 32),
+					 __builtin_amdgcn_mbcnt_lo((u32)uniform_mask, 0));
+}
+
 /* workgroup exclusive scan of one value per thread; returns the exclusive
  * prefix and writes the total to *total.  Two barriers. */
 static __device__ u32 block_scan(lds_t *L, u32 v, u32 *total)
@@ -1847,67 +1861,62 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 		if (mode >= 2 && ((pmask >> 62) & 1) && l2 >= 3 && l2 < nice)
 			spill |= 1;
 	}
-	/* ranks by a scan, not by atomics: which items fall under the cap must
-	 * not depend on timing.  The token starts come first in the list, the
-	 * look-ahead positions after them: what a limit cuts off is the
-	 * look-ahead of the tile's last positions. */
-	u32 want[TILE / NT];
-	u64 balf[TILE / NT], balh[TILE / NT];
-	u32 cwf = 0, cwh = 0;
+	/* ranks by a scan, not by atomics: which items fall under the limit must
+	 * not depend on timing.  (One round B per tile - S3_ROUNDS is 1 - so the
+	 * classes of the items taken need not be recorded: the next shallow
+	 * search rewrites dhalf[] / dfull[].)  The phase is instruction bound -
+	 * 16 waves, ~100 instructions per group of 64 positions - so the masks
+	 * stay wave-uniform words and every per-lane test is one v_cndmask. */
+	static_assert(S3_ROUNDS <= 1, "build_worklist() does not record the classes it hands out");
+	u32 item[TILE / NT];
+	u64 bal[TILE / NT];
+	u64 tm_[TILE / NT], dh_[TILE / NT], df_[TILE / NT];
+	u32 l0_[TILE / NT];
+	u32 cw = 0;
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-		const u64 tmask = L->pmA[g];
-		const u32 l0 = L->M[4 + q] & 0xFFFF;
+		tm_[k] = L->pmA[g];
+		dh_[k] = L->dhalf[g];
+		df_[k] = L->dfull[g];
+		l0_[k] = L->M[4 + q] & 0xFFFF;
+	}
+#pragma unroll
+	for (u32 k = 0; k < TILE / NT; k++) {
+		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
+		const u64 tmask = bcast64(tm_[k]);
+		const bool below = l0_[k] < nice;
 		const u64 b = mode >= 1 && S3_HALF ?
-			__ballot(((tmask >> lane) & 1) && l0 >= 3 && l0 < nice) : 0;
+			__ballot(lane_bit(tmask) && l0_[k] >= 3 && below) : 0;
 		const u64 hmask = (b << 1) | (mode >= 2 ? b << 2 : 0) | spill;
 		spill = (b >> 63) | (mode >= 2 ? b >> 62 : 0);
-		want[k] = ((tmask >> lane) & 1) ? DC_FULL :
-			  ((hmask >> lane) & 1) ? DC_HALF : DC_SHALLOW;
-		const u64 dh = L->dhalf[g], df = L->dfull[g];
-		const u32 had = ((dh >> lane) & 1) + ((df >> lane) & 1);
-		const bool add = want[k] > had && l0 < nice;
-		balf[k] = __ballot(add && want[k] == DC_FULL);
-		balh[k] = __ballot(add && want[k] != DC_FULL);
-		cwf += (u32)__builtin_popcountll(balf[k]);
-		cwh += (u32)__builtin_popcountll(balh[k]);
+		/* wanted: full depth where a token starts and the position has not
+		 * had it; half depth where the lazy rule looked and the position
+		 * has had only the shallow pass */
+		const u64 wantf = tmask & ~bcast64(df_[k]);
+		const u64 wanth = hmask & ~tmask & ~bcast64(dh_[k]);
+		const bool isf = lane_bit(wantf);
+		bal[k] = __ballot((isf || lane_bit(wanth)) && below);
+		item[k] = q | ((isf ? DC_FULL : DC_HALF) << 12);
+		cw += (u32)__builtin_popcountll(bal[k]);
 	}
 	if (lane == 0)
-		L->scan[0][wave] = cwf | (cwh << 16);
+		L->scan[0][wave] = cw;
 	__syncthreads();
-	u32 basef = 0, baseh = 0, wcf = 0, wch = 0;
+	u32 base = 0, wc = 0;
 #pragma unroll
 	for (u32 w = 0; w < NWAVES; w++) {
 		const u32 c = L->scan[0][w];
-		if (w < wave) {
-			basef += c & 0xFFFF;
-			baseh += c >> 16;
-		}
-		wcf += c & 0xFFFF;
-		wch += c >> 16;
+		if (w < wave)
+			base += c;
+		wc += c;
 	}
-	baseh += wcf;
-	const u32 wc = wcf + wch;
-	const u64 ltm = (1ull << lane) - 1;
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
-		const u32 g = wave * (TILE / NT) + k, q = 64 * g + lane;
-		const bool isf = (balf[k] >> lane) & 1, ish = (balh[k] >> lane) & 1;
-		const u32 j = isf ? basef + (u32)__builtin_popcountll(balf[k] & ltm) :
-				    baseh + (u32)__builtin_popcountll(balh[k] & ltm);
-		const bool take = (isf || ish) && j < limit;
-		if (take)
-			W[j] = q | (want[k] << 12);
-		{	/* the items taken have their class from now on */
-			const u64 th = __ballot(take), tf = __ballot(take && isf);
-			if (lane == 0 && th) {
-				L->dhalf[g] |= th;
-				L->dfull[g] |= tf;
-			}
-		}
-		basef += (u32)__builtin_popcountll(balf[k]);
-		baseh += (u32)__builtin_popcountll(balh[k]);
+		const u32 j = base + rank_below(bal[k]);
+		if (lane_bit(bal[k]) && j < limit)
+			W[j] = item[k];
+		base += (u32)__builtin_popcountll(bal[k]);
 	}
 	if (tid == 0)
 		L->qn[0] = 0;
@@ -2091,6 +2100,12 @@ search_items(lds_t *L, AS3 u32 *Mo, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 d
  * cannot beat it; M[] is rewritten only when a longer match turns up.
  * Whole workgroup; ends with a barrier.
  */
+#ifdef LDA_PROFILE
+#define PROF_GEN(g) do { if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); \
+	atomicAdd(&lda_prof[35 + ((g) < 3 ? (g) : 3)], n_ - pg_); pg_ = n_; } } while (0)
+#else
+#define PROF_GEN(g) do { } while (0)
+#endif
 static __device__ __forceinline__ void
 search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid)
@@ -2101,6 +2116,9 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	const u32 quantum = 8 * npass;
 	const u64 lt = (1ull << lane) - 1;
 	u32 ncur = wc;
+#ifdef LDA_PROFILE
+	unsigned long long pg_ = __builtin_readcyclecounter();
+#endif
 
 	PROF_COUNT(15, wc);
 	PROF_COUNT(18, 1);
@@ -2200,6 +2218,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 					(e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);
 		}
 		__syncthreads();
+		PROF_GEN(gen);
 		ncur = *(volatile AS3 u32 *)ctr;
 		if (!ncur)
 			break;
@@ -2471,6 +2490,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					if (rounds) {
 						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice,
 									      wq_limit, tid);
+						PROF_MARK(39);
 						if (wc)
 							search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
 								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);

@@ -71,7 +71,8 @@ PHASES_DEFLATE = ["init/other", "S0 load", "S2 insert", "S3 round B + worklist",
                   "X: insert (wave N-1)", "X: insert3 (wave N-2)", "X: final parse (wave 0)",
                   "X: round A (wave 1)", "X: wait parse (wave 1)", "X: emit (wave 1)",
                   "X: barrier (wave 1)", "X: wave 0 after parse", "split stats",
-                  "X: steps of first parse (wave 1)", "X: wave 0 until first parse done"]
+                  "X: steps of first parse (wave 1)", "X: wave 0 until first parse done",
+                  "RB: generation 0", "RB: generation 1", "RB: generation 2", "RB: generations 3+", "worklist"]
 
 
 def read_profile(name, labels):
