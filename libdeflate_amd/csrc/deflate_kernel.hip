@@ -212,7 +212,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
 	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT,
-	V_CTR2, V_PFLAG, V_RADONE, V_CTR3, V_STDONE
+	V_CTR2, V_PFLAG, V_RADONE, V_CTR3, V_STDONE, V_EMDONE
 };
 
 /* depth classes of the progressive search (done[]): what a position has been
@@ -1786,15 +1786,24 @@ static __device__ __forceinline__ void
 emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
 {
 	const u64 lt = (1ull << lane) - 1;
+	bool had = false;
 
 #pragma unroll 1
 	for (;;) {
 		u32 g = 0;
-		if (lane == 0)
+		/* (the group finished in the round before is counted here, in the
+		 * loop's one lane-0 section: see round_a(); its histogram atomics
+		 * are LDS operations of this wave and complete after the wait) */
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		if (lane == 0) {
+			if (had)
+				atomicAdd((u32 *)&L->vars[V_EMDONE], 1u);
 			g = atomicAdd((u32 *)&L->vars[V_CTR2], 1u);
+		}
 		g = bcast_first(g);
 		if (g >= TILE / 64)
 			break;
+		had = true;
 		const u64 pmk = L->pm[g];
 		if (!pmk)
 			continue;
@@ -2225,6 +2234,65 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	}
 }
 
+/*
+ * Block split observations of the tile just emitted (ONE wave; see "block
+ * end?" in the schedule): the reference ends a block when the kind of symbols
+ * changes (lib/deflate_compress.c:2092-2218) - ten observation classes
+ * (literals by their top two bits and low bit, matches shorter / not shorter
+ * than 9) and a split when the distribution of the new observations is far
+ * from the block's.  Here the classes are sums over the block histogram and
+ * "new" is what this tile added.  Leaves V_SPLIT: 0 no split, 2 the part
+ * before this tile is a block of its own, 1 the block ends after the tile.
+ */
+static __device__ __forceinline__ void
+split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
+{
+	/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
+	 * matches: length slots 0..5 (3..8) / 6..28 */
+	u32 onow[10], oprev[10];
+#pragma unroll
+	for (u32 j = 0; j < 4; j++) {
+		u32 f = L->freq[lane + 64 * j];
+		onow[2 * j] = wave_sum(lane & 1 ? 0 : f);
+		onow[2 * j + 1] = wave_sum(lane & 1 ? f : 0);
+	}
+	{
+		u32 f = lane < 29 ? L->freq[257 + lane] : 0;
+		onow[8] = wave_sum(lane < 6 ? f : 0);
+		onow[9] = wave_sum(lane < 6 ? 0 : f);
+	}
+	u32 nprev = 0, nnew = 0;
+	u64 delta = 0;
+#pragma unroll
+	for (u32 i = 0; i < 10; i++) {
+		oprev[i] = bcast_first(L->obs[0][i]);	/* wave-uniform: scalar arithmetic */
+		nprev += oprev[i];
+		nnew += onow[i] - oprev[i];
+	}
+#pragma unroll
+	for (u32 i = 0; i < 10; i++) {
+		u64 a = (u64)(onow[i] - oprev[i]) * nprev;
+		u64 e = (u64)oprev[i] * nnew;
+		delta += a > e ? a - e : e - a;
+	}
+	/* cutoff 200/512 of the mass as :2179-2193; blocks below
+	 * the minimum length of :2204 are never cut */
+	bool sp = nprev && walkpos - block_start >= 5000 &&
+		  delta >= (u64)nnew * 200 / 512 * nprev;
+	if (fit_split && walkpos - block_start >= 5000)
+		sp = true;	/* see opt_build_costs() */
+	wave_sync();
+#pragma unroll
+	for (u32 i = 0; i < 10; i++)
+		if (lane == i)
+			L->obs[0][i] = sp ? 0 : onow[i];
+	/* 2: the part before this tile is a block of its own
+	 * (>= the minimum block length of :2204) */
+	if (lane == 0)
+		L->vars[V_SPLIT] = !sp ? 0 :
+			L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
+}
+
 #ifdef LDA_DEBUG_SPLIT	/* per-tile trace of the block-split inputs of buffer 0 (debug builds) */
 static __device__ u32 lda_dbg[2048];
 extern "C" __attribute__((visibility("default"))) void libdeflate_amd_debug_read(u32 *out)
@@ -2598,6 +2666,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_CTR3] = 0;
 						L->vars[V_RADONE] = 0;
 						L->vars[V_STDONE] = 0;
+						L->vars[V_EMDONE] = 0;
 					}
 					/* what the first parse of tile nxt reads around its search
 					 * results: the entries its predecessor's walk deferred, and
@@ -2727,6 +2796,13 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						emit_groups(L, tokg, t, lane);
 						if (wave == 1)
 							PROF_W(29);
+						/* block split observations of tile cur, by the last wave
+						 * once every group is emitted (wave 0 is still walking
+						 * the next tile's first parse) */
+						if (wave == NWAVES - 1 && use3) {
+							wait_lds_eq(L, V_EMDONE, TILE / 64);
+							split_stats(L, L->vars[V_WALKPOS_LO], block_start, false, lane);
+						}
 					}
 					__syncthreads();
 					if (wave == 1)
@@ -2766,59 +2842,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (!use3) {
 					if (tid == 0)
 						L->vars[V_SPLIT] = 0;
-				} else if (wave == NWAVES - 1) {
-					/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
-					 * matches: length slots 0..5 (3..8) / 6..28 */
-					u32 onow[10];
-#pragma unroll
-					for (u32 j = 0; j < 4; j++) {
-						u32 f = L->freq[lane + 64 * j];
-						onow[2 * j] = wave_sum(lane & 1 ? 0 : f);
-						onow[2 * j + 1] = wave_sum(lane & 1 ? f : 0);
-					}
-					{
-						u32 f = lane < 29 ? L->freq[257 + lane] : 0;
-						onow[8] = wave_sum(lane < 6 ? f : 0);
-						onow[9] = wave_sum(lane < 6 ? 0 : f);
-					}
-					u32 nprev = 0, nnew = 0;
-					u64 delta = 0;
-#pragma unroll
-					for (u32 i = 0; i < 10; i++) {
-						nprev += L->obs[0][i];
-						nnew += onow[i] - L->obs[0][i];
-					}
-#pragma unroll
-					for (u32 i = 0; i < 10; i++) {
-						u64 a = (u64)(onow[i] - L->obs[0][i]) * nprev;
-						u64 e = (u64)L->obs[0][i] * nnew;
-						delta += a > e ? a - e : e - a;
-					}
-					/* cutoff 200/512 of the mass as :2179-2193; blocks below
-					 * the minimum length of :2204 are never cut */
-					bool sp = nprev && walkpos - block_start >= 5000 &&
-						  delta >= (u64)nnew * 200 / 512 * nprev;
-					if (OPT && mode == 3 && L->vars[V_FIT] == 2 &&
-					    walkpos - block_start >= 5000)
-						sp = true;	/* see opt_build_costs() */
-					wave_sync();
-#pragma unroll
-					for (u32 i = 0; i < 10; i++)
-						if (lane == i)
-							L->obs[0][i] = sp ? 0 : onow[i];
-					/* 2: the part before this tile is a block of its own
-					 * (>= the minimum block length of :2204) */
-					if (lane == 0)
-						L->vars[V_SPLIT] = !sp ? 0 :
-							L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
-					if (lane == 0 && c == 0) {
-						DBG(tile, 0, nprev);
-						DBG(tile, 1, nnew);
-						DBG(tile, 2, (u32)(delta / (nprev ? nprev : 1)));
-						DBG(tile, 3, sp);
-						DBG(tile, 4, walkpos - block_start);
-						DBG(tile, 5, onow[8] + onow[9]);
-					}
+				} else if (wave == NWAVES - 1 && optm) {
+					/* (levels 0-9: done in phase X, beside the first parse of
+					 * the next tile) */
+					split_stats(L, walkpos, block_start, L->vars[V_FIT] == 2, lane);
 				}
 			}
 			__syncthreads();
