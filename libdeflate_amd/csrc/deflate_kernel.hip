@@ -3252,11 +3252,16 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				 * at most 48 bits: 6 KiB per window in the worst case, a
 				 * fifth of that on text). */
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				/* (the next window's token is requested before this one is
+				 * encoded: the list is in HBM) */
+				u32 tok_nxt = tid < nseq ? tokg[tid] : 0;
 				for (u32 b0 = 0; b0 < nseq; b0 += NT) {
 					u64 code = 0;
 					u32 nb = 0;
+					const u32 tok = tok_nxt;
+					if (b0 + NT + tid < nseq)
+						tok_nxt = tokg[b0 + NT + tid];
 					if (b0 + tid < nseq) {
-						const u32 tok = tokg[b0 + tid];
 						if (tok & TOK_MATCH) {
 							const u32 len = (tok & 0xFF) + 3, dist = ((tok >> 8) & 0x7FFF) + 1;
 							u32 sl, xb, xv, ds, dxb, dxv;
