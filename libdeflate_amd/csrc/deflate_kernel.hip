@@ -138,6 +138,16 @@
 #define WQ_CAP 2048u		/* round B items per round; the rest waits for the next round */
 #endif
 #define WQ_SEG (WQ_CAP / NWAVES)
+#ifndef RA_PAIR
+/* round A measures its two candidates side by side (match_length2()).  Not
+ * in the small-buffer kernel: three workgroups share a CU there and hide each
+ * other's LDS round trips already; the longer code measured 12 % slower. */
+#ifdef LDA_SMALL
+#define RA_PAIR 0
+#else
+#define RA_PAIR 1
+#endif
+#endif
 #ifndef GEN_GROW
 #define GEN_GROW 1		/* round B: generation g walks (g + 1) quanta */
 #endif
@@ -1486,7 +1496,7 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		u32 c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
 		u32 best = 3, bestd = 0, dprev = 0;
 
-		if (ra_depth == 2) {
+		if (ra_depth == 2 && RA_PAIR) {
 			/* the usual case: both chain links first, then both candidates
 			 * measured side by side (match_length2()); the same results as
 			 * two rounds of the loop below */
