@@ -205,6 +205,12 @@ libdeflate_amd_device_ready(void);
 /* human-readable reason for the last non-OK status (thread-local) */
 LIBDEFLATEAPI const char *
 libdeflate_amd_last_error(void);
+/* The tuning switches of INTEGRATION.md (LDA_* environment variables) are
+ * read ONCE, when the library is loaded - not per call.  A process that
+ * changes them afterwards calls this to have them read again (not to be
+ * called while batches are in flight). */
+LIBDEFLATEAPI void
+libdeflate_amd_reload_env(void);
 
 /*
  * Chunk i of a batch occupies bytes [offsets[i], offsets[i] + nbytes[i]) of a
@@ -230,8 +236,11 @@ libdeflate_amd_compress_batch(struct libdeflate_compressor *compressor,
  * The same with an upper bound of the chunk sizes stated by the caller (the
  * sizes themselves live in HBM, where the host cannot see them): batches of
  * small chunks - at most 4096 bytes, the filesystem-block shape - run on a
- * kernel that keeps three chunks per CU in flight instead of one.  A chunk
- * larger than the bound reports 0, like one that does not fit its slot.
+ * kernel that keeps three chunks per CU in flight instead of one.  The bound
+ * is a promise, and it is only CHECKED where it selects that kernel (bound <=
+ * 4096, levels 0-9): there a chunk larger than the bound reports 0, like one
+ * that does not fit its slot.  With any other bound, or at levels 10-12, the
+ * ordinary kernel runs and takes chunks of any size.
  */
 LIBDEFLATEAPI int
 libdeflate_amd_compress_batch_bounded(struct libdeflate_compressor *compressor,

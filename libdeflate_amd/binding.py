@@ -38,6 +38,7 @@ DROPIN_SYMBOLS = [
 ]
 BATCH_SYMBOLS = [
     "libdeflate_amd_device_ready", "libdeflate_amd_last_error",
+    "libdeflate_amd_reload_env",
     "libdeflate_amd_compress_batch", "libdeflate_amd_decompress_batch",
     "libdeflate_amd_compress_batch_bounded",
     "libdeflate_amd_crc32_batch", "libdeflate_amd_adler32_batch",
@@ -99,6 +100,7 @@ def load():
     sig("libdeflate_set_memory_allocator", None, P, P)
     sig("libdeflate_amd_device_ready", c_int)
     sig("libdeflate_amd_last_error", c_char_p)
+    sig("libdeflate_amd_reload_env", None)
     sig("libdeflate_amd_crc32_batch", c_int, SZ, P, P, P, P, P, P)
     sig("libdeflate_amd_adler32_batch", c_int, SZ, P, P, P, P, P, P)
     sig("libdeflate_amd_compress_batch", c_int, P, c_int, SZ, P, P, P, P, P,
@@ -116,6 +118,12 @@ def load():
     sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib
     return lib
+
+
+def reload_env():
+    """Have the library read its LDA_* tuning switches again (it reads them
+    once, at load)."""
+    load().libdeflate_amd_reload_env()
 
 
 def last_error():

@@ -39,6 +39,17 @@ struct DeviceCtx {
 /* context of the calling thread's current device; nullptr (+error) if none */
 DeviceCtx *device_ctx();
 
+/* the environment switches (tuning aids), read ONCE per
+ * process at the first use - not per call */
+struct EnvCfg {
+	bool no_small = false;		/* LDA_NO_SMALL */
+	bool no_segments = false;	/* LDA_NO_SEGMENTS */
+	int inflate_lpw = 0;		/* LDA_INFLATE_LPW (0 = automatic) */
+	bool inflate_par = true;	/* LDA_INFLATE_PAR */
+	int inflate_waves_per_cu = 16;	/* LDA_INFLATE_WAVES_PER_CU */
+};
+const EnvCfg &env_cfg();
+
 /* grow-only device staging; caller holds ctx->stage_mu */
 void *stage_reserve(DeviceCtx *ctx, size_t nbytes);
 
@@ -59,10 +70,14 @@ struct PinnedPair {
 	uint8_t *buf[2] = { nullptr, nullptr };
 	hipEvent_t ev[2] = { nullptr, nullptr };
 	size_t cap = 0;
-	bool ensure();		/* false + error if pinned memory is unavailable */
+	/* grow-only, sized to what the batch needs (a call on a few KiB pins a
+	 * few KiB: 64 KiB at least, LDA_PINNED_SLICE at most per buffer); false
+	 * + error if pinned memory is unavailable */
+	bool ensure(size_t want);
 	void release();
 };
 #define LDA_PINNED_SLICE ((size_t)32 << 20)
+#define LDA_PINNED_MIN ((size_t)64 << 10)
 
 /* host chunks -> device, packed at d_base + off[i] (off ascending); blocking
  * only on its own pinned buffers */

@@ -144,7 +144,7 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 	 * three workgroups per CU (deflate_small.hip); levels 10-12 keep the
 	 * big one (their parse wants its LDS) */
 	const bool small = max_in_nbytes <= lda_deflate_small_max() &&
-			   c->level <= 9 && !d_seg_info && !getenv("LDA_NO_SMALL");
+			   c->level <= 9 && !d_seg_info && !env_cfg().no_small;
 	/* scratch: [token lists: u64 x words x grid][chunk counter][sums u32 x n] */
 	size_t grid_max = (size_t)ctx->num_cus * (small ? 3 : 1);
 	size_t grid = n < grid_max ? n : grid_max;
@@ -480,7 +480,7 @@ static size_t compress_one(struct libdeflate_compressor *c, int format,
 			   size_t out_avail)
 {
 	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 && in_nbytes < 0xFFFF0000u &&
-	    !getenv("LDA_NO_SEGMENTS"))
+	    !env_cfg().no_segments)
 		return compress_large(c, format, (const uint8_t *)in, in_nbytes,
 				      (uint8_t *)out, out_avail);
 	const void *ins[1] = { in };

@@ -35,22 +35,65 @@ void complain(const char *what, int status)
 	fprintf(stderr, "libdeflate_amd: %s: status %d (%s)\n", what, status, g_err);
 }
 
-bool PinnedPair::ensure()
+static EnvCfg read_env()
 {
-	if (cap)
+	EnvCfg c;
+	c.no_small = getenv("LDA_NO_SMALL") != nullptr;
+	c.no_segments = getenv("LDA_NO_SEGMENTS") != nullptr;
+	if (const char *e = getenv("LDA_INFLATE_LPW")) {
+		int v = atoi(e);
+		if (v >= 1 && v <= 64)
+			c.inflate_lpw = v;
+	}
+	if (const char *e = getenv("LDA_INFLATE_PAR"))
+		c.inflate_par = atoi(e) != 0;
+	if (const char *e = getenv("LDA_INFLATE_WAVES_PER_CU")) {
+		int v = atoi(e);
+		if (v >= 1 && v <= 16)
+			c.inflate_waves_per_cu = v;
+	}
+	return c;
+}
+
+static EnvCfg g_env = read_env();	/* once, when the library is loaded */
+
+const EnvCfg &env_cfg()
+{
+	return g_env;
+}
+
+bool PinnedPair::ensure(size_t want)
+{
+	if (want > LDA_PINNED_SLICE)
+		want = LDA_PINNED_SLICE;
+	if (want < LDA_PINNED_MIN)
+		want = LDA_PINNED_MIN;
+	if (cap >= want)
 		return true;
+	/* grow: round up to a power of two so that a sequence of slowly
+	 * growing batches does not re-pin every time */
+	size_t ncap = LDA_PINNED_MIN;
+	while (ncap < want)
+		ncap <<= 1;
+	uint8_t *nb[2] = { nullptr, nullptr };
 	for (int b = 0; b < 2; b++) {
-		hipError_t e = hipHostMalloc((void **)&buf[b], LDA_PINNED_SLICE,
-					     hipHostMallocDefault);
-		if (e == hipSuccess)
+		hipError_t e = hipHostMalloc((void **)&nb[b], ncap, hipHostMallocDefault);
+		if (e == hipSuccess && !ev[b])
 			e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
 		if (e != hipSuccess) {
-			set_error("pinned staging: %s", hipGetErrorString(e));
-			release();
-			return false;
+			set_error("pinned staging (%zu bytes): %s", ncap, hipGetErrorString(e));
+			for (int k = 0; k <= b; k++)
+				if (nb[k])
+					(void)hipHostFree(nb[k]);
+			return false;	/* what was there stays usable */
 		}
 	}
-	cap = LDA_PINNED_SLICE;
+	for (int b = 0; b < 2; b++) {
+		if (buf[b])
+			(void)hipHostFree(buf[b]);
+		buf[b] = nb[b];
+	}
+	cap = ncap;
 	return true;
 }
 
@@ -71,8 +114,11 @@ int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
 		   const void *const *in, const size_t *in_nbytes,
 		   const uint64_t *off, hipStream_t st)
 {
-	if (!pp->ensure())
-		return LIBDEFLATE_AMD_OOM;
+	{	/* pinned staging sized by the batch's span (two buffers alternate) */
+		uint64_t span = n ? off[n - 1] + in_nbytes[n - 1] - off[0] : 0;
+		if (!pp->ensure(span))
+			return LIBDEFLATE_AMD_OOM;
+	}
 	int b = 0;
 	bool used[2] = { false, false };
 	for (size_t i = 0; i < n;) {
@@ -113,8 +159,19 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		    void *const *out, const uint64_t *nbytes,
 		    const uint64_t *off, hipStream_t st)
 {
-	if (!pp->ensure())
-		return LIBDEFLATE_AMD_OOM;
+	{
+		uint64_t lo = 0, hi = 0;
+		bool any = false;
+		for (size_t i = 0; i < n; i++)
+			if (nbytes[i]) {
+				if (!any)
+					lo = off[i];
+				any = true;
+				hi = off[i] + nbytes[i];
+			}
+		if (!pp->ensure(hi - lo))
+			return LIBDEFLATE_AMD_OOM;
+	}
 	struct slice { size_t i, j; uint64_t s0, span; int b; };
 	auto next_slice = [&](size_t i, int b, slice *s) {
 		while (i < n && nbytes[i] == 0)
@@ -276,6 +333,14 @@ void *stage_reserve(DeviceCtx *ctx, size_t nbytes)
 extern "C" LIBDEFLATEAPI int libdeflate_amd_device_ready(void)
 {
 	return lda::device_ctx() ? LIBDEFLATE_AMD_OK : LIBDEFLATE_AMD_NO_DEVICE;
+}
+
+/* the tuning switches are read when the library is loaded; a process that
+ * changes them afterwards (the tests do) asks for a re-read.  Not thread safe
+ * against calls in flight. */
+extern "C" LIBDEFLATEAPI void libdeflate_amd_reload_env(void)
+{
+	lda::g_env = lda::read_env();
 }
 
 extern "C" LIBDEFLATEAPI const char *libdeflate_amd_last_error(void)

@@ -163,18 +163,13 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 	uint32_t lpw = 2;
 	while (lpw < 64 && (size_t)lpw * 32 * (size_t)c->num_cus < n)
 		lpw <<= 1;
-	if (const char *e = getenv("LDA_INFLATE_LPW")) {	/* tuning aid */
-		int v = atoi(e);
-		if (v >= 1 && v <= 64)
-			lpw = (uint32_t)v;
-	}
+	if (env_cfg().inflate_lpw)	/* tuning aid */
+		lpw = (uint32_t)env_cfg().inflate_lpw;
 	/* wave per stream with sub-block parallel token decoding (the default):
 	 * one stream keeps all 64 lanes of its wave busy, so even a batch that
 	 * is small next to the machine (4096 streams on 1024 SIMDs) runs at the
 	 * rate of a huge one.  LDA_INFLATE_PAR=0 selects lane-per-stream. */
-	bool par = true;
-	if (const char *e = getenv("LDA_INFLATE_PAR"))
-		par = atoi(e) != 0;
+	const bool par = env_cfg().inflate_par;
 	static std::atomic<bool> attr_set[16];
 	if (!attr_set[c->device].load(std::memory_order_acquire)) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
@@ -186,9 +181,7 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		attr_set[c->device].store(true, std::memory_order_release);
 	}
 	if (par) {
-		size_t per_cu = 16;
-		if (const char *e = getenv("LDA_INFLATE_WAVES_PER_CU"))	/* tuning */
-			per_cu = (size_t)atoi(e) >= 1 && atoi(e) <= 16 ? (size_t)atoi(e) : 16;
+		const size_t per_cu = (size_t)env_cfg().inflate_waves_per_cu;	/* tuning */
 		size_t grid = (size_t)c->num_cus * per_cu;
 		if (grid > n)
 			grid = n;
@@ -326,12 +319,13 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 
 	if (rc != LIBDEFLATE_AMD_OK) {
 		/* the reference never aborts: a library-side failure comes back
-		 * through the result (the reason is in libdeflate_amd_last_error):
-		 * no memory for the staged output -> INSUFFICIENT_SPACE, anything
-		 * else -> BAD_DATA */
+		 * through the result (the reason is in libdeflate_amd_last_error).
+		 * Always BAD_DATA, also when device or pinned memory ran out:
+		 * INSUFFICIENT_SPACE means "the output buffer was too small" to
+		 * the reference's callers, who answer it with a larger buffer -
+		 * which makes a memory shortage worse on every retry */
 		complain("libdeflate_*_decompress", rc);
-		return rc == LIBDEFLATE_AMD_OOM ? LIBDEFLATE_INSUFFICIENT_SPACE :
-						  LIBDEFLATE_BAD_DATA;
+		return LIBDEFLATE_BAD_DATA;
 	}
 	if (res == LIBDEFLATE_SUCCESS) {
 		if (actual_in_ret)
@@ -375,9 +369,9 @@ DEFINE_DECOMPRESS(gzip, LIBDEFLATE_AMD_GZIP)
  * one call - and where the members say how long they are (the "BC" extra
  * subfield of BGZF: total member size - 1) the whole file is indexed from the
  * headers alone, the output offsets follow from the ISIZE footers, and ALL
- * members go to the device as ONE batch.  Anything else (plain concatenations)
- * is decoded member after member: a member's end is only known once it has
- * been decoded.
+ * members go to the device as ONE batch.  Anything else (plain concatenations,
+ * or what follows the indexed part of a file) is decoded member after member:
+ * a member's end is only known once it has been decoded.
  */
 extern "C" LIBDEFLATEAPI enum libdeflate_result
 libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
@@ -426,7 +420,11 @@ libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 		total += isize;
 		pos += bsize;
 	}
-	if (indexed && !off.empty()) {
+	size_t ipos = 0, opos = 0, members = 0;
+	/* The indexed PREFIX goes to the device as one batch; whatever follows it
+	 * (a plain gzip member appended to a BGZF file, say) continues member
+	 * after member from where the index ends - not from the start. */
+	if (!off.empty()) {
 		if (total > out_avail)
 			return LIBDEFLATE_INSUFFICIENT_SPACE;
 		const size_t n = off.size();
@@ -447,8 +445,7 @@ libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 			osz.data(), res.data(), ain.data(), NULL);
 		if (rc != LIBDEFLATE_AMD_OK) {
 			complain("libdeflate_amd_gzip_decompress_members", rc);
-			return rc == LIBDEFLATE_AMD_OOM ? LIBDEFLATE_INSUFFICIENT_SPACE :
-							  LIBDEFLATE_BAD_DATA;
+			return LIBDEFLATE_BAD_DATA;	/* see decompress_one() */
 		}
 		for (size_t i = 0; i < n; i++) {
 			if (res[i] != LIBDEFLATE_SUCCESS)
@@ -456,17 +453,12 @@ libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 			if (ain[i] != len[i])	/* the member is shorter than it says */
 				return LIBDEFLATE_BAD_DATA;
 		}
-		if (actual_in_ret)
-			*actual_in_ret = pos;
-		if (actual_out_ret)
-			*actual_out_ret = total;
-		if (members_ret)
-			*members_ret = n;
-		return LIBDEFLATE_SUCCESS;
+		ipos = pos;
+		opos = total;
+		members = n;
 	}
 	/* member after member (programs/gzip.c:236-299) */
-	size_t ipos = 0, opos = 0, members = 0;
-	do {
+	while (ipos < in_nbytes || members == 0) {
 		size_t ain = 0, aout = 0;
 		enum libdeflate_result r = decompress_one(
 			d, LIBDEFLATE_AMD_GZIP, in + ipos, in_nbytes - ipos, out + opos,
@@ -478,7 +470,7 @@ libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 		ipos += ain;
 		opos += aout;
 		members++;
-	} while (ipos < in_nbytes);
+	}
 	if (actual_in_ret)
 		*actual_in_ret = ipos;
 	if (actual_out_ret)

@@ -39,8 +39,9 @@
  *     the litlen/offset tables of ONE stream are then built by ALL 64 lanes
  *     (ballot-ranked counting sort of the code lengths, then each lane
  *     canonically decodes its own table indices);
- *   - the host picks lpw so that the whole batch is in flight at once with
- *     about one wave per SIMD (lpw = 4 for 4096 streams, 64 for >= 65536).
+ *   - the host picks lpw (streams per wave) so that the whole batch is in
+ *     flight at once: 2 while the batch fits, doubling from there (2 at 4096
+ *     streams, 8 at 65 536 on 256 CUs; host_decompress.hip).
  *
  * Result codes follow the reference bit for bit, including the implicit
  * zero-padding rule: the reference fails when a refill would need a 9th
@@ -1121,6 +1122,12 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					bad |= toofar;
 					vfar[k] = 0x100;	/* not a byte: no far source */
 					if (__ballot(far)) {
+						/* the source may be a byte another lane of this
+						 * wave stored earlier in the round (flush_ring):
+						 * those stores are complete before the load is
+						 * issued, not merely issued before it (rare path:
+						 * sources further back than the LDS mirror) */
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 						if (far)
 							vfar[k] = gfar[bi + 32768u - dist];
 					}

@@ -9,6 +9,8 @@ import zlib
 import numpy as np
 import pytest
 
+from libdeflate_amd import binding
+
 from tests import datagen, streams
 
 pytestmark = pytest.mark.gpu
@@ -247,6 +249,7 @@ def test_both_mappings_agree(dec, oracle, monkeypatch):
     outs = []
     for mode in ("1", "0"):
         monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()        # the switches are read once, at load
         got = []
         for want in (True, False):
             grp = [c for c in cases if c[3] == want]
@@ -275,6 +278,7 @@ def test_stored_block_then_short_match(dec, oracle, monkeypatch):
         cases.append(("zlib", z, len(want), True, f"stored{i}/zlib"))
     for mode in ("1", "0"):
         monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()        # the switches are read once, at load
         _run_cases(dec, oracle, cases)
         for i, (s, want) in enumerate(streams.stored_then_match_streams()):
             assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
@@ -296,6 +300,7 @@ def test_parallel_round_corner_streams(dec, oracle, monkeypatch):
         cases.append(("deflate", s, 200000, True, f"baddist{i}"))
     for mode in ("1", "0"):
         monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()        # the switches are read once, at load
         _run_cases(dec, oracle, cases)
         for name, s, want in streams.parallel_round_streams():
             assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, name)
@@ -401,6 +406,14 @@ def test_multi_member_gzip(dec, ref):
     assert ref_loop(bytes(bad), len(plain))[0] != 0
     assert dec.gzip_decompress_members(cat + b"junk", len(want))[0] == \
         ref_loop(cat + b"junk", len(want))[0] == 1
+    # an ordinary member behind an indexed (BGZF) prefix: the prefix is one
+    # batch, the rest continues member after member from where the index ends
+    mixed = b"".join(_bgzf_member(p) for p in parts[:5]) + \
+        streams._zcompress("gzip", 6, parts[5]) + _bgzf_member(parts[6])
+    wantm = b"".join(parts[:7])
+    assert ref_loop(mixed, len(wantm)) == (0, wantm)
+    r, ain, aout, nm, out = dec.gzip_decompress_members(mixed, len(wantm))
+    assert (r, ain, aout, nm) == (0, len(mixed), len(wantm), 7) and out == wantm
     # a single ordinary member is the one-member case of the same call
     one = streams._zcompress("gzip", 6, parts[0])
     assert dec.gzip_decompress_members(one, len(parts[0]))[:4] == (0, len(one), len(parts[0]), 1)

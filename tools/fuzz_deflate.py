@@ -18,13 +18,18 @@ from tests.test_deflate_gpu import _weird_chunk  # noqa: E402
 WB = {"deflate": -15, "zlib": 15, "gzip": 31}
 
 
-def main():
+def run(seeds, budget_s=None, log=print):
+    """-> (buffers compressed, failures); stops after `budget_s` seconds (at
+    least one seed)."""
+    import time
     from libdeflate_amd import api
-    seeds = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
     edges = [1, 2, 3, 17, 18, 19, 52, 53, 4094, 4095, 4096, 4097, 8190, 8194, 12288,
              65534, 65536, 65538, 69632, 131071, 131072, 131073]
-    nbad = 0
-    for seed in seeds:
+    nbad = nbuf = 0
+    t0 = time.time()
+    for k, seed in enumerate(seeds):
+        if budget_s is not None and k and time.time() - t0 > budget_s:
+            break
         rng = np.random.default_rng(0x0F220000 + seed)
         level = int(rng.integers(0, 13))
         fmt = ("deflate", "zlib", "gzip")[seed % 3]
@@ -46,12 +51,20 @@ def main():
             ok = z is not None and len(z) <= c.bound(fmt, len(d)) and zlib.decompress(z, WB[fmt]) == d
             if not ok:
                 nbad += 1
-                print("FAIL", seed, level, fmt, len(d), None if z is None else len(z))
+                log("FAIL", seed, level, fmt, len(d), None if z is None else len(z))
         c.close()
-        print(f"seed {seed}: level {level} {fmt} {'small' if small else 'mixed'} "
-              f"{len(chunks)} buffers, {sum(map(len, chunks))} bytes, bad {nbad}", flush=True)
+        nbuf += len(chunks)
+        log(f"seed {seed}: level {level} {fmt} {'small' if small else 'mixed'} "
+            f"{len(chunks)} buffers, {sum(map(len, chunks))} bytes, bad {nbad}", flush=True)
         if nbad:
-            sys.exit(1)
+            break
+    return nbuf, nbad
+
+
+def main():
+    seeds = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
+    _, bad = run(seeds)
+    sys.exit(1 if bad else 0)
 
 
 if __name__ == "__main__":
