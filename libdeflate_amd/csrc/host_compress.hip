@@ -372,10 +372,13 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 
 	if (out_avail <= hdr + ftr)
 		return 0;
-	/* device layout: [5 u64 arrays + u32 seg_info + u32 sums][input][slots] */
-	size_t desc_bytes = align_up(nseg * (5 * 8 + 4 + 4), 64);
+	/* device layout: [5 u64 arrays + u32 seg_info + u32 sums + compaction
+	 * offsets][input][slots][the slots' used parts back to back] */
+	const size_t ncmp = libdeflate_amd_compact_offsets_len(nseg);
+	size_t desc_bytes = align_up(nseg * (5 * 8 + 4 + 4) + 64 + ncmp * 8, 64);
 	size_t in_at = desc_bytes, out_at = align_up(in_at + n + 64, 64);
-	uint8_t *st = (uint8_t *)c->stage.reserve(out_at + nseg * slot + 64);
+	size_t pk_at = align_up(out_at + nseg * slot + 64, 64);
+	uint8_t *st = (uint8_t *)c->stage.reserve(pk_at + nseg * slot + 64);
 	if (!st) {
 		complain("libdeflate_*_compress (device memory)", LIBDEFLATE_AMD_OOM);
 		return 0;
@@ -395,6 +398,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	uint64_t *d_desc = (uint64_t *)st;
 	uint32_t *d_seg = (uint32_t *)(st + 5 * 8 * nseg);
 	uint32_t *d_sums = d_seg + nseg;
+	uint64_t *d_cmp = (uint64_t *)(st + align_up(nseg * (5 * 8 + 4 + 4), 64));
 	if (hipMemcpy(d_desc, d64.data(), 4 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(st + in_at, in, n, hipMemcpyHostToDevice) != hipSuccess)
@@ -423,8 +427,14 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 		if (rc != LIBDEFLATE_AMD_OK)
 			return large_fail("checksum");
 	}
-	if (hipDeviceSynchronize() != hipSuccess ||
-	    hipMemcpy(&d64[4 * nseg], d_desc + 4 * nseg, 8 * nseg, hipMemcpyDeviceToHost) != hipSuccess ||
+	/* the segments' streams back to back on the device (prefix sum + one
+	 * gather copy), then ONE transfer to the caller's buffer - not a
+	 * blocking copy per segment */
+	rc = libdeflate_amd_compact_batch(nseg, st, d_desc + 2 * nseg, d_desc + 4 * nseg,
+					  st + pk_at, d_cmp, NULL);
+	if (rc != LIBDEFLATE_AMD_OK)
+		return large_fail("compaction");
+	if (hipMemcpy(&d64[4 * nseg], d_desc + 4 * nseg, 8 * nseg, hipMemcpyDeviceToHost) != hipSuccess ||
 	    (ftr && hipMemcpy(&d32[nseg], d_sums, 4 * nseg, hipMemcpyDeviceToHost) != hipSuccess))
 		return large_fail("copy out");
 	size_t total = hdr + ftr;
@@ -435,13 +445,9 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	}
 	if (total > out_avail)
 		return 0;
-	size_t at = hdr;
-	for (size_t i = 0; i < nseg; i++) {
-		size_t sz = d64[4 * nseg + i];
-		if (hipMemcpy(out + at, st + out_off[i], sz, hipMemcpyDeviceToHost) != hipSuccess)
-			return large_fail("copy out");
-		at += sz;
-	}
+	const size_t at = total - ftr;
+	if (hipMemcpy(out + hdr, st + pk_at, at - hdr, hipMemcpyDeviceToHost) != hipSuccess)
+		return large_fail("copy out");
 	if (format == LIBDEFLATE_AMD_GZIP) {
 		/* lib/gzip_compress.c:44-79 */
 		uint32_t crc = 0;
@@ -479,8 +485,10 @@ static size_t compress_one(struct libdeflate_compressor *c, int format,
 			   const void *in, size_t in_nbytes, void *out,
 			   size_t out_avail)
 {
-	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 && in_nbytes < 0xFFFF0000u &&
-	    !env_cfg().no_segments)
+	/* (inputs of 4 GiB and more always take this path: the kernels index a
+	 * chunk with 32 bits, the segments are 64 KiB each) */
+	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 &&
+	    (!env_cfg().no_segments || in_nbytes >= 0xFFFF0000u))
 		return compress_large(c, format, (const uint8_t *)in, in_nbytes,
 				      (uint8_t *)out, out_avail);
 	const void *ins[1] = { in };

@@ -526,3 +526,37 @@ print("ok")
 ''' % os.path.join(os.path.dirname(__file__), "..")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_input_over_4gib(ref):
+    """An input of 4.5 GiB through the single-buffer API (the reference takes
+    any size_t, lib/deflate_compress.c:4030-4072): cut into 64 KiB segments,
+    one stream, ISIZE mod 2^32, CRC-32 combined over 73 728 pieces; decoded by
+    the REAL reference and compared byte for byte."""
+    import ctypes
+    import psutil
+    from libdeflate_amd import api
+    n = (9 << 29) + 12345                # 4.5 GiB + an odd tail
+    if psutil.virtual_memory().available < 4 * n:
+        pytest.skip("needs ~18 GiB of free host memory")
+    block = np.frombuffer(b"".join(datagen.chunk(i, 1 << 20, 0x0E110077) for i in range(16)),
+                          dtype=np.uint8)
+    data = np.tile(block, n // block.size + 1)[:n]
+    # make every 16 MiB repetition differ (no trivially repeating stream)
+    data[::1 << 24] = (np.arange((n + (1 << 24) - 1) >> 24) & 255).astype(np.uint8)
+    c = api.Compressor(1)
+    bound = c.bound("gzip", n)
+    out = np.empty(bound, dtype=np.uint8)
+    r = c._lib.libdeflate_gzip_compress(c._h, data.ctypes.data_as(ctypes.c_void_p), n,
+                                        out.ctypes.data_as(ctypes.c_void_p), bound)
+    c.close()
+    assert 0 < r <= bound
+    # ISIZE is n mod 2^32 (gzip_compress.c:78-79)
+    assert int.from_bytes(out[r - 4:r].tobytes(), "little") == n & 0xFFFFFFFF
+    back = np.empty(n, dtype=np.uint8)
+    ai, ao = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    res = ref.lib.libdeflate_gzip_decompress_ex(
+        ref._d, ctypes.cast(out.ctypes.data, ctypes.c_char_p), r,
+        back.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(ai), ctypes.byref(ao))
+    assert (res, ai.value, ao.value) == (0, r, n)
+    assert np.array_equal(back, data)
