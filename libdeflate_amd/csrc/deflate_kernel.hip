@@ -328,7 +328,7 @@ static __device__ u32 block_scan(lds_t *L, u32 v, u32 *total)
 		tot += s;
 	}
 	__syncthreads();
-	*total = tot;
+	*total = bcast_first(tot);
 	return base + incl - v;
 }
 
@@ -355,7 +355,7 @@ static __device__ u32 block_scan1(lds_t *L, u32 v, u32 *total,
 			base += s;
 		tot += s;
 	}
-	*total = tot;
+	*total = bcast_first(tot);
 	return base + incl - v;
 }
 
@@ -1733,9 +1733,9 @@ static __device__ __forceinline__ void
 parse_and_base(lds_t *L, u32 *__restrict__ tokg, u32 t, s32 limit, u32 mode,
 	       u32 nice, u32 lane)
 {
-	const s32 entry = (s32)L->vars[V_ENTRY];
+	const s32 entry = (s32)bcast_first(L->vars[V_ENTRY]);
 	const u32 lim_idx = (u32)(limit + 4);
-	const u32 seq0 = L->vars[V_NSEQ];
+	const u32 seq0 = bcast_first(L->vars[V_NSEQ]);
 	u32 e = (u32)(entry + 4), npre = 0;
 
 	for (u32 pre = 0; pre < 2; pre++) {	/* idx 2, 3 */
@@ -1940,7 +1940,7 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 	if (tid == 0)
 		L->qn[0] = 0;
 	__syncthreads();
-	return wc < limit ? wc : limit;
+	return bcast_first(wc < limit ? wc : limit);
 }
 
 /*
@@ -2238,7 +2238,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 		}
 		__syncthreads();
 		PROF_GEN(gen);
-		ncur = *(volatile AS3 u32 *)ctr;
+		ncur = bcast_first(*(volatile AS3 u32 *)ctr);
 		if (!ncur)
 			break;
 	}
@@ -2367,7 +2367,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		if (tid == 0)
 			L->vars[V_TMP0] = atomicAdd(next_chunk, 1u);
 		__syncthreads();
-		const u64 c = L->vars[V_TMP0];
+		/* (workgroup-uniform values read back from LDS are made scalar: what
+		 * derives from them - descriptors, addresses, loop bounds - then lives
+		 * in SGPRs instead of vector registers) */
+		const u64 c = bcast_first(L->vars[V_TMP0]);
 		if (c >= n_chunks)
 			break;
 		const u8 *inp = in_base + in_offsets[c];
@@ -2689,7 +2692,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					/* (the minimum match length of tile nxt was estimated a
 					 * tile ahead, beside phase X) */
 					if (nxt_real && it)
-						ml_nxt = L->vars[V_MINLEN];
+						ml_nxt = bcast_first(L->vars[V_MINLEN]);
 					__syncthreads();
 				}
 				PROF_MARK(1);
@@ -2708,7 +2711,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					}
 					__syncthreads();
 					if (nxt_real)
-						ml_nxt = L->vars[V_MINLEN];
+						ml_nxt = bcast_first(L->vars[V_MINLEN]);
 					PROF_MARK(2);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2811,7 +2814,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						 * the next tile's first parse) */
 						if (wave == NWAVES - 1 && use3) {
 							wait_lds_eq(L, V_EMDONE, TILE / 64);
-							split_stats(L, L->vars[V_WALKPOS_LO], block_start, false, lane);
+							split_stats(L, bcast_first(L->vars[V_WALKPOS_LO]), block_start, false, lane);
 						}
 					}
 					__syncthreads();
@@ -2842,7 +2845,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (!cur_real)
 					continue;	/* iteration 0, dictionary tiles: nothing to emit */
 
-				walkpos = L->vars[V_WALKPOS_LO];
+				walkpos = bcast_first(L->vars[V_WALKPOS_LO]);
 				/* the last 4 match entries go to the front of the next tile's,
 				 * for the positions the walk deferred */
 				if (tid < 4)
@@ -2874,9 +2877,9 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * the tile's tokens (already in the match list) become the start
 			 * of the next block.  Only when that would leave a block shorter
 			 * than the minimum, the block ends after the tile. */
-			const u32 splitv = !stored_only && !last_tile ? L->vars[V_SPLIT] : 0;
+			const u32 splitv = !stored_only && !last_tile ? bcast_first(L->vars[V_SPLIT]) : 0;
 			bool end_block = last_tile || splitv ||
-				(!stored_only && L->vars[V_NSEQ] + 2 * TOK_TILE_MAX > TOK_CAP) ||
+				(!stored_only && bcast_first(L->vars[V_NSEQ]) + 2 * TOK_TILE_MAX > TOK_CAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
 				continue;
@@ -2885,10 +2888,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 
 			const bool retro = splitv == 2;
 			const u32 bstart = block_start;
-			const u32 bend = last_tile ? n : retro ? L->vars[V_WPOS_PRE] : walkpos;
+			const u32 bend = last_tile ? n : retro ? bcast_first(L->vars[V_WPOS_PRE]) : walkpos;
 			const u32 blen = bend - bstart;
-			const u32 nseq_all = stored_only ? 0 : L->vars[V_NSEQ];
-			const u32 nseq = retro ? L->vars[V_NSEQ_PRE] : nseq_all;
+			const u32 nseq_all = stored_only ? 0 : bcast_first(L->vars[V_NSEQ]);
+			const u32 nseq = retro ? bcast_first(L->vars[V_NSEQ_PRE]) : nseq_all;
 			const u32 is_final = last_tile && seg_last ? 1 : 0;
 			if (retro) {
 				for (u32 i = tid; i < 320; i += NT) {
