@@ -23,3 +23,17 @@ def test_lds_atomics_are_served_in_lane_order():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["lane_order"] is True and out["mismatches"] == 0
     assert out["same_instruction_conflicts"] > 1_000_000     # the test did exercise conflicts
+
+
+def test_global_store_is_visible_to_a_following_load_of_the_wave():
+    """The inflate copy phase reads far match sources from the output in HBM
+    that another lane of the same wave may have stored a moment earlier, with
+    only a compiler barrier in between (tools/hwtest_global_visibility.hip)."""
+    exe = os.path.join(ROOT, "tools", "hwtest_global_visibility")
+    if not os.path.exists(exe):
+        pytest.skip("tools/hwtest_global_visibility not built (__graft_entry__.build() builds it)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["store_then_load_visible"] is True and out["stale"] == 0
+    assert out["loads"] > 1_000_000_000
