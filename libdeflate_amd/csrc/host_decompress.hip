@@ -144,9 +144,9 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		set_error("decompress_batch: bad argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	/* scratch: [sums u32 x n][actual_in u64 x n][actual_out u64 x n] */
+	/* scratch: [sums u32 x n][actual_in u64 x n][actual_out u64 x n][order u32 x n] */
 	size_t sums_bytes = align_up(n * 4, 16);
-	uint8_t *s = (uint8_t *)d->scratch.reserve(sums_bytes + 16 * n);
+	uint8_t *s = (uint8_t *)d->scratch.reserve(sums_bytes + 16 * n + 4 * n + 16);
 	if (!s)
 		return LIBDEFLATE_AMD_OOM;
 	uint32_t *sums = (uint32_t *)s;
@@ -194,10 +194,19 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 			return LIBDEFLATE_AMD_OOM;
 		uint32_t *next = (uint32_t *)((uint8_t *)tok + tok_bytes);
 		LDA_HIP_TRY(hipMemsetAsync(next, 0, 16, st), LIBDEFLATE_AMD_NO_DEVICE);
+		/* a batch of several streams per wave slot is handed out longest
+		 * stream first (a batch that fits the grid starts all at once) */
+		uint32_t *order = NULL;
+		if (n >= 2 * grid && n < 0xFFFFFFFFull) {
+			order = (uint32_t *)(s + sums_bytes + 16 * n);
+			hipLaunchKernelGGL(lda_inflate_order_kernel, dim3(1), dim3(1024), 0, st,
+					   (uint64_t)n, d_in_nbytes, order);
+		}
 		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared() +
 			     lda_inflate_window_bytes();
 		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
 				   dim3(64), lds, st, (uint64_t)n, format, tok, next,
+				   (const uint32_t *)order,
 				   (const uint8_t *)d_in, d_in_offsets, d_in_nbytes,
 				   (uint8_t *)d_out, d_out_offsets, d_out_avail,
 				   d_results, ain, aout);

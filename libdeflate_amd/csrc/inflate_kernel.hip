@@ -1915,9 +1915,55 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 #ifndef PAR_WAVES_PER_SIMD
 #define PAR_WAVES_PER_SIMD 4	/* 16 streams in flight per CU: occupancy hides the LDS chains */
 #endif
+/*
+ * Longest first: the streams of a batch larger than the grid are handed out
+ * in the order of their compressed size, largest first (the cost of a stream
+ * follows its size: the classic longest-processing-time rule keeps the last
+ * waves from starting a long stream when the others are about to finish).
+ * One workgroup: a 256-bucket counting sort by size / 512 (everything from
+ * 128 KiB up shares the first bucket); the order inside a bucket is whatever
+ * the atomics give - it only decides which wave decodes which stream.
+ */
+extern "C" __global__ void __launch_bounds__(1024)
+lda_inflate_order_kernel(u64 n, const u64 *__restrict__ in_nbytes,
+			 u32 *__restrict__ order)
+{
+	__shared__ u32 cnt[256], at[256];
+	const u32 tid = threadIdx.x;
+
+	if (tid < 256)
+		cnt[tid] = 0;
+	__syncthreads();
+	for (u64 i = tid; i < n; i += 1024) {
+		const u64 b = in_nbytes[i] >> 9;
+		atomicAdd(&cnt[255 - (b < 255 ? (u32)b : 255u)], 1u);
+	}
+	__syncthreads();
+	if (tid < 64) {		/* exclusive prefix over the 256 buckets, one wave */
+		u32 v[4], s = 0;
+#pragma unroll
+		for (u32 k = 0; k < 4; k++) {
+			v[k] = cnt[4 * tid + k];
+			s += v[k];
+		}
+		u32 base = wave_scan_incl(s) - s;
+#pragma unroll
+		for (u32 k = 0; k < 4; k++) {
+			at[4 * tid + k] = base;
+			base += v[k];
+		}
+	}
+	__syncthreads();
+	for (u64 i = tid; i < n; i += 1024) {
+		const u64 b = in_nbytes[i] >> 9;
+		order[atomicAdd(&at[255 - (b < 255 ? (u32)b : 255u)], 1u)] = (u32)i;
+	}
+}
+
 extern "C" __global__ void __launch_bounds__(64, PAR_WAVES_PER_SIMD)
 lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 			u32 *__restrict__ next_stream,
+			const u32 *__restrict__ order,
 			const u8 *__restrict__ in_base,
 			const u64 *__restrict__ in_offsets,
 			const u64 *__restrict__ in_nbytes,
@@ -1949,7 +1995,8 @@ lda_inflate_wave_kernel(u64 n_chunks, int format, u32 *__restrict__ tokscratch,
 	 * the grid are handed out as the waves become free (their cost depends
 	 * on their content) */
 	for (u64 blk = first; blk < n_chunks;) {
-		inflate_block(blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
+		/* (order: see lda_inflate_order_kernel(); NULL = index order) */
+		inflate_block(order ? order[blk] : blk, lds_raw, 1, tok, n_chunks, format, 1, in_base,
 			      in_offsets, in_nbytes, out_base, out_offsets,
 			      out_avail_arr, results, actual_in, actual_out);
 		wave_sync();

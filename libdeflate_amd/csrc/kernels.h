@@ -29,11 +29,14 @@ lda_inflate_batch_kernel(uint64_t n_chunks, int format, uint32_t lpw,
 			 uint64_t *actual_in, uint64_t *actual_out);
 extern "C" __global__ void
 lda_inflate_wave_kernel(uint64_t n_chunks, int format, uint32_t *tokscratch,
-			uint32_t *next_stream, const uint8_t *in_base,
+			uint32_t *next_stream, const uint32_t *order,
+			const uint8_t *in_base,
 			const uint64_t *in_offsets, const uint64_t *in_nbytes,
 			uint8_t *out_base, const uint64_t *out_offsets,
 			const uint64_t *out_avail, int32_t *results,
 			uint64_t *actual_in, uint64_t *actual_out);
+extern "C" __global__ void
+lda_inflate_order_kernel(uint64_t n, const uint64_t *in_nbytes, uint32_t *order);
 extern "C" size_t lda_inflate_tokcap(void);
 extern "C" size_t lda_inflate_window_bytes(void);
 extern "C" __global__ void
