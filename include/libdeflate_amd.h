@@ -313,8 +313,12 @@ libdeflate_amd_compact_batch(size_t n_chunks, const void *d_in,
  * object may have batches in flight on ONE stream at a time (they are ordered
  * by the stream); use one object per stream for concurrent batches, exactly
  * as the reference asks for one object per thread (libdeflate.h:56-57,
- * :178-179).  Inputs of 4 GiB and more per chunk are not supported by the
- * batch kernels (positions are 32-bit): such a chunk reports 0 / BAD_DATA.
+ * :178-179).  Chunks of 4 GiB and more are not supported by the batch
+ * kernels (positions are 32-bit): such a chunk reports 0 / BAD_DATA.  The
+ * single-buffer libdeflate_*_compress calls take inputs of any size (they cut
+ * them into 64 KiB segments that run as one batch and stitch the streams);
+ * the single-buffer decompress calls are limited to streams of less than
+ * 4 GiB each.
  */
 
 /*

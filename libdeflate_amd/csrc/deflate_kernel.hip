@@ -20,21 +20,26 @@
  *   M[]     per-position best (length, distance) of the current tile
  *
  * and advances in TILES of 4096 positions (each stage is a function below;
- * deflate_batch_body() is the schedule):
+ * deflate_batch_body() is the schedule: two tiles are in flight - the final
+ * parse, the token emission and the split statistics of tile k run in the
+ * same phase ("phase X") as the shallow search and the first parse of tile
+ * k + 1 and the chain insertion of tile k + 2, handing over through LDS
+ * counters and flags; see the comment at the tile loop and DESIGN.md 3.3):
  *
- *   S0  input of this tile AND the next (the next tile joins the chains
- *       while this one is searched);
+ *   S0  input up to the end of the tile after the next (it joins the chains
+ *       while the next one is searched);
  *   S1+S2  chain insertion WITHOUT a sort (insert_tile): a masked LDS
  *       exchange per position; conflicting lanes of one LDS atomic are
  *       served in lane order, so 64 consecutive positions per instruction
- *       get what a serial insertion loop would have returned.  One wave, one
- *       tile ahead, beside round A;
+ *       get what a serial insertion loop would have returned.  One wave, two
+ *       tiles ahead of the parse, beside round A;
  *   S3  progressive search: round A - every position measures its two
- *       nearest chain members (round_a); then, after a parse, round B - only
- *       the positions that parse visited are searched to the full depth
+ *       nearest chain members (round_a); then, after a first parse, round B -
+ *       only the positions that parse visited are searched to the full depth
  *       (depth / nice length per level as lib/deflate_compress.c:3927-3979),
- *       in packed generations of 16 chain steps (build_worklist,
- *       search_queue).  Levels 10-12 search every position (search_items);
+ *       in packed generations of growing quanta of chain steps
+ *       (build_worklist, search_queue).  Levels 10-12 search every position
+ *       (search_items);
  *   S4  the greedy / lazy / lazy2 choice is a pure function of the
  *       per-position results (rules of deflate_compress.c:2573-2575,
  *       2712-2755): steps position-parallel (stage_steps), the path by one
