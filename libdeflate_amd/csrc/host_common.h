@@ -47,6 +47,7 @@ struct EnvCfg {
 	int inflate_lpw = 0;		/* LDA_INFLATE_LPW (0 = automatic) */
 	bool inflate_par = true;	/* LDA_INFLATE_PAR */
 	int inflate_waves_per_cu = 16;	/* LDA_INFLATE_WAVES_PER_CU */
+	int host_threads = 4;		/* LDA_HOST_THREADS: packing threads of the host-pointer batches */
 };
 const EnvCfg &env_cfg();
 
@@ -78,6 +79,24 @@ struct PinnedPair {
 };
 #define LDA_PINNED_SLICE ((size_t)32 << 20)
 #define LDA_PINNED_MIN ((size_t)64 << 10)
+
+/*
+ * Two streams of an object for its host-pointer batch entry points: the batch
+ * goes through in slices, the transfers of a slice on `copy`, its kernels on
+ * `comp`, so that the kernels of slice k run while the host packs and sends
+ * slice k + 1 and unpacks slice k - 1.
+ */
+struct StreamPair {
+	hipStream_t copy = nullptr, comp = nullptr;
+	bool ensure();
+	void release();
+};
+
+/* cut n chunks into at most `max_slices` consecutive slices of about equal
+ * byte counts (each at least `min_bytes`, as far as the total allows);
+ * bounds[0..k] with bounds[0] = 0, bounds[k] = n; returns k >= 1 */
+size_t slice_by_bytes(size_t n, const size_t *nbytes, size_t max_slices,
+		      size_t min_bytes, size_t *bounds);
 
 /* host chunks -> device, packed at d_base + off[i] (off ascending); blocking
  * only on its own pinned buffers */

@@ -89,6 +89,7 @@ libdeflate_free_compressor(struct libdeflate_compressor *c)
 	c->scratch.release();
 	c->stage.release();
 	c->pinned.release();
+	c->streams.release();
 	free_func_t f = c->free_func;
 	c->~libdeflate_compressor();
 	f(c);
@@ -241,9 +242,24 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 		set_error("compress_batch_host: NULL argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	/* device layout: [in_off in_n out_off out_av out_n cmp_off...] [inputs]
-	 * [output slots] [compacted outputs]; everything 16-byte aligned */
-	const size_t ncmp = libdeflate_amd_compact_offsets_len(n);
+	/* The batch goes through in SLICES (up to 8, >= 64 MiB of input each - a
+	 * slice has to fill the GPU several times over, or its kernel's tail
+	 * costs more than the overlap gives: 8 MiB slices measured slower than
+	 * no slices): the
+	 * kernels of slice k run on the object's compute stream while the host
+	 * packs and sends slice k + 1 and unpacks slice k - 1 on its copy stream.
+	 * device layout: [in_off in_n out_off out_av out_n][cmp_off of every
+	 * slice] [inputs] [output slots] [compacted outputs, slice after slice];
+	 * everything 16-byte aligned */
+	enum { MAX_SLICES = 8 };
+	size_t bounds[MAX_SLICES + 1];
+	const size_t ns = slice_by_bytes(n, in_nbytes, MAX_SLICES, (size_t)64 << 20, bounds);
+	size_t cmp_len[MAX_SLICES], cmp_pos[MAX_SLICES], ncmp = 0;
+	for (size_t k = 0; k < ns; k++) {
+		cmp_pos[k] = ncmp;
+		cmp_len[k] = libdeflate_amd_compact_offsets_len(bounds[k + 1] - bounds[k]);
+		ncmp += cmp_len[k];
+	}
 	std::vector<uint64_t> desc(5 * n + ncmp);
 	uint64_t *in_off = &desc[0], *in_n = &desc[n], *out_off = &desc[2 * n],
 		 *out_av = &desc[3 * n], *out_n = &desc[4 * n], *cmp_off = &desc[5 * n];
@@ -254,41 +270,86 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 		pos = align_up(pos + in_nbytes[i] + 16, 16);
 	}
 	size_t total_avail = 0;
-	for (size_t i = 0; i < n; i++) {
-		out_off[i] = pos;
-		out_av[i] = out_avail[i];
-		pos = align_up(pos + out_avail[i] + 16, 16);
-		total_avail += out_avail[i];
+	size_t avail_before[MAX_SLICES + 1];
+	for (size_t k = 0, i = 0; k < ns; k++) {
+		avail_before[k] = total_avail;
+		for (; i < bounds[k + 1]; i++) {
+			out_off[i] = pos;
+			out_av[i] = out_avail[i];
+			pos = align_up(pos + out_avail[i] + 16, 16);
+			total_avail += out_avail[i];
+		}
 	}
 	const size_t cmp_at = pos;
-	uint8_t *st = (uint8_t *)c->stage.reserve(cmp_at + total_avail + 64);
+	uint8_t *st = (uint8_t *)c->stage.reserve(cmp_at + total_avail + 64 * ns + 64);
 	if (!st)
 		return LIBDEFLATE_AMD_OOM;
+	if (!c->streams.ensure())
+		return LIBDEFLATE_AMD_NO_DEVICE;
+	/* the kernels' scratch for the largest launch up front: growing it between
+	 * two slices would free memory a running kernel uses (and synchronise) */
+	if (!c->scratch.reserve((size_t)device_ctx()->num_cus * 3 * lda_deflate_seq_words() * 8 +
+				16 + n * 4))
+		return LIBDEFLATE_AMD_OOM;
+	hipStream_t s_copy = c->streams.copy, s_comp = c->streams.comp;
 	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
-				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
-	int rc = copy_in_packed(&c->pinned, st, n, in, in_nbytes, in_off, nullptr);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return rc;
+				   s_copy), LIBDEFLATE_AMD_NO_DEVICE);
 	uint64_t *d_desc = (uint64_t *)st;
 	size_t max_in = 0;
 	for (size_t i = 0; i < n; i++)
 		max_in = in_nbytes[i] > max_in ? in_nbytes[i] : max_in;
-	rc = libdeflate_amd_compress_batch_bounded(c, format, n, st, d_desc, d_desc + n,
-						   st, d_desc + 2 * n, d_desc + 3 * n,
-						   d_desc + 4 * n, max_in, NULL);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return rc;
-	rc = libdeflate_amd_compact_batch(n, st, d_desc + 2 * n, d_desc + 4 * n,
-					  st + cmp_at, d_desc + 5 * n, NULL);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return rc;
-	LDA_HIP_TRY(hipMemcpyAsync(out_n, d_desc + 4 * n, (n + n + 1) * 8,
-				   hipMemcpyDeviceToHost, nullptr),
-		    LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipStreamSynchronize(nullptr), LIBDEFLATE_AMD_NO_DEVICE);
-	for (size_t i = 0; i < n; i++)
-		out_nbytes[i] = out_n[i];
-	return copy_out_packed(&c->pinned, st + cmp_at, n, out, out_n, cmp_off, nullptr);
+	hipEvent_t ev_done[MAX_SLICES] = {};
+	int rc = LIBDEFLATE_AMD_OK;
+	auto cleanup = [&]() {
+		(void)hipStreamSynchronize(s_comp);
+		(void)hipStreamSynchronize(s_copy);
+		for (size_t k = 0; k < ns; k++)
+			if (ev_done[k])
+				(void)hipEventDestroy(ev_done[k]);
+	};
+	/* slice k's streams are complete on the device: sizes to the caller,
+	 * bytes through the pinned pair */
+	auto drain = [&](size_t k) -> int {
+		const size_t lo = bounds[k], nk = bounds[k + 1] - lo;
+		LDA_HIP_TRY(hipEventSynchronize(ev_done[k]), LIBDEFLATE_AMD_NO_DEVICE);
+		for (size_t i = lo; i < lo + nk; i++)
+			out_nbytes[i] = out_n[i];
+		return copy_out_packed(&c->pinned, st + cmp_at + avail_before[k] + 64 * k, nk,
+				       out + lo, out_n + lo, cmp_off + cmp_pos[k], s_copy);
+	};
+	for (size_t k = 0; k < ns && rc == LIBDEFLATE_AMD_OK; k++) {
+		const size_t lo = bounds[k], nk = bounds[k + 1] - lo;
+		/* (returns when the slice is on the device) */
+		rc = copy_in_packed(&c->pinned, st, nk, in + lo, in_nbytes + lo, in_off + lo, s_copy);
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		rc = libdeflate_amd_compress_batch_bounded(
+			c, format, nk, st, d_desc + lo, d_desc + n + lo, st, d_desc + 2 * n + lo,
+			d_desc + 3 * n + lo, d_desc + 4 * n + lo, max_in, s_comp);
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		rc = libdeflate_amd_compact_batch(nk, st, d_desc + 2 * n + lo, d_desc + 4 * n + lo,
+						  st + cmp_at + avail_before[k] + 64 * k,
+						  d_desc + 5 * n + cmp_pos[k], s_comp);
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		if (hipMemcpyAsync(out_n + lo, d_desc + 4 * n + lo, nk * 8, hipMemcpyDeviceToHost,
+				   s_comp) != hipSuccess ||
+		    hipMemcpyAsync(cmp_off + cmp_pos[k], d_desc + 5 * n + cmp_pos[k], (nk + 1) * 8,
+				   hipMemcpyDeviceToHost, s_comp) != hipSuccess ||
+		    hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
+		    hipEventRecord(ev_done[k], s_comp) != hipSuccess) {
+			set_error("compress_batch_host: %s", hipGetErrorString(hipGetLastError()));
+			rc = LIBDEFLATE_AMD_NO_DEVICE;
+			break;
+		}
+		if (k)
+			rc = drain(k - 1);
+	}
+	if (rc == LIBDEFLATE_AMD_OK)
+		rc = drain(ns - 1);
+	cleanup();
+	return rc;
 }
 
 /*

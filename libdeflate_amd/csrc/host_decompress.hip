@@ -114,6 +114,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->stage.release();
 	d->tokens.release();
 	d->pinned.release();
+	d->streams.release();
 	free_func_t f = d->free_func;
 	d->~libdeflate_decompressor();
 	f(d);
@@ -257,7 +258,15 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 		set_error("decompress_batch_host: NULL argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
-	/* staging layout: 6 u64 arrays + results, then inputs, then outputs */
+	/* In slices like libdeflate_amd_compress_batch_host(): the kernels of
+	 * slice k (compute stream) run while the host packs and sends slice k + 1
+	 * and unpacks slice k - 1 (copy stream).  Slices of at least 256 MiB of
+	 * output: a launch of few streams is latency bound (one wave per stream),
+	 * so small slices cost more kernel time than their overlap saves.
+	 * staging layout: 6 u64 arrays + results, then inputs, then outputs */
+	enum { MAX_SLICES = 8 };
+	size_t bounds[MAX_SLICES + 1];
+	const size_t ns = slice_by_bytes(n, out_avail, MAX_SLICES, (size_t)256 << 20, bounds);
 	std::vector<uint64_t> desc(6 * n);
 	uint64_t *in_off = &desc[0], *in_n = &desc[n], *out_off = &desc[2 * n],
 		 *out_av = &desc[3 * n];
@@ -268,7 +277,6 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 		in_n[i] = in_nbytes[i];
 		pos = align_up(pos + in_nbytes[i] + 16, 16);
 	}
-	size_t out_begin = pos;
 	for (size_t i = 0; i < n; i++) {
 		out_off[i] = pos;
 		out_av[i] = out_avail[i];
@@ -277,38 +285,80 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 	uint8_t *st = (uint8_t *)d->stage.reserve(pos + 64);
 	if (!st)
 		return LIBDEFLATE_AMD_OOM;
+	if (!d->streams.ensure())
+		return LIBDEFLATE_AMD_NO_DEVICE;
+	/* scratch of the largest launch up front (see the compress side) */
+	if (!d->scratch.reserve(align_up(n * 4, 16) + 16 * n + 4 * n + 16))
+		return LIBDEFLATE_AMD_OOM;
+	{
+		size_t grid = (size_t)device_ctx()->num_cus * (size_t)env_cfg().inflate_waves_per_cu;
+		if (grid > n)
+			grid = n;
+		if (env_cfg().inflate_par && !d->tokens.reserve(grid * lda_inflate_tokcap() * 4 + 16))
+			return LIBDEFLATE_AMD_OOM;
+	}
+	hipStream_t s_copy = d->streams.copy, s_comp = d->streams.comp;
 	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
-				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
-	int rc = copy_in_packed(&d->pinned, st, n, in, in_nbytes, in_off, nullptr);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return rc;
+				   s_copy), LIBDEFLATE_AMD_NO_DEVICE);
 	uint64_t *d_desc = (uint64_t *)st;
 	int32_t *d_res = (int32_t *)(st + 6 * n * 8);
-	rc = libdeflate_amd_decompress_batch(
-		d, format, n, st, d_desc, d_desc + n, st, d_desc + 2 * n,
-		d_desc + 3 * n, d_res, d_desc + 4 * n,
-		actual_out ? d_desc + 5 * n : NULL, NULL);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return rc;
-	LDA_HIP_TRY(hipMemcpyAsync(&desc[4 * n], d_desc + 4 * n, 2 * n * 8,
-				   hipMemcpyDeviceToHost, nullptr),
-		    LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipMemcpyAsync(results, d_res, n * 4, hipMemcpyDeviceToHost,
-				   nullptr), LIBDEFLATE_AMD_NO_DEVICE);
-	LDA_HIP_TRY(hipStreamSynchronize(nullptr), LIBDEFLATE_AMD_NO_DEVICE);
-	(void)out_begin;
-	/* bytes to bring back per chunk: the produced ones of successful chunks
-	 * (output is undefined on failure, libdeflate.h:216-217) */
 	std::vector<uint64_t> nout(n);
-	for (size_t i = 0; i < n; i++) {
-		const bool ok = results[i] == LIBDEFLATE_SUCCESS;
-		if (actual_in)
-			actual_in[i] = ok ? desc[4 * n + i] : 0;
-		if (actual_out)
-			actual_out[i] = ok ? desc[5 * n + i] : 0;
-		nout[i] = !ok ? 0 : actual_out ? desc[5 * n + i] : out_avail[i];
+	hipEvent_t ev_done[MAX_SLICES] = {};
+	int rc = LIBDEFLATE_AMD_OK;
+	auto cleanup = [&]() {
+		(void)hipStreamSynchronize(s_comp);
+		(void)hipStreamSynchronize(s_copy);
+		for (size_t k = 0; k < ns; k++)
+			if (ev_done[k])
+				(void)hipEventDestroy(ev_done[k]);
+	};
+	auto drain = [&](size_t k) -> int {
+		const size_t lo = bounds[k], nk = bounds[k + 1] - lo;
+		LDA_HIP_TRY(hipEventSynchronize(ev_done[k]), LIBDEFLATE_AMD_NO_DEVICE);
+		/* bytes to bring back per chunk: the produced ones of successful
+		 * chunks (output is undefined on failure, libdeflate.h:216-217) */
+		for (size_t i = lo; i < lo + nk; i++) {
+			const bool ok = results[i] == LIBDEFLATE_SUCCESS;
+			if (actual_in)
+				actual_in[i] = ok ? desc[4 * n + i] : 0;
+			if (actual_out)
+				actual_out[i] = ok ? desc[5 * n + i] : 0;
+			nout[i] = !ok ? 0 : actual_out ? desc[5 * n + i] : out_avail[i];
+		}
+		return copy_out_packed(&d->pinned, st, nk, out + lo, nout.data() + lo,
+				       out_off + lo, s_copy);
+	};
+	for (size_t k = 0; k < ns && rc == LIBDEFLATE_AMD_OK; k++) {
+		const size_t lo = bounds[k], nk = bounds[k + 1] - lo;
+		rc = copy_in_packed(&d->pinned, st, nk, in + lo, in_nbytes + lo, in_off + lo, s_copy);
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		rc = libdeflate_amd_decompress_batch(
+			d, format, nk, st, d_desc + lo, d_desc + n + lo, st, d_desc + 2 * n + lo,
+			d_desc + 3 * n + lo, d_res + lo, d_desc + 4 * n + lo,
+			actual_out ? d_desc + 5 * n + lo : NULL, s_comp);
+		if (rc != LIBDEFLATE_AMD_OK)
+			break;
+		if (hipMemcpyAsync(&desc[4 * n + lo], d_desc + 4 * n + lo, nk * 8,
+				   hipMemcpyDeviceToHost, s_comp) != hipSuccess ||
+		    (actual_out &&
+		     hipMemcpyAsync(&desc[5 * n + lo], d_desc + 5 * n + lo, nk * 8,
+				    hipMemcpyDeviceToHost, s_comp) != hipSuccess) ||
+		    hipMemcpyAsync(results + lo, d_res + lo, nk * 4, hipMemcpyDeviceToHost,
+				   s_comp) != hipSuccess ||
+		    hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
+		    hipEventRecord(ev_done[k], s_comp) != hipSuccess) {
+			set_error("decompress_batch_host: %s", hipGetErrorString(hipGetLastError()));
+			rc = LIBDEFLATE_AMD_NO_DEVICE;
+			break;
+		}
+		if (k)
+			rc = drain(k - 1);
 	}
-	return copy_out_packed(&d->pinned, st, n, out, nout.data(), out_off, nullptr);
+	if (rc == LIBDEFLATE_AMD_OK)
+		rc = drain(ns - 1);
+	cleanup();
+	return rc;
 }
 
 /* ---- the single-buffer calls: batches of one ---- */
