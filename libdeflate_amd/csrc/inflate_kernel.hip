@@ -52,6 +52,9 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#ifndef PAR_PRIO
+#define PAR_PRIO 1	/* wave-per-stream: issue priority by the share of the input still ahead */
+#endif
 #define LIT_TB 9
 #define OFF_TB 7
 
@@ -1570,6 +1573,29 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				u64 nb = 0, no = 0;
 				if (ring_lo == ~0ull)
 					ring_lo = o0;
+#if PAR_PRIO
+				{
+					/* A launch of one stream per wave slot lasts as long
+					 * as its slowest stream.  The waves of a SIMD share its
+					 * issue slots; the one with most of its input still
+					 * ahead gets them first, so the streams of a CU finish
+					 * closer together (s_setprio takes an immediate). */
+					const u64 inn = bcast64(in_n), left = inn - (bpos0 >> 3);
+#if PAR_PRIO == 2
+					const u32 q = left > 18432 ? 3 : left > 10240 ? 2 : left > 4096 ? 1 : 0;
+#else
+					const u32 q = inn ? (u32)(4 * left / inn) : 0;
+#endif
+					if (q >= 3)
+						__builtin_amdgcn_s_setprio(3);
+					else if (q == 2)
+						__builtin_amdgcn_s_setprio(2);
+					else if (q == 1)
+						__builtin_amdgcn_s_setprio(1);
+					else
+						__builtin_amdgcn_s_setprio(0);
+				}
+#endif
 				u32 pr = par_round(inp0, bcast64(in_n), outp0,
 						   bcast64(out_avail), &SL[0], SH, tok,
 						   (lu8 *)(SH + 1), (lu8 *)(SH + 1) + PAR_RW,
