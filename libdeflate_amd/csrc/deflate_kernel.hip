@@ -130,6 +130,9 @@
 #ifndef S6_ALWAYS_FLUSH
 #define S6_ALWAYS_FLUSH 0
 #endif
+#ifndef S3_HALF_SHIFT
+#define S3_HALF_SHIFT 1		/* the look-ahead positions are searched to depth >> this (the reference: 1) */
+#endif
 #ifndef S3_HALF
 #define S3_HALF 1		/* 0: the lazy rule's look-ahead positions are not searched deeper */
 #endif
@@ -822,6 +825,9 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 {
 	PROF_DECL;
 	PROF_START();
+	/* a serial stretch (the merge is one lane): where other workgroups share
+	 * the CU (small-buffer kernel) it gets its SIMD's issue slots first */
+	__builtin_amdgcn_s_setprio(3);
 	for (u32 s = lane; s < n; s += 64)
 		lens[s] = 0;
 	if (!presorted) {
@@ -1028,6 +1034,7 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 		}
 	}
 	wave_sync();
+	__builtin_amdgcn_s_setprio(0);
 }
 
 /* ---------------- bit output through the LDS staging area ---------------- */
@@ -1979,7 +1986,7 @@ search_items(lds_t *L, AS3 u32 *Mo, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 d
 	if ((tid >> 6) >= nwaves)
 		return;
 	const u32 drain = depth < 8 ? depth : depth >> 3 > 8 ? depth >> 3 : 8;
-	const u32 half = depth >> 1 ? depth >> 1 : 1;
+	const u32 half = depth >> S3_HALF_SHIFT ? depth >> S3_HALF_SHIFT : 1;
 	u32 my_i = 0xFFFFFFFFu, p = 0, cur = 0, c16 = 0, dmaxp = 0,
 	    maxlen = 0, dep = 0, best = 3, bestd = 0, dprev = 0,
 	    cnt = 0, boff = 0, curb = 0, best0 = 3;
@@ -2135,7 +2142,7 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
-	const u32 half = depth >> 1 ? depth >> 1 : 1;
+	const u32 half = depth >> S3_HALF_SHIFT ? depth >> S3_HALF_SHIFT : 1;
 	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;	/* walk passes per generation */
 	const u32 quantum = 8 * npass;
 	const u64 lt = (1ull << lane) - 1;
@@ -2477,7 +2484,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		const u32 dlim3 = mode ? 8192u : 4096u;
 		const u32 ra_depth = ra_all ? depth : S3_RA_DEPTH;
 		const u32 ra_class = ra_all ? DC_FULL :
-				     ra_depth >= (depth >> 1) ? DC_HALF : DC_SHALLOW;
+				     ra_depth >= (depth >> S3_HALF_SHIFT) ? DC_HALF : DC_SHALLOW;
 		/* one batch of 64 per wave: the lazy levels' first generation of
 		 * round B is one round of batches (what is cut off: look-ahead
 		 * positions at the end of a tile, +0.0x % size); lazy2 has twice the
