@@ -205,6 +205,7 @@ struct deflate_lds {
 	u64 lit2A[TILE / 64];	/* runs beside the final parse of the current tile */
 	u32 qn[4];		/* round B: item counts of three generations in rotation */
 	u32 gbase[TILE / 64];	/* emit: first token-list index of each group of 64 positions */
+	u32 rdy[TILE / 64 + 1];	/* round A: the iteration that last finished this group of nxt (+ 1) */
 };
 
 /* LDS-resident: every pointer into the block carries the address space, and
@@ -230,7 +231,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
 	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT,
-	V_CTR2, V_PFLAG, V_RADONE, V_CTR3, V_STDONE, V_EMDONE
+	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE
 };
 
 /* depth classes of the progressive search (done[]): what a position has been
@@ -1475,28 +1476,21 @@ stage_input(lds_t *L, const u8 *__restrict__ inp, u32 loaded, u32 want,
 static __device__ __forceinline__ void
 round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
 	u32 lo_pos, u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3,
-	u32 tid)
+	u32 tag, u32 tid)
 {
 	const u32 lane = tid & 63;
 
 	/* groups of 64 positions are taken from a counter: the two waves that
 	 * insert the next tile meanwhile join in when they are done */
-	bool had = false;
 #pragma unroll 1
 	for (;;) {
 		u32 g = 0;
-		/* (one lane-0 section per round: see the note at the end of the
-		 * body.  The group finished in the round before is counted here:
-		 * its LDS writes are complete - the fence at the end of the body) */
-		if (lane == 0) {
-			if (had)
-				atomicAdd((u32 *)&L->vars[V_RADONE], 1u);
+		/* (ONE lane-0 section per round: see the note at the end of the body) */
+		if (lane == 0)
 			g = atomicAdd((u32 *)&L->vars[V_CTR], 1u);
-		}
 		g = bcast_first(g);
 		if (g >= TILE / 64)
 			break;
-		had = true;
 		const u32 i = 64 * g + lane, p = t + i;
 		const u32 c3v = min_len <= 3 ? c3[4 + i] : 0;
 		bool act = p < tend && p + 4 <= n;
@@ -1571,6 +1565,9 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		L->dhalf[g] = __ballot(dcl >= DC_HALF);
 		L->dfull[g] = __ballot(dcl == DC_FULL);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		/* the group's results are in place: whoever computes the steps of
+		 * the next tile's first parse may take it (every lane stores) */
+		*(volatile AS3 u32 *)&L->rdy[g] = tag;
 	}
 }
 
@@ -1601,10 +1598,13 @@ stage_steps(lds_t *L, s32 limit, u32 mode, u32 nice, u32 tid)
 
 /* the same for groups of 64 positions claimed from a counter (V_CTR3), into
  * the bitmaps of the next tile's first parse; the groups done are counted in
- * V_STDONE.  Ms = the tile's search results (complete: the step of a group's
- * last positions reads the first entries of the next group). */
+ * V_STDONE.  Ms = the tile's search results; a group is taken as soon as round
+ * A has finished it and the next one (rdy[] == tag: the step of a group's last
+ * positions reads the first entries of the next group), so the steps of most
+ * groups are computed while the last groups of round A are still searched. */
 static __device__ __forceinline__ void
-stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, u32 lane)
+stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, u32 tag,
+		    u32 lane)
 {
 	bool had = false;
 
@@ -1620,6 +1620,12 @@ stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, 
 		if (g >= TILE / 64)
 			break;
 		had = true;
+		/* round A may still be working on the tile's last groups: a group's
+		 * steps need its own results and the first two of the next group */
+		while (*(volatile AS3 u32 *)&L->rdy[g] != tag ||
+		       (g + 1 < TILE / 64 && *(volatile AS3 u32 *)&L->rdy[g + 1] != tag))
+			__builtin_amdgcn_s_sleep(2);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		const u32 q = 64 * g + lane, idx = q + 4;
 		u32 st = 1;
 		if ((s32)q < limit)
@@ -2419,6 +2425,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			L->freq[i] = 0;
 		if (tid < 10)
 			L->obs[0][tid] = 0;
+		if (tid < TILE / 64 + 1)
+			L->rdy[tid] = 0;
 		for (u32 i = tid; i < STG_WORDS + 8; i += NT)
 			stg_of(L)[i] = 0;
 		if (tid < 8)
@@ -2689,7 +2697,6 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_CTR] = 0;
 						L->vars[V_CTR2] = 0;
 						L->vars[V_CTR3] = 0;
-						L->vars[V_RADONE] = 0;
 						L->vars[V_STDONE] = 0;
 						L->vars[V_EMDONE] = 0;
 					}
@@ -2783,7 +2790,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 									     NULL, TILE, NWAVES - 2, tid);
 						} else {
 							round_a(L, Mo, c3nxt, tn, tnend, n, lo_nxt, ml_nxt, ra_depth,
-								ra_class, nice, dlim3, tid);
+								ra_class, nice, dlim3, it + 1, tid);
 						}
 					}
 					if (wave == 1)
@@ -2794,8 +2801,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						 * wave 0 (its entry point is where the final parse of
 						 * tile cur, which it ran itself, left) ---- */
 						const s32 lim_n = it + 1 == num_tiles ? (s32)(tnend - tn) : (s32)TILE - 2;
-						wait_lds_eq(L, V_RADONE, TILE / 64);
-						stage_steps_claimed(L, Mo, lim_n, mode, nice, lane);
+						stage_steps_claimed(L, Mo, lim_n, mode, nice, it + 1, lane);
 						if (wave == 0) {
 							u64 mk;
 							wait_lds_eq(L, V_STDONE, TILE / 64);
