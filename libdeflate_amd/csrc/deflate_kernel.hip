@@ -156,6 +156,9 @@
 #define RA_PAIR 1
 #endif
 #endif
+#ifndef GEN_TRIM
+#define GEN_TRIM 1		/* round B: the depth ends with a generation, see search_queue() */
+#endif
 #ifndef GEN_GROW
 #define GEN_GROW 1		/* round B: generation g walks (g + 1) quanta */
 #endif
@@ -2148,9 +2151,22 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
-	const u32 half = depth >> S3_HALF_SHIFT ? depth >> S3_HALF_SHIFT : 1;
 	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;	/* walk passes per generation */
 	const u32 quantum = 8 * npass;
+#if GEN_TRIM
+	/* a depth a few steps past the end of a generation (level 6: 35 = 16 +
+	 * 16 + 3, level 7: 100 = 16 + 32 + 48 + 4) would cost a whole round of
+	 * batches - or a third pass for every batch of the last generation - for
+	 * those few steps: up to an eighth of the depth is given up instead */
+	for (u32 g = 1, end = quantum; end < depth; g++, end += quantum * (GEN_GROW ? g : 1))
+		if (depth - end <= depth / 8)
+			depth = end;
+	/* and the same for a pass of 8 steps (level 6: 35 -> 32, two passes in
+	 * the second generation instead of three) */
+	if (depth >= 16 && (depth & 7) <= depth / 8)
+		depth &= ~7u;
+#endif
+	const u32 half = depth >> S3_HALF_SHIFT ? depth >> S3_HALF_SHIFT : 1;
 	const u64 lt = (1ull << lane) - 1;
 	u32 ncur = wc;
 #ifdef LDA_PROFILE
