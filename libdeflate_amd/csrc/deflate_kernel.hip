@@ -2600,6 +2600,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					__syncthreads();
 					PROF_MARK(6);
 				}
+				/* the input of the tile that S0 stages below is requested now:
+				 * its trip from HBM runs beside round B */
+				const u32 s0_want0 = (it + 2) * TILE + LOOKAHEAD;
+				const u32 s0_want = s0_want0 < n ? s0_want0 : n;
+				const u32 s0_p = (loaded & ~15u) + tid * 16;
+				const bool s0_pre = aligned_in && s0_p < s0_want;
+				uint4 s0_v = make_uint4(0, 0, 0, 0);
+				if (s0_pre)
+					s0_v = *(const uint4 *)(inp + s0_p);
 				if (cur_real && !optm) {
 					/* ---- S3 round B: the positions the first parse visited
 					 * (pmA: it ran beside phase X of the iteration before) are
@@ -2705,9 +2714,18 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				 * the shallow search of tile nxt reads and what the insertion
 				 * of tile it + 1 hashes ---- */
 				{
-					const u32 want0 = (it + 2) * TILE + LOOKAHEAD;
-					const u32 want = want0 < n ? want0 : n;
-					stage_input(L, inp, loaded, want, aligned_in, tid);
+					const u32 want = s0_want;
+					if (s0_pre) {
+						*(uint4 *)&L->in[s0_p & RMASK] = s0_v;
+						if ((s0_p & RMASK) < 32)
+							*(uint4 *)&L->in[RING + (s0_p & RMASK)] = s0_v;
+					}
+					if (aligned_in) {	/* (more than one unit per thread: first tile only) */
+						if ((loaded & ~15u) + NT * 16 < want)
+							stage_input(L, inp, (loaded & ~15u) + NT * 16, want, true, tid);
+					} else {
+						stage_input(L, inp, loaded, want, false, tid);
+					}
 					loaded = want > loaded ? want : loaded;
 					if (tid == 0) {
 						L->vars[V_CTR] = 0;
