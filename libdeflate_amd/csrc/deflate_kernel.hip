@@ -436,18 +436,29 @@ find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 {
 	if (dmax > dlim)
 		dmax = dlim;
-	u32 want = cur & 0xFFFFFFu;
 	if (p >= 8) {
-		u64 w8 = ld64(L->in, p - 8);
-#pragma unroll
-		for (u32 d = 1; d <= 8; d++) {
-			u64 t = w8 >> (8 * (8 - d));
-			if (d < 3)
-				t |= (u64)cur << (8 * d);
-			if (d <= dmax && ((u32)t & 0xFFFFFFu) == want) {
-				*best = 3;
-				return d;
-			}
+		/* the eight nearest distances without a branch: the three bytes at
+		 * p - d for d = 8..1 are byte windows of (p-8..p-5, p-4..p-1, cur) -
+		 * one funnel shift each - and the smallest matching distance is the
+		 * lowest set bit of the eight comparison results */
+		const u64 w8 = ld64(L->in, p - 8);
+		const u32 A = (u32)w8, B = (u32)(w8 >> 32);
+		u32 m = 0;
+#define LEN3_TRY(d, x) m |= ((((x) ^ cur) & 0xFFFFFFu) == 0) << ((d) - 1)
+		LEN3_TRY(8, A);
+		LEN3_TRY(7, __builtin_amdgcn_alignbyte(B, A, 1));
+		LEN3_TRY(6, __builtin_amdgcn_alignbyte(B, A, 2));
+		LEN3_TRY(5, __builtin_amdgcn_alignbyte(B, A, 3));
+		LEN3_TRY(4, B);
+		LEN3_TRY(3, __builtin_amdgcn_alignbyte(cur, B, 1));
+		LEN3_TRY(2, __builtin_amdgcn_alignbyte(cur, B, 2));
+		LEN3_TRY(1, __builtin_amdgcn_alignbyte(cur, B, 3));
+#undef LEN3_TRY
+		if (dmax < 8)
+			m &= (1u << dmax) - 1;
+		if (m) {
+			*best = 3;
+			return (u32)__builtin_ctz(m) + 1;
 		}
 	}
 	u32 d = (p - c3_16) & 0xFFFF;
