@@ -2325,9 +2325,12 @@ split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
 	}
 	u32 nprev = 0, nnew = 0;
 	u64 delta = 0;
+	/* (one LDS round trip for the ten words, then lane reads: wave-uniform
+	 * values, scalar arithmetic) */
+	const u32 ov = lane < 10 ? L->obs[0][lane] : 0;
 #pragma unroll
 	for (u32 i = 0; i < 10; i++) {
-		oprev[i] = bcast_first(L->obs[0][i]);	/* wave-uniform: scalar arithmetic */
+		oprev[i] = (u32)__builtin_amdgcn_readlane((int)ov, i);
 		nprev += oprev[i];
 		nnew += onow[i] - oprev[i];
 	}
