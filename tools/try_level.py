@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""try_level.py LEVEL SIZE [COUNT] - compress COUNT chunks of SIZE bytes of the
+benchmark mix at LEVEL through the host-pointer batch call and decode them
+with zlib: the smallest possible "does this build still work" run, meant to be
+started under `timeout` when a change to the compress kernel's wave hand-overs
+could hang it."""
 import sys, zlib
 sys.path.insert(0, '/root/repo')
 from libdeflate_amd import api
