@@ -124,9 +124,6 @@
 #ifndef S3_RA_DEPTH
 #define S3_RA_DEPTH 2u		/* chain members the shallow pass measures at every position */
 #endif
-#ifndef S3_ITEMS_PER_WAVE
-#define S3_ITEMS_PER_WAVE 384u	/* round B: one more wave joins per so many items */
-#endif
 #ifndef S6_ALWAYS_FLUSH
 #define S6_ALWAYS_FLUSH 0
 #endif
@@ -236,7 +233,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
-	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_PEXIT,
+	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_UNUSED0,
 	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE
 };
 
@@ -2555,9 +2552,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		 * tile cur - the parse is one wave's serial walk and the emission
 		 * starts when it ends, the insertion is one wave's serial instruction
 		 * stream, and the shallow search is what fills the other waves'
-		 * issue slots meanwhile.  The search results of tile nxt land in MX
-		 * (the LDS of the round-B lists and the bit staging area, both idle
-		 * in that phase) and move to M[] at the top of the next iteration.
+		 * issue slots meanwhile; the step bitmaps and the FIRST parse of
+		 * tile nxt follow inside the same phase as soon as its groups are
+		 * searched, and the split statistics of cur as soon as its tokens
+		 * are out.  The search results of tile nxt land in MX (the LDS of
+		 * the round-B lists and the bit staging area, both idle in that
+		 * phase) and move to M[] at the top of the next iteration.  The
+		 * hand-overs inside the phase are LDS words polled with s_sleep
+		 * (V_PFLAG, rdy[], V_STDONE, V_EMDONE): every wait is for work that
+		 * some wave is already doing or will do without waiting itself.
 		 * Iteration 0 has no cur: it inserts tile 0 and runs phase X for
 		 * tile 0 alone; dictionary tiles (segment mode) are only inserted.
 		 */
