@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/libdeflate_amd.h"
@@ -34,6 +35,10 @@ struct DeviceCtx {
 	std::mutex stage_mu;
 	void *d_stage = nullptr;
 	size_t stage_cap = 0;
+	/* the kernels' dynamic-LDS limits are raised once per device (setting
+	 * them again is harmless, so a race between two first calls only repeats
+	 * it); part of the context so that no table is indexed by a device id */
+	std::atomic<bool> deflate_attr_set{false}, inflate_attr_set{false};
 };
 
 /* context of the calling thread's current device; nullptr (+error) if none */
@@ -75,6 +80,16 @@ struct PinnedPair {
 	 * few KiB: 64 KiB at least, LDA_PINNED_SLICE at most per buffer); false
 	 * + error if pinned memory is unavailable */
 	bool ensure(size_t want);
+	void release();
+};
+/* a small grow-only pinned buffer: what a batch reads back per chunk (sizes,
+ * offsets, result codes).  An asynchronous copy to pageable memory is staged
+ * by the runtime and blocks the host until the stream gets there; to pinned
+ * memory it is a real asynchronous copy and the host looks after the event */
+struct PinnedBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	void *ensure(size_t want);	/* nullptr + error on failure */
 	void release();
 };
 #define LDA_PINNED_SLICE ((size_t)32 << 20)

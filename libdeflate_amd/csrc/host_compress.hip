@@ -89,6 +89,7 @@ libdeflate_free_compressor(struct libdeflate_compressor *c)
 	c->scratch.release();
 	c->stage.release();
 	c->pinned.release();
+	c->meta.release();
 	c->streams.release();
 	free_func_t f = c->free_func;
 	c->~libdeflate_compressor();
@@ -166,11 +167,8 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		if (rc != LIBDEFLATE_AMD_OK)
 			return rc;
 	}
-	/* once per device (setting it again is harmless, so a race between two
-	 * first calls only repeats it) */
-	static std::atomic<bool> attr_set[16];
 	const size_t lds = small ? lda_deflate_small_lds_bytes() : lda_deflate_lds_bytes();
-	if (!attr_set[ctx->device].load(std::memory_order_acquire)) {
+	if (!ctx->deflate_attr_set.load(std::memory_order_acquire)) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_deflate_small_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -183,7 +181,7 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 				(const void *)lda_deflate_opt_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)lda_deflate_lds_bytes()), LIBDEFLATE_AMD_NO_DEVICE);
-		attr_set[ctx->device].store(true, std::memory_order_release);
+		ctx->deflate_attr_set.store(true, std::memory_order_release);
 	}
 	const level_cfg &lv = k_levels[c->level];
 	hipLaunchKernelGGL(small ? lda_deflate_small_kernel :
@@ -286,18 +284,37 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 		return LIBDEFLATE_AMD_OOM;
 	if (!c->streams.ensure())
 		return LIBDEFLATE_AMD_NO_DEVICE;
+	size_t max_in = 0;
+	for (size_t i = 0; i < n; i++)
+		max_in = in_nbytes[i] > max_in ? in_nbytes[i] : max_in;
 	/* the kernels' scratch for the largest launch up front: growing it between
-	 * two slices would free memory a running kernel uses (and synchronise) */
-	if (!c->scratch.reserve((size_t)device_ctx()->num_cus * 3 * lda_deflate_seq_words() * 8 +
-				16 + n * 4))
+	 * two slices would free memory a running kernel uses (and synchronise).
+	 * Sized by the launches that are made (compress_batch_impl(): one token
+	 * list per workgroup, the grid never larger than the slice) - a one-shot
+	 * call on a small buffer reserves one list, not a device's worth */
+	{
+		size_t max_nk = 0;
+		for (size_t k = 0; k < ns; k++)
+			max_nk = bounds[k + 1] - bounds[k] > max_nk ? bounds[k + 1] - bounds[k] : max_nk;
+		const bool small = max_in <= lda_deflate_small_max() && c->level <= 9 &&
+				   !env_cfg().no_small;
+		const size_t grid_max = (size_t)device_ctx()->num_cus * (small ? 3 : 1);
+		const size_t grid = max_nk < grid_max ? max_nk : grid_max;
+		if (!c->scratch.reserve(grid * lda_deflate_seq_words() * 8 + 16 + max_nk * 4))
+			return LIBDEFLATE_AMD_OOM;
+	}
+	/* what comes back per slice (sizes, compaction offsets) lands in pinned
+	 * memory, so the copies are asynchronous and the host is free to pack the
+	 * next slice while this one's kernels run */
+	uint64_t *h_back = (uint64_t *)c->meta.ensure((n + ncmp) * 8);
+	if (!h_back)
 		return LIBDEFLATE_AMD_OOM;
+	out_n = h_back;
+	cmp_off = h_back + n;
 	hipStream_t s_copy = c->streams.copy, s_comp = c->streams.comp;
 	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
 				   s_copy), LIBDEFLATE_AMD_NO_DEVICE);
 	uint64_t *d_desc = (uint64_t *)st;
-	size_t max_in = 0;
-	for (size_t i = 0; i < n; i++)
-		max_in = in_nbytes[i] > max_in ? in_nbytes[i] : max_in;
 	hipEvent_t ev_done[MAX_SLICES] = {};
 	int rc = LIBDEFLATE_AMD_OK;
 	auto cleanup = [&]() {

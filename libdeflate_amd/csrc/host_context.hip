@@ -103,6 +103,33 @@ bool PinnedPair::ensure(size_t want)
 	return true;
 }
 
+void *PinnedBuf::ensure(size_t want)
+{
+	if (want <= cap)
+		return p;
+	size_t ncap = 4096;
+	while (ncap < want)
+		ncap <<= 1;
+	void *np = nullptr;
+	hipError_t e = hipHostMalloc(&np, ncap, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		set_error("pinned read-back buffer (%zu bytes): %s", ncap, hipGetErrorString(e));
+		return nullptr;
+	}
+	release();
+	p = np;
+	cap = ncap;
+	return p;
+}
+
+void PinnedBuf::release()
+{
+	if (p)
+		(void)hipHostFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
 bool StreamPair::ensure()
 {
 	if (copy && comp)
@@ -182,17 +209,27 @@ template <typename F> static void for_chunks_parallel(size_t lo, size_t hi, uint
 	}
 	std::thread th[16];
 	const size_t per = (hi - lo + nt - 1) / nt;
-	size_t started = 0;
+	size_t started = 0, own_hi = lo + per < hi ? lo + per : hi;
 	for (size_t t = 1; t < nt; t++) {
 		const size_t a = lo + t * per, b = a + per < hi ? a + per : hi;
 		if (a >= hi)
 			break;
-		th[started++] = std::thread([=]() {
-			for (size_t k = a; k < b; k++)
+		/* a thread that cannot be created (EAGAIN under a thread or cgroup
+		 * limit) must not unwind through the extern "C" entry points: the
+		 * calling thread takes the rest */
+		try {
+			th[started] = std::thread([=]() {
+				for (size_t k = a; k < b; k++)
+					fn(k);
+			});
+			started++;
+		} catch (...) {
+			for (size_t k = a; k < hi; k++)
 				fn(k);
-		});
+			break;
+		}
 	}
-	for (size_t k = lo; k < (lo + per < hi ? lo + per : hi); k++)
+	for (size_t k = lo; k < own_hi; k++)
 		fn(k);
 	for (size_t t = 0; t < started; t++)
 		th[t].join();
@@ -240,10 +277,12 @@ int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
 		b ^= 1;
 		i = j;
 	}
-	/* the pinned buffers are reused by the caller's next step */
-	for (b = 0; b < 2; b++)
-		if (used[b])
-			LDA_HIP_TRY(hipEventSynchronize(pp->ev[b]), LIBDEFLATE_AMD_NO_DEVICE);
+	/* "returns when the slice is on the device": the kernels that read it run
+	 * on ANOTHER stream, so everything queued on this one has to have landed -
+	 * the packed slices (whose pinned buffers the caller's next step reuses),
+	 * the chunks copied straight from the caller's memory, and whatever the
+	 * caller queued in front (its descriptor upload) */
+	LDA_HIP_TRY(hipStreamSynchronize(st), LIBDEFLATE_AMD_NO_DEVICE);
 	return LIBDEFLATE_AMD_OK;
 }
 

@@ -114,6 +114,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->stage.release();
 	d->tokens.release();
 	d->pinned.release();
+	d->meta.release();
 	d->streams.release();
 	free_func_t f = d->free_func;
 	d->~libdeflate_decompressor();
@@ -171,15 +172,14 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 	 * is small next to the machine (4096 streams on 1024 SIMDs) runs at the
 	 * rate of a huge one.  LDA_INFLATE_PAR=0 selects lane-per-stream. */
 	const bool par = env_cfg().inflate_par;
-	static std::atomic<bool> attr_set[16];
-	if (!attr_set[c->device].load(std::memory_order_acquire)) {
+	if (!c->inflate_attr_set.load(std::memory_order_acquire)) {
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_inflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
 				(int)(lda_inflate_lds_per_stream() * 64 +
 				      lda_inflate_lds_shared())),
 			    LIBDEFLATE_AMD_NO_DEVICE);
-		attr_set[c->device].store(true, std::memory_order_release);
+		c->inflate_attr_set.store(true, std::memory_order_release);
 	}
 	if (par) {
 		const size_t per_cu = (size_t)env_cfg().inflate_waves_per_cu;	/* tuning */
@@ -267,7 +267,7 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 	enum { MAX_SLICES = 8 };
 	size_t bounds[MAX_SLICES + 1];
 	const size_t ns = slice_by_bytes(n, out_avail, MAX_SLICES, (size_t)256 << 20, bounds);
-	std::vector<uint64_t> desc(6 * n);
+	std::vector<uint64_t> desc(4 * n);
 	uint64_t *in_off = &desc[0], *in_n = &desc[n], *out_off = &desc[2 * n],
 		 *out_av = &desc[3 * n];
 	size_t desc_bytes = align_up(6 * n * 8 + n * 4, 64);
@@ -297,6 +297,13 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 		if (env_cfg().inflate_par && !d->tokens.reserve(grid * lda_inflate_tokcap() * 4 + 16))
 			return LIBDEFLATE_AMD_OOM;
 	}
+	/* per-chunk read-backs land in pinned memory (asynchronous for real) and
+	 * go to the caller's arrays in drain() */
+	uint64_t *h_back = (uint64_t *)d->meta.ensure(n * (8 + 8 + 4));
+	if (!h_back)
+		return LIBDEFLATE_AMD_OOM;
+	uint64_t *h_ain = h_back, *h_aout = h_back + n;
+	int32_t *h_res = (int32_t *)(h_back + 2 * n);
 	hipStream_t s_copy = d->streams.copy, s_comp = d->streams.comp;
 	LDA_HIP_TRY(hipMemcpyAsync(st, desc.data(), 4 * n * 8, hipMemcpyHostToDevice,
 				   s_copy), LIBDEFLATE_AMD_NO_DEVICE);
@@ -318,12 +325,13 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 		/* bytes to bring back per chunk: the produced ones of successful
 		 * chunks (output is undefined on failure, libdeflate.h:216-217) */
 		for (size_t i = lo; i < lo + nk; i++) {
+			results[i] = h_res[i];
 			const bool ok = results[i] == LIBDEFLATE_SUCCESS;
 			if (actual_in)
-				actual_in[i] = ok ? desc[4 * n + i] : 0;
+				actual_in[i] = ok ? h_ain[i] : 0;
 			if (actual_out)
-				actual_out[i] = ok ? desc[5 * n + i] : 0;
-			nout[i] = !ok ? 0 : actual_out ? desc[5 * n + i] : out_avail[i];
+				actual_out[i] = ok ? h_aout[i] : 0;
+			nout[i] = !ok ? 0 : actual_out ? h_aout[i] : out_avail[i];
 		}
 		return copy_out_packed(&d->pinned, st, nk, out + lo, nout.data() + lo,
 				       out_off + lo, s_copy);
@@ -339,12 +347,12 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 			actual_out ? d_desc + 5 * n + lo : NULL, s_comp);
 		if (rc != LIBDEFLATE_AMD_OK)
 			break;
-		if (hipMemcpyAsync(&desc[4 * n + lo], d_desc + 4 * n + lo, nk * 8,
+		if (hipMemcpyAsync(h_ain + lo, d_desc + 4 * n + lo, nk * 8,
 				   hipMemcpyDeviceToHost, s_comp) != hipSuccess ||
 		    (actual_out &&
-		     hipMemcpyAsync(&desc[5 * n + lo], d_desc + 5 * n + lo, nk * 8,
+		     hipMemcpyAsync(h_aout + lo, d_desc + 5 * n + lo, nk * 8,
 				    hipMemcpyDeviceToHost, s_comp) != hipSuccess) ||
-		    hipMemcpyAsync(results + lo, d_res + lo, nk * 4, hipMemcpyDeviceToHost,
+		    hipMemcpyAsync(h_res + lo, d_res + lo, nk * 4, hipMemcpyDeviceToHost,
 				   s_comp) != hipSuccess ||
 		    hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
 		    hipEventRecord(ev_done[k], s_comp) != hipSuccess) {

@@ -35,6 +35,7 @@ struct libdeflate_decompressor {
 	lda::DevBuf stage;	/* host-pointer entry points */
 	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
 	lda::PinnedPair pinned;	/* host-pointer entry points */
+	lda::PinnedBuf meta;	/* host-pointer entry points: per-chunk read-backs */
 	lda::StreamPair streams;	/* host-pointer entry points: transfers / kernels */
 };
 
@@ -44,6 +45,7 @@ struct libdeflate_compressor {
 	lda::DevBuf scratch;	/* parse/encode workspace + per-chunk sums */
 	lda::DevBuf stage;
 	lda::PinnedPair pinned;	/* host-pointer entry points */
+	lda::PinnedBuf meta;	/* host-pointer entry points: per-chunk read-backs */
 	lda::StreamPair streams;	/* host-pointer entry points: transfers / kernels */
 };
 

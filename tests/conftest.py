@@ -28,3 +28,27 @@ def ref():
     if r is None:
         pytest.skip("oracle/_ref/libdeflate_ref.so not built")
     return r
+
+
+_LDA_SWITCHES = ("LDA_INFLATE_PAR", "LDA_INFLATE_LPW", "LDA_INFLATE_WAVES_PER_CU",
+                 "LDA_NO_SMALL", "LDA_NO_SEGMENTS", "LDA_HOST_THREADS",
+                 "LDA_NO_STREAM_PAR", "LDA_STREAM_PAR_MIN")
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_switches():
+    """The library reads its tuning switches once; tests that change them call
+    binding.reload_env().  After every test the switches are put back and the
+    library re-reads them, so the tests that follow run the default kernels
+    again (monkeypatch may already have restored the environment by the time
+    this teardown runs, which is why the re-read is unconditional)."""
+    before = {k: os.environ.get(k) for k in _LDA_SWITCHES}
+    yield
+    for k, v in before.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    from libdeflate_amd import binding
+    if binding._lib is not None:
+        binding.reload_env()

@@ -422,3 +422,71 @@ def bad_distance_streams():
         co = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=zdict)
         out.append(co.compress(body) + co.flush())
     return out
+
+
+def _take_bytes(gen_block, nbytes):
+    """The first nbytes of an endless sequence of blocks: what the reference's
+    generators leave when put_bits() runs out of buffer
+    (programs/test_util.c:210-228, test_slow_decompression.c:24-27)."""
+    w = BitWriter()
+    while len(w.out) < nbytes:
+        gen_block(w)
+    return bytes(w.out[:nbytes])
+
+
+def empty_static_blocks(nbytes=4096):
+    """test_slow_decompression.c:18-30: BFINAL=0, static Huffman, end of block,
+    over and over; the stream runs into the end of its buffer."""
+    def block(w):
+        w.put(0, 1)
+        w.put(1, 2)
+        w.put(0, 7)     # litlen symbol 256
+    return _take_bytes(block, nbytes)
+
+
+def empty_dynamic_blocks(nbytes=4096):
+    """test_slow_decompression.c:32-108: the smallest dynamic block - litlen
+    code {256: 1 bit}, offset code {0: 1 bit}, precode {1: 1 bit, 18: 1 bit} -
+    holding nothing but its end-of-block symbol, over and over."""
+    def block(w):
+        w.put(0, 1)         # BFINAL
+        w.put(2, 2)         # dynamic
+        w.put(0, 5)         # 257 litlen symbols
+        w.put(0, 5)         # 1 offset symbol
+        w.put(14, 4)        # 18 explicit precode lengths
+        for _ in range(2):
+            w.put(0, 3)     # presym 16, 17
+        w.put(1, 3)         # presym 18: 1 bit
+        for _ in range(14):
+            w.put(0, 3)
+        w.put(1, 3)         # presym 1: 1 bit
+        for _ in range(2):
+            w.put(1, 1)     # presym 18 ...
+            w.put(117, 7)   # ... 128 zeros
+        w.put(0, 1)         # presym 1 (litlen 256)
+        w.put(0, 1)         # presym 1 (offset 0)
+        w.put(0, 1)         # end of block
+    return _take_bytes(block, nbytes)
+
+
+def damage(stream, cut=None, flip=None):
+    """A variant of a valid stream: its first `cut` bytes, or bit 4 of byte
+    `flip` inverted (tests/golden/golden_64k.json stores each stream once)."""
+    s = bytearray(stream)
+    if flip is not None:
+        s[flip] ^= 0x10
+    return bytes(s if cut is None else s[:cut])
+
+
+def golden_64k_cases(path):
+    """(fmt, stream, avail, want, tag, expected-dict) per variant of
+    tests/golden/golden_64k.json."""
+    import base64
+    import json
+    with open(path) as f:
+        g = json.load(f)
+    for st in g["streams"]:
+        z = base64.b64decode(st["stream_b64"])
+        for v in st["variants"]:
+            yield (st["fmt"], damage(z, v["cut"], v["flip"]), v["avail"],
+                   v["want_out"], f'{st["tag"]}/{v["name"]}', v)

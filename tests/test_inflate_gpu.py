@@ -43,6 +43,39 @@ def _run_cases(dec, oracle, cases):
                 assert g[3] == o[3], (cs[4], "bytes differ")
 
 
+def _device_batch_timed(dec, fmt, chunks, avail):
+    """The chunks as one device batch (HBM to HBM): result codes and the
+    milliseconds of the second of two runs (HIP events around the call)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = len(chunks)
+    offs, blob = [], bytearray()
+    for c in chunks:
+        offs.append(len(blob))
+        blob += c
+        blob += bytes(-len(blob) % 16)
+    data = torch.frombuffer(bytearray(blob) + bytearray(64), dtype=torch.uint8).to(dev)
+    in_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    in_n = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=dev)
+    slot = (avail + 15) // 16 * 16
+    out = torch.zeros(n * slot + 64, dtype=torch.uint8, device=dev)
+    out_off = torch.arange(n, dtype=torch.int64, device=dev) * slot
+    out_av = torch.full((n,), avail, dtype=torch.int64, device=dev)
+    res = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ain = torch.zeros(n, dtype=torch.int64, device=dev)
+    aout = torch.zeros(n, dtype=torch.int64, device=dev)
+    ms = 0.0
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dec.decompress_batch(fmt, data, in_off, in_n, out, out_off, out_av, res, ain, aout,
+                             stream=torch.cuda.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+    return res.cpu().tolist(), ms
+
+
 def test_reference_unit_test_vectors(dec, oracle):
     cases = []
     for i, (s, want) in enumerate([streams.incomplete_empty_offset_code(),
@@ -92,6 +125,64 @@ def test_golden_fixtures(dec):
                 if want:
                     assert r[2] == cs["actual_out"], cs["tag"]
                 assert zlib.crc32(r[3]) == cs["out_crc32"], cs["tag"]
+
+
+def test_golden_64k_fixtures(dec):
+    """64 KiB chunks of the benchmark mix compressed by the real reference
+    (committed, so config-sized parity does not rest on oracle/_ref being on
+    the box), valid and damaged, both mappings."""
+    cases = list(streams.golden_64k_cases(os.path.join(GOLDEN, "golden_64k.json")))
+    assert len(cases) == 50
+    for mode in ("1", "0"):
+        os.environ["LDA_INFLATE_PAR"] = mode
+        binding.reload_env()
+        for want in (True, False):
+            grp = [c for c in cases if c[3] == want]
+            for fmt in ("deflate", "zlib", "gzip"):
+                g2 = [c for c in grp if c[0] == fmt]
+                got = dec.decompress_batch_host(fmt, [c[1] for c in g2],
+                                                [c[2] for c in g2], want)
+                for c, r in zip(g2, got):
+                    exp = c[5]
+                    assert r[0] == exp["result"], (mode, c[4])
+                    if r[0] == 0:
+                        assert r[1] == exp["actual_in"], c[4]
+                        if want:
+                            assert r[2] == exp["actual_out"], c[4]
+                        assert zlib.crc32(r[3]) == exp["out_crc32"], c[4]
+
+
+def test_slow_decompression_vectors(dec, oracle):
+    """programs/test_slow_decompression.c: streams that open a new Huffman
+    block every few bits (:18-108) and the blob of issue #33 (in golden.json)
+    must come back BAD_DATA or INSUFFICIENT_SPACE (:128-129) - in both
+    mappings, with the oracle's verdict - and a whole batch of them must not
+    keep the device for long: the block headers are the serial part of this
+    decoder (lane 0 of the stream's wave)."""
+    import time
+    import torch
+    vec = [streams.empty_static_blocks(), streams.empty_dynamic_blocks()]
+    cases = []
+    for i, s in enumerate(vec):
+        for want in (True, False):
+            cases.append(("deflate", s, 10000, want, f"slow{i}"))
+    for mode in ("1", "0"):
+        os.environ["LDA_INFLATE_PAR"] = mode
+        binding.reload_env()
+        _run_cases(dec, oracle, cases)
+        for s in vec:
+            assert dec.decompress_ex("deflate", s, 10000)[0] in (1, 3)
+    os.environ.pop("LDA_INFLATE_PAR")
+    binding.reload_env()
+    # 4096 such streams as one device batch (the shape of BASELINE configs[3]
+    # with the worst input there is): time it
+    for name, s in (("static", vec[0]), ("dynamic", vec[1])):
+        n = 4096
+        got, ms = _device_batch_timed(dec, "deflate", [s] * n, 10000)
+        assert all(r in (1, 3) for r in got), name
+        print(f"slow_decompression batch, {name}: {n} x 4 KiB in {ms:.2f} ms "
+              f"({n * 4096 / ms / 1e3:.1f} MB/s of input)")
+        assert ms < 2000, (name, ms)
 
 
 def test_randomized_vs_oracle(dec, oracle):

@@ -93,6 +93,36 @@ def test_golden_fixtures(oracle):
         assert oracle.adler32(d, cs["adler_init"]) == cs["adler32"]
 
 
+def test_golden_64k_fixtures(oracle):
+    """Config-sized streams (64 KiB chunks of the benchmark mix) compressed
+    by the real reference, valid and damaged."""
+    n = 0
+    for fmt, s, avail, want, tag, exp in streams.golden_64k_cases(
+            os.path.join(GOLDEN, "golden_64k.json")):
+        r, ain, aout, out = oracle.decompress_ex(fmt, s, avail, want)
+        assert r == exp["result"], tag
+        if r == 0:
+            assert ain == exp["actual_in"], tag
+            if want:
+                assert aout == exp["actual_out"], tag
+            assert oracle.crc32(out) == exp["out_crc32"], tag
+        n += 1
+    assert n == 50
+
+
+def test_slow_decompression_vectors(oracle):
+    """programs/test_slow_decompression.c:18-108,128-129: streams of nothing
+    but empty blocks must end in BAD_DATA or INSUFFICIENT_SPACE."""
+    for s in (streams.empty_static_blocks(), streams.empty_dynamic_blocks()):
+        assert len(s) == 4096
+        for want in (True, False):
+            assert oracle.decompress_ex("deflate", s, 10000, want)[0] in (1, 3)
+    # one complete empty dynamic block, made final, is a valid stream of 0 bytes
+    one = bytearray(streams.empty_dynamic_blocks(64))
+    one[0] |= 1
+    assert oracle.decompress_ex("deflate", bytes(one), 0)[:3] == (0, 12, 0)
+
+
 def test_live_against_reference(oracle, ref):
     comp = lambda fmt, lvl, d: ref.compress(fmt, lvl, d)
     cases = streams.random_cases(11, 250, compress=comp)

