@@ -346,6 +346,21 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 				     size_t *actual_out /* NULL allowed */);
 
 /*
+ * What the last single-buffer libdeflate_*_decompress[_ex] call of this thread
+ * did with its stream (diagnostics; tests use it to see that a large stream
+ * really went over many waves): [0] 1 = decoded on the many-wave path, 0 = on
+ * one wave; [1] why not (0 none, 1 switched off or too small, 2 container
+ * header, 3 chain, 4 a chunk failed, 5 no final block, 6 output does not fit,
+ * 7 output does not fill, 8 decode pass disagrees, 9 device, 10 too many
+ * repairs); [2] bit offsets that passed the first filter of the block finder;
+ * [3] block starts found; [4] chunks planned; [5] repairs; [6] chunks decoded;
+ * [7] bytes produced.
+ */
+#define LIBDEFLATE_AMD_STREAM_STATS 8
+LIBDEFLATEAPI void
+libdeflate_amd_stream_stats(uint64_t *out /* [8] */);
+
+/*
  * A gzip buffer of SEVERAL members (concatenated .gz files, pigz -i, BGZF).
  * libdeflate_gzip_decompress decodes the first member only
  * (lib/gzip_decompress.c:103-131, libdeflate.h:289-296); its caller loops, as

@@ -46,6 +46,7 @@ BATCH_SYMBOLS = [
     "libdeflate_amd_decompress_batch_host",
     "libdeflate_amd_compact_offsets_len", "libdeflate_amd_compact_batch",
     "libdeflate_amd_gzip_decompress_members",
+    "libdeflate_amd_stream_stats",
 ]
 
 _lib = None
@@ -114,6 +115,7 @@ def load():
     sig("libdeflate_amd_decompress_batch_host", c_int, P, c_int, SZ, P, P, P,
         P, P, P, P)
     sig("libdeflate_amd_gzip_decompress_members", c_int, P, P, SZ, P, SZ, psz, psz, psz)
+    sig("libdeflate_amd_stream_stats", None, POINTER(c_uint64))
     sig("libdeflate_amd_compact_offsets_len", SZ, SZ)
     sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib
@@ -124,6 +126,16 @@ def reload_env():
     """Have the library read its LDA_* tuning switches again (it reads them
     once, at load)."""
     load().libdeflate_amd_reload_env()
+
+
+def stream_stats():
+    """libdeflate_amd_stream_stats: what the last single-buffer decompress
+    call of this thread did (see include/libdeflate_amd.h)."""
+    out = (c_uint64 * 8)()
+    load().libdeflate_amd_stream_stats(out)
+    keys = ("parallel", "why_not", "filter_a", "blocks_found", "chunks_planned",
+            "repairs", "chunks_decoded", "bytes")
+    return dict(zip(keys, [int(v) for v in out]))
 
 
 def last_error():

@@ -53,6 +53,9 @@ struct EnvCfg {
 	bool inflate_par = true;	/* LDA_INFLATE_PAR */
 	int inflate_waves_per_cu = 16;	/* LDA_INFLATE_WAVES_PER_CU */
 	int host_threads = 4;		/* LDA_HOST_THREADS: packing threads of the host-pointer batches */
+	bool no_stream_par = false;	/* LDA_NO_STREAM_PAR: single streams stay on one wave */
+	size_t stream_par_min = 32768;	/* LDA_STREAM_PAR_MIN: smallest stream (bytes in) for the many-wave path */
+	size_t stream_chunk = 0;	/* LDA_STREAM_CHUNK: input bytes per chunk of that path (0 = by size) */
 };
 const EnvCfg &env_cfg();
 
@@ -125,6 +128,11 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		    const uint64_t *off, hipStream_t st);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* checksum of A || B from the checksums of A and B and the length of B
+ * (host_compress.hip) */
+uint32_t crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+uint32_t adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b);
 
 } /* namespace lda */
 

@@ -397,7 +397,7 @@ static uint32_t crc_mulmod(uint32_t a, uint32_t b)
 	return p;
 }
 
-static uint32_t crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+uint32_t lda::crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
 {
 	uint32_t xp = 0x80000000u;	/* 1 */
 	uint32_t base = 0x00800000u;	/* x^8 */
@@ -409,7 +409,7 @@ static uint32_t crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
 	return crc_mulmod(crc_a, xp) ^ crc_b;
 }
 
-static uint32_t adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b)
+uint32_t lda::adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b)
 {
 	const uint32_t M = 65521;
 	uint32_t a1 = ad_a & 0xFFFF, b1 = ad_a >> 16;

@@ -113,6 +113,10 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->scratch.release();
 	d->stage.release();
 	d->tokens.release();
+	d->sin.release();
+	d->schunks.release();
+	d->ssym.release();
+	d->sout.release();
 	d->pinned.release();
 	d->meta.release();
 	d->streams.release();
@@ -380,6 +384,20 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 	void *outs[1] = { out };
 	int32_t res = LIBDEFLATE_BAD_DATA;
 	size_t ain = 0, aout = 0;
+	/* a large stream: many waves (host_stream.hip); it answers only for what
+	 * it decoded cleanly, everything else goes on to the sequential kernel */
+	if (d && in && out &&
+	    decompress_stream_parallel(d, format, (const uint8_t *)in, in_nbytes,
+				       (uint8_t *)out, out_avail, actual_out_ret == NULL,
+				       &res, &ain, &aout)) {
+		if (res == LIBDEFLATE_SUCCESS) {
+			if (actual_in_ret)
+				*actual_in_ret = ain;
+			if (actual_out_ret)
+				*actual_out_ret = aout;
+		}
+		return (enum libdeflate_result)res;
+	}
 	int rc = libdeflate_amd_decompress_batch_host(
 		d, format, 1, ins, &in_nbytes, outs, &out_avail, &res, &ain,
 		actual_out_ret ? &aout : NULL);

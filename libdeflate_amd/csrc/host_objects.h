@@ -34,6 +34,9 @@ struct libdeflate_decompressor {
 	lda::DevBuf scratch;	/* per-chunk u32 sums + u64 actual_in/out */
 	lda::DevBuf stage;	/* host-pointer entry points */
 	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
+	/* one large stream on many waves (host_stream.hip): input + finder
+	 * queues, chunk descriptors / results, 16-bit symbols, output bytes */
+	lda::DevBuf sin, schunks, ssym, sout;
 	lda::PinnedPair pinned;	/* host-pointer entry points */
 	lda::PinnedBuf meta;	/* host-pointer entry points: per-chunk read-backs */
 	lda::StreamPair streams;	/* host-pointer entry points: transfers / kernels */
@@ -48,5 +51,14 @@ struct libdeflate_compressor {
 	lda::PinnedBuf meta;	/* host-pointer entry points: per-chunk read-backs */
 	lda::StreamPair streams;	/* host-pointer entry points: transfers / kernels */
 };
+
+namespace lda {
+/* host_stream.hip: true = answered (result, sizes, output); false = the
+ * caller takes the sequential path */
+bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
+				const uint8_t *in, size_t in_nbytes, uint8_t *out,
+				size_t out_avail, bool exact_fill, int32_t *res,
+				size_t *ain, size_t *aout);
+}
 
 #endif /* LDA_HOST_OBJECTS_H */

@@ -1,0 +1,455 @@
+/*
+ * host_stream.hip - ONE large stream on many waves: the host side of
+ * inflate_stream.hip (find -> plan -> count -> chain -> decode -> window ->
+ * resolve -> checksum; see that file's header for what each step is).
+ *
+ * Entered from the single-buffer libdeflate_{deflate,zlib,gzip}_decompress[_ex]
+ * calls (host_decompress.hip) for streams of LDA_STREAM_PAR_MIN bytes and up -
+ * what programs/gzip.c:187-303 and programs/benchmark.c:543-544 hand to the
+ * library.  It only ever ANSWERS for a clean success (or a footer that does not
+ * match a cleanly decoded stream): anything else - an invalid header, a chain
+ * that does not close, an output that does not fit or does not fill - is left
+ * to the sequential kernel, which follows the reference's result codes bit for
+ * bit, so the codes cannot depend on which path ran.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "host_objects.h"
+#include "kernels.h"
+#include "stream_kernels.h"
+
+namespace lda {
+
+static thread_local uint64_t g_stats[LIBDEFLATE_AMD_STREAM_STATS];
+
+#define ST_TRY(expr)                                                          \
+	do {                                                                  \
+		hipError_t e_ = (expr);                                       \
+		if (e_ != hipSuccess) {                                       \
+			set_error("%s: %s", #expr, hipGetErrorString(e_));    \
+			return false;                                         \
+		}                                                             \
+	} while (0)
+
+enum { WHY_OK = 0, WHY_DISABLED, WHY_HEADER, WHY_CHAIN, WHY_ERRCHUNK, WHY_NOFINAL,
+       WHY_SPACE, WHY_FILL, WHY_DECODE, WHY_DEVICE, WHY_REPAIRS };
+
+struct planned {
+	lda_stream_chunk c;
+	uint64_t at;	/* nominal start: hdr_bit (HEADER) or target_bit (WARM) */
+};
+
+/* gzip / zlib container: offset of the raw stream and the footer's size; false
+ * if the sequential path should look at it (lib/gzip_decompress.c:45-107,
+ * lib/zlib_decompress.c:45-72) */
+static bool container(int format, const uint8_t *in, size_t n, size_t *hdr, size_t *ftr)
+{
+	*hdr = *ftr = 0;
+	if (format == LIBDEFLATE_AMD_DEFLATE)
+		return true;
+	if (format == LIBDEFLATE_AMD_ZLIB) {
+		if (n < 6)
+			return false;
+		const uint32_t h = ((uint32_t)in[0] << 8) | in[1];
+		if (h % 31 || ((h >> 8) & 0xF) != 8 || (h >> 12) > 7 || ((h >> 5) & 1))
+			return false;
+		*hdr = 2;
+		*ftr = 4;
+		return true;
+	}
+	if (n < 18 || in[0] != 0x1F || in[1] != 0x8B || in[2] != 8 || (in[3] & 0xE0))
+		return false;
+	const uint32_t flg = in[3];
+	size_t p = 10;
+	if (flg & 0x04) {
+		const size_t xlen = in[p] | ((size_t)in[p + 1] << 8);
+		p += 2;
+		if (n - p < xlen + 8)
+			return false;
+		p += xlen;
+	}
+	for (int k = 0; k < 2; k++)
+		if (flg & (k ? 0x10 : 0x08)) {
+			while (in[p++] != 0 && p != n)
+				;
+			if (n - p < 8)
+				return false;
+		}
+	if (flg & 0x02) {
+		p += 2;
+		if (n - p < 8)
+			return false;
+	}
+	*hdr = p;
+	*ftr = 8;
+	return true;
+}
+
+static bool launch_count(hipStream_t st, uint32_t n, const lda_stream_chunk *d_chunks,
+			 lda_stream_res *d_res, const uint8_t *d_raw, uint64_t raw_n)
+{
+	hipLaunchKernelGGL(lda_stream_count_kernel, dim3(n), dim3(64), lda_stream_chunk_lds(),
+			   st, n, d_chunks, d_res, d_raw, raw_n, (uint32_t *)NULL);
+	ST_TRY(hipGetLastError());
+	return true;
+}
+
+/*
+ * true: *res (and on success *ain / *aout, the output in `out`) are final.
+ * false: not answered here - the caller takes the sequential path (the reason
+ * is in the stats; a device failure is also in last_error).
+ */
+bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
+				const uint8_t *in, size_t in_nbytes, uint8_t *out,
+				size_t out_avail, bool exact_fill, int32_t *res,
+				size_t *ain, size_t *aout)
+{
+	uint64_t *S = g_stats;
+	memset(g_stats, 0, sizeof(g_stats));
+	DeviceCtx *ctx = device_ctx();
+	const EnvCfg &env = env_cfg();
+	if (!ctx || env.no_stream_par || in_nbytes < env.stream_par_min) {
+		S[1] = WHY_DISABLED;
+		return false;
+	}
+	size_t hdr, ftr;
+	if (!container(format, in, in_nbytes, &hdr, &ftr)) {
+		S[1] = WHY_HEADER;
+		return false;
+	}
+	const uint64_t raw_n = in_nbytes - hdr - ftr;
+	const uint64_t raw_bits = 8 * raw_n;
+	if (raw_n < 8) {
+		S[1] = WHY_HEADER;
+		return false;
+	}
+	S[1] = WHY_DEVICE;	/* until something better is known */
+	if (!d->streams.ensure())
+		return false;
+	hipStream_t s_copy = d->streams.copy, s_comp = d->streams.comp;
+
+	/* ---- input to the device; the finder's queues behind it ---- */
+	const uint64_t nbits = raw_bits > 80 ? raw_bits - 80 : 0;	/* a header needs its bits */
+	const uint32_t qcap = (uint32_t)std::min<uint64_t>(nbits / 64 + 1024, 1u << 28);
+	const size_t in_at = 64, q_at = align_up(in_at + in_nbytes + 64, 64);
+	const size_t c_at = q_at + (size_t)qcap * 8, cnt_at = c_at + (size_t)qcap * 8;
+	uint8_t *sin = (uint8_t *)d->sin.reserve(cnt_at + 64);
+	if (!sin)
+		return false;
+	uint8_t *d_raw = sin + in_at + hdr;
+	{
+		const void *ins[1] = { in };
+		const uint64_t off[1] = { in_at };
+		if (copy_in_packed(&d->pinned, sin, 1, ins, &in_nbytes, off, s_copy) != LIBDEFLATE_AMD_OK)
+			return false;
+	}
+	uint64_t *d_queue = (uint64_t *)(sin + q_at), *d_cand = (uint64_t *)(sin + c_at);
+	uint32_t *d_cnt = (uint32_t *)(sin + cnt_at);	/* [0] queue, [1] candidates, [2] error flag */
+	ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
+	std::vector<uint64_t> cands;
+	if (nbits) {
+		hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nbits + 255) / 256)),
+				   dim3(256), 0, s_comp, d_raw, raw_n, nbits, d_queue, d_cnt, qcap);
+		hipLaunchKernelGGL(lda_stream_find_b_kernel, dim3((qcap + 63) / 64), dim3(64), 16384,
+				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, qcap);
+		ST_TRY(hipGetLastError());
+		uint32_t cnt[2];
+		ST_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s_comp));
+		ST_TRY(hipStreamSynchronize(s_comp));
+		const uint32_t nc = std::min(cnt[1], qcap);
+		cands.resize(nc);
+		if (nc) {
+			ST_TRY(hipMemcpyAsync(cands.data(), d_cand, (size_t)nc * 8,
+					      hipMemcpyDeviceToHost, s_comp));
+			ST_TRY(hipStreamSynchronize(s_comp));
+		}
+		std::sort(cands.begin(), cands.end());
+		S[2] = cnt[0];
+		S[3] = nc;
+	}
+
+	/* ---- plan ---- */
+	uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk : raw_n / 512;
+	T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 4096), 65536);
+	const uint64_t OV = 8192, HDRSAFE = 4608;
+	std::vector<planned> plan;
+	auto add_block = [&](uint64_t start, uint64_t next, bool dynamic) {
+		planned p = {};
+		p.c.kind = LDA_CHUNK_HEADER;
+		p.c.hdr_bit = p.c.start_bit = p.c.target_bit = start;
+		p.at = start;
+		plan.push_back(p);
+		if (!dynamic)
+			return;
+		for (uint64_t P = start + T; P + T / 2 <= next; P += T) {
+			uint64_t ws = P > OV ? P - OV : 0;
+			if (ws < start + HDRSAFE)
+				ws = start + HDRSAFE;
+			if (ws + OV / 4 > P)
+				continue;
+			planned q = {};
+			q.c.kind = LDA_CHUNK_WARM;
+			q.c.hdr_bit = start;
+			q.c.start_bit = ws;
+			q.c.target_bit = P;
+			q.at = P;
+			plan.push_back(q);
+		}
+	};
+	{
+		/* block starts: the stream's first bit, then the candidates that are
+		 * not too close to the chunk start before them */
+		std::vector<std::pair<uint64_t, bool>> starts;
+		starts.push_back({ 0, !cands.empty() && cands[0] == 0 });
+		for (uint64_t c : cands)
+			if (c >= starts.back().first + T / 2)
+				starts.push_back({ c, true });
+		for (size_t i = 0; i < starts.size(); i++)
+			add_block(starts[i].first, i + 1 < starts.size() ? starts[i + 1].first : raw_bits,
+				  starts[i].second);
+	}
+	for (size_t i = 0; i < plan.size(); i++)
+		plan[i].c.limit_bit = i + 1 < plan.size() ? plan[i + 1].at : raw_bits;
+	const uint32_t np = (uint32_t)plan.size();
+	S[4] = np;
+
+	/* ---- count ---- */
+	const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
+	const size_t rep_at = res_at + align_up((size_t)np * sizeof(lda_stream_res) + 64, 64);
+	const size_t off_at = rep_at + 256;
+	uint8_t *sch = (uint8_t *)d->schunks.reserve(off_at + ((size_t)np + 2) * 8 + 64);
+	if (!sch)
+		return false;
+	lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
+	lda_stream_res *d_res = (lda_stream_res *)(sch + res_at);
+	std::vector<lda_stream_chunk> hc(np);
+	for (uint32_t i = 0; i < np; i++)
+		hc[i] = plan[i].c;
+	std::vector<lda_stream_res> hr(np);
+	ST_TRY(hipMemcpyAsync(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk),
+			      hipMemcpyHostToDevice, s_comp));
+	if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, raw_n))
+		return false;
+	ST_TRY(hipMemcpyAsync(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res),
+			      hipMemcpyDeviceToHost, s_comp));
+	ST_TRY(hipStreamSynchronize(s_comp));
+
+	/* ---- chain ---- */
+	std::vector<lda_stream_chunk> acc;	/* accepted chunks, exact starts */
+	std::vector<lda_stream_res> accr;
+	{
+		lda_stream_chunk cur = hc[0];
+		lda_stream_res r = hr[0];
+		size_t next = 1;	/* first planned chunk not yet passed */
+		uint32_t repairs = 0;
+		const uint32_t max_repairs = 24 + np / 8;
+		for (;;) {
+			if (r.status == LDA_STREAM_ERR) {
+				S[1] = WHY_ERRCHUNK;
+				return false;
+			}
+			cur.start_bit = r.start_bit;
+			if (cur.kind == LDA_CHUNK_WARM)
+				cur.kind = LDA_CHUNK_EXACT;
+			acc.push_back(cur);
+			accr.push_back(r);
+			if (r.status == LDA_STREAM_FINAL)
+				break;
+			if (r.end_bit >= raw_bits) {
+				S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
+				return false;
+			}
+			/* the planned chunk that starts exactly where this one ended */
+			const bool bnd = r.flags & LDA_RES_BOUNDARY;
+			size_t j = next;
+			bool found = false;
+			while (j < np && plan[j].at <= r.end_bit) {
+				const lda_stream_chunk &c = hc[j];
+				const lda_stream_res &q = hr[j];
+				if (bnd ? (c.kind == LDA_CHUNK_HEADER && c.hdr_bit == r.end_bit) :
+					  (c.kind == LDA_CHUNK_WARM && q.status != LDA_STREAM_ERR &&
+					   q.start_bit == r.end_bit && c.hdr_bit == r.end_hdr_bit)) {
+					found = true;
+					break;
+				}
+				j++;
+			}
+			if (found) {
+				cur = hc[j];
+				r = hr[j];
+				next = j + 1;
+				continue;
+			}
+			/* repair: count from the exact end state up to the next planned start */
+			if (++repairs > max_repairs) {
+				S[1] = WHY_REPAIRS;
+				S[5] = repairs;
+				return false;
+			}
+			next = j;
+			lda_stream_chunk rc = {};
+			rc.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
+			rc.hdr_bit = r.end_hdr_bit;
+			rc.start_bit = rc.target_bit = r.end_bit;
+			rc.limit_bit = j < np ? plan[j].at : raw_bits;
+			lda_stream_chunk *d_rc = (lda_stream_chunk *)(sch + rep_at);
+			lda_stream_res *d_rr = (lda_stream_res *)(sch + rep_at + 128);
+			lda_stream_res rr;
+			ST_TRY(hipMemcpyAsync(d_rc, &rc, sizeof(rc), hipMemcpyHostToDevice, s_comp));
+			if (!launch_count(s_comp, 1, d_rc, d_rr, d_raw, raw_n))
+				return false;
+			ST_TRY(hipMemcpyAsync(&rr, d_rr, sizeof(rr), hipMemcpyDeviceToHost, s_comp));
+			ST_TRY(hipStreamSynchronize(s_comp));
+			cur = rc;
+			r = rr;
+			S[5] = repairs;
+		}
+	}
+	const uint32_t na = (uint32_t)acc.size();
+	S[6] = na;
+	std::vector<uint64_t> offs(na + 1);
+	uint64_t total = 0;
+	for (uint32_t i = 0; i < na; i++) {
+		offs[i] = total;
+		acc[i].out_off = total;
+		total += accr[i].nout;
+	}
+	offs[na] = total;
+	const uint64_t end_bit = accr[na - 1].end_bit;
+	if (total > out_avail) {
+		S[1] = WHY_SPACE;
+		return false;
+	}
+	if (exact_fill && total != out_avail) {
+		S[1] = WHY_FILL;
+		return false;
+	}
+
+	/* ---- decode -> window -> resolve ---- */
+	uint8_t *d_out = NULL;
+	if (total) {
+		S[1] = WHY_DEVICE;
+		const size_t BATCH = 2048;	/* decode waves per launch (their token scratch) */
+		uint16_t *d_sym = (uint16_t *)d->ssym.reserve((size_t)total * 2 + 64);
+		d_out = (uint8_t *)d->sout.reserve((size_t)total + 64);
+		uint32_t *d_tok = (uint32_t *)d->tokens.reserve(
+			std::min<size_t>(na, BATCH) * lda_stream_tokcap() * 4 + 64);
+		if (!d_sym || !d_out || !d_tok)
+			return false;
+		uint64_t *d_off = (uint64_t *)(sch + off_at);
+		ST_TRY(hipMemcpyAsync(d_chunks, acc.data(), (size_t)na * sizeof(lda_stream_chunk),
+				      hipMemcpyHostToDevice, s_comp));
+		ST_TRY(hipMemcpyAsync(d_off, offs.data(), ((size_t)na + 1) * 8,
+				      hipMemcpyHostToDevice, s_comp));
+		for (size_t lo = 0; lo < na; lo += BATCH) {
+			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
+			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
+					   lda_stream_chunk_lds(), s_comp, nk, d_chunks + lo,
+					   d_res + lo, d_raw, raw_n, d_sym, d_tok);
+		}
+		hipLaunchKernelGGL(lda_stream_window_kernel, dim3(1), dim3(1024), 0, s_comp, na,
+				   d_off, d_sym, d_out, d_cnt + 2);
+		{
+			uint64_t longest = 0;
+			for (uint32_t i = 0; i < na; i++)
+				longest = std::max(longest, accr[i].nout);
+			if (longest > 32768) {
+				const unsigned gx = (unsigned)std::min<uint64_t>(
+					(longest - 32768 + 2047) / 2048, 64);
+				hipLaunchKernelGGL(lda_stream_resolve_kernel, dim3(gx, na), dim3(256),
+						   0, s_comp, na, d_off, d_sym, d_out, d_cnt + 2);
+			}
+		}
+		ST_TRY(hipGetLastError());
+		std::vector<lda_stream_res> dr(na);
+		uint32_t err = 0;
+		ST_TRY(hipMemcpyAsync(dr.data(), d_res, (size_t)na * sizeof(lda_stream_res),
+				      hipMemcpyDeviceToHost, s_comp));
+		ST_TRY(hipMemcpyAsync(&err, d_cnt + 2, 4, hipMemcpyDeviceToHost, s_comp));
+		ST_TRY(hipStreamSynchronize(s_comp));
+		bool same = err == 0;
+		for (uint32_t i = 0; i < na && same; i++)
+			same = dr[i].end_bit == accr[i].end_bit && dr[i].nout == accr[i].nout &&
+			       dr[i].status == accr[i].status && !(dr[i].flags & LDA_RES_BAD_DIST);
+		if (!same) {
+			S[1] = WHY_DECODE;
+			return false;
+		}
+	}
+
+	/* ---- footer: checksum of the output in pieces, combined on the host ---- */
+	const size_t consumed = (size_t)((end_bit + 7) / 8);
+	int32_t result = LIBDEFLATE_SUCCESS;
+	if (ftr) {
+		uint32_t sum = format == LIBDEFLATE_AMD_GZIP ? 0u : 1u;
+		if (total) {
+			S[1] = WHY_DEVICE;
+			const uint64_t piece = std::max<uint64_t>(65536, align_up(total / 4096, 4096));
+			const size_t npc = (size_t)((total + piece - 1) / piece);
+			std::vector<uint64_t> po(2 * npc);
+			for (size_t i = 0; i < npc; i++) {
+				po[i] = i * piece;
+				po[npc + i] = std::min<uint64_t>(piece, total - i * piece);
+			}
+			uint8_t *scr = (uint8_t *)d->scratch.reserve(npc * 20 + 64);
+			if (!scr)
+				return false;
+			uint64_t *d_po = (uint64_t *)scr;
+			uint32_t *d_sums = (uint32_t *)(scr + npc * 16);
+			std::vector<uint32_t> sums(npc);
+			ST_TRY(hipMemcpyAsync(d_po, po.data(), npc * 16, hipMemcpyHostToDevice, s_comp));
+			const int rc = format == LIBDEFLATE_AMD_GZIP ?
+				libdeflate_amd_crc32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp) :
+				libdeflate_amd_adler32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp);
+			if (rc != LIBDEFLATE_AMD_OK)
+				return false;
+			ST_TRY(hipMemcpyAsync(sums.data(), d_sums, npc * 4, hipMemcpyDeviceToHost, s_comp));
+			ST_TRY(hipStreamSynchronize(s_comp));
+			for (size_t i = 0; i < npc; i++)
+				sum = i == 0 ? sums[0] :
+				      format == LIBDEFLATE_AMD_GZIP ?
+					      crc32_concat(sum, sums[i], po[npc + i]) :
+					      adler32_concat(sum, sums[i], po[npc + i]);
+		}
+		const uint8_t *f = in + hdr + consumed;
+		if (format == LIBDEFLATE_AMD_GZIP) {
+			const uint32_t want = f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) |
+					      ((uint32_t)f[3] << 24);
+			const uint32_t isize = f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) |
+					       ((uint32_t)f[7] << 24);
+			if (want != sum || isize != (uint32_t)total)
+				result = LIBDEFLATE_BAD_DATA;
+		} else {
+			const uint32_t want = ((uint32_t)f[0] << 24) | ((uint32_t)f[1] << 16) |
+					      ((uint32_t)f[2] << 8) | f[3];
+			if (want != sum)
+				result = LIBDEFLATE_BAD_DATA;
+		}
+	}
+	if (result == LIBDEFLATE_SUCCESS && total) {
+		void *outs[1] = { out };
+		const uint64_t nb[1] = { total }, off[1] = { 0 };
+		if (copy_out_packed(&d->pinned, d_out, 1, outs, nb, off, s_copy) != LIBDEFLATE_AMD_OK)
+			return false;
+	}
+	*res = result;
+	if (result == LIBDEFLATE_SUCCESS) {
+		*ain = hdr + consumed + ftr;
+		*aout = (size_t)total;
+	}
+	S[0] = 1;
+	S[1] = WHY_OK;
+	S[7] = total;
+	return true;
+}
+
+} /* namespace lda */
+
+extern "C" LIBDEFLATEAPI void libdeflate_amd_stream_stats(uint64_t *out)
+{
+	memcpy(out, lda::g_stats, sizeof(lda::g_stats));
+}

@@ -1329,6 +1329,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 	u64 bitbuf = 0, rpos = 0, out_pos = 0, filled = 0;
 	u32 bitcnt = 0, final_block = 0, nlit = 0, noff = 0;
 	u64 stored_left = 0;
+	bool static_loaded = false;	/* the stream's tables are the static codes' */
 	u64 pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;	/* loaded, not yet stored */
 	u8 *pend_dst = outp;
 	u32 pend_n = 0, pend_len = 0;
@@ -1381,17 +1382,28 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					result = LDA_BAD_DATA;
 					state = ST_DONE;
 				} else if (btype == 1) {
-					/* static codes: decompress_template.h:313-326 */
+					/* static codes: decompress_template.h:313-326; the
+					 * tables of the block before are kept when that one
+					 * was static too (static_codes_loaded, :303-311 - a
+					 * stream of tiny static blocks is the case of
+					 * programs/test_slow_decompression.c:18-30) */
 					CONSUME(3);
-					for (u32 i = 0; i < 320; i++)
-						S->lens[i] = i < 144 ? 8 : i < 256 ? 9 :
-							     i < 280 ? 7 : i < 288 ? 8 : 5;
-					nlit = 288;
-					noff = 32;
-					state = ST_TABLES;
+					if (static_loaded) {
+						state = ST_TOK;
+					} else {
+						for (u32 i = 0; i < 320; i++)
+							S->lens[i] = i < 144 ? 8 : i < 256 ? 9 :
+								     i < 280 ? 7 : i < 288 ? 8 : 5;
+						nlit = 288;
+						noff = 32;
+						state = ST_TABLES;
+						static_loaded = true;	/* taken back if the build fails */
+					}
 				} else {
-					/* dynamic header: decompress_template.h:85-245 */
+					/* dynamic header: decompress_template.h:85-245 (its
+					 * scratch shares the tables' LDS) */
 					u8 plens[19];
+					static_loaded = false;
 					nlit = 257 + (((u32)bitbuf >> 3) & 31);
 					noff = 1 + (((u32)bitbuf >> 8) & 31);
 					u32 npre = 4 + (((u32)bitbuf >> 13) & 15);
@@ -1914,6 +1926,8 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 	}
 }
 
+/* inflate_stream.hip includes this file for its device functions only */
+#ifndef LDA_INFLATE_DEVICE_ONLY
 extern "C" __global__ void __launch_bounds__(64, 4)
 lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 			 const u8 *__restrict__ in_base,
@@ -2110,3 +2124,4 @@ lda_inflate_finalize_kernel(u64 n_chunks, int format, int exact_fill,
 }
 
 LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_inflate)
+#endif /* LDA_INFLATE_DEVICE_ONLY */

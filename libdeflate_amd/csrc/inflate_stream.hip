@@ -1,0 +1,1056 @@
+/*
+ * inflate_stream.hip - ONE large DEFLATE stream decoded by many waves.
+ *
+ * The reference decodes a stream front to back, one token after the other
+ * (lib/decompress_template.h:344-671), and that is what the batch kernels of
+ * inflate_kernel.hip do per stream: a stream of 16 MiB keeps one wave busy and
+ * 255 CUs idle.  This is what programs/gzip.c:187-303 and the default 1 MiB
+ * chunks of programs/benchmark.c:543-544 hand to libdeflate_*_decompress, so
+ * the single-buffer calls get a second path (host_stream.hip) built from these
+ * kernels:
+ *
+ *   find     every bit offset of the compressed stream is tried as the start
+ *            of a dynamic Huffman block (BTYPE, HLIT/HDIST, a complete precode:
+ *            lda_stream_find_a_kernel; then the code lengths decoded in full
+ *            and both codes checked: lda_stream_find_b_kernel).  What passes
+ *            is, with overwhelming probability, a block boundary; the chain
+ *            check below does not depend on it.
+ *   plan     (host) the stream is cut into chunks of a few KiB of input.  A
+ *            chunk starts at a found block header, or INSIDE a block: a parse
+ *            started at an arbitrary bit falls in step with the true one
+ *            within a few dozen bits (the property the rounds of
+ *            inflate_kernel.hip rest on), so a chunk that knows its block's
+ *            header parses 1 KiB of warm-up in front of its nominal start,
+ *            and the first token boundary at or after that start is its start.
+ *   count    lda_stream_chunk_kernel<COUNT>: a wave per chunk parses its
+ *            chunk up to the first token (or block) boundary at or after the
+ *            next chunk's nominal start and reports where it started, where
+ *            it ended, under which block header, and how many bytes it makes.
+ *   chain    (host) chunk 0 starts at the stream's first bit and is exact.
+ *            A chunk is accepted iff its start - position, governing header,
+ *            boundary kind - is exactly the end of an accepted chunk, so by
+ *            induction every accepted chunk is the reference's parse.  Where
+ *            the chain breaks (a block the finder does not look for - stored,
+ *            static -, a false candidate, a warm-up that did not fall in
+ *            step) a repair chunk is counted from the exact end state; too
+ *            many repairs, any error, or an output that does not fit send the
+ *            whole stream to the sequential kernel, which owns the result
+ *            codes.
+ *   decode   lda_stream_chunk_kernel<MARK>: the same parse again (tokens are
+ *            cheaper to decode twice than to keep), now executed: 16-bit
+ *            symbols, a byte or - for a match source in front of the chunk's
+ *            first byte - a MARKER 0x8000 | index into the 32 KiB in front of
+ *            the chunk.
+ *   window   lda_stream_window_kernel: one workgroup walks the chunks in
+ *            order with the window in LDS and settles the last 32 KiB of
+ *            every chunk (32 Ki symbols per step, the only serial part).
+ *   resolve  lda_stream_resolve_kernel: every other symbol, all in parallel.
+ *
+ * Not a restatement of anything in the reference; the validity rules of the
+ * headers are those of lib/deflate_decompress.c:721-1004 and
+ * lib/decompress_template.h:85-245 through the functions of inflate_kernel.hip.
+ */
+#define LDA_INFLATE_DEVICE_ONLY
+#include "inflate_kernel.hip"
+#include "stream_kernels.h"
+
+typedef AS3 u16 lsym;
+
+#define SM_COUNT 1
+#define SM_MARK 2
+
+/* LDS of one chunk wave: tables, shared tables, 16-bit output mirror, stage +
+ * token map (the layout of lda_inflate_wave_kernel with a 16-bit mirror) */
+#define STREAM_LDS (sizeof(struct stream_lds) + sizeof(struct shared_lds) + \
+		    2 * PAR_RW + PAR_STAGE_BYTES + PAR_MAP_BYTES)
+
+/* positions [flushed, end) are in the mirror and not yet in memory: store
+ * the whole pairs among them (a 4-byte word of two symbols) */
+static __device__ __forceinline__ u64
+flush_ring16(u16 *__restrict__ sym, const lsym *win, u64 flushed, u64 end, u32 lane)
+{
+	u64 a = (flushed + 1) & ~(u64)1;
+	if (a > end)
+		return flushed;
+	if (flushed < a && lane == 0)
+		sym[flushed] = win[(u32)flushed & (PAR_RW - 1)];
+	const u64 e = end & ~(u64)1;
+	if (e <= a)
+		return a;
+	const u32 nw = (u32)(e - a) >> 1;
+	u32 *dst = (u32 *)(sym + a);
+	const u32 a32 = (u32)a;
+	for (u32 w = lane; w < nw; w += 64)
+		dst[w] = *(const lu32 *)(win + ((a32 + 2 * w) & (PAR_RW - 1)));
+	return e;
+}
+
+/*
+ * One round of a chunk: par_round() of inflate_kernel.hip with
+ *   - a LIMIT: the round (and with it the chunk) ends at the first token
+ *     boundary at or after bit `limit_abs`;
+ *   - WARM rounds, whose lane 0 starts at a guess like every other lane and
+ *     which run over end-of-block symbols (they only look for the boundary);
+ *   - MODE SM_COUNT: no tokens kept, nothing executed, bytes counted;
+ *   - MODE SM_MARK: tokens executed into 16-bit symbols at absolute output
+ *     positions; a source in front of `chunk_abs` becomes a marker.
+ * *bad_ret is set when a distance reaches back before the stream's first byte.
+ */
+template <int MODE> static __device__ u32
+chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
+	    u32 *__restrict__ tok, lsym *win, lu8 *stage, u64 ring_lo, u32 lane,
+	    u64 bpos_abs, u64 limit_abs, bool warm, u16 *__restrict__ sym,
+	    u64 out0, u64 chunk_abs, u64 *bpos_ret, u64 *out_ret, u32 *bad_ret)
+{
+	const u64 byte0 = bpos_abs >> 3;
+	if (byte0 + 64 > in_n)
+		return PAR_STOP;
+	u32 *__restrict__ tokS = tok;
+	const u32 cb = in_n - byte0 >= 64 * (PAR_CB / 8) ? PAR_CB : 256u;
+	const u64 room = (in_n - byte0 + cb / 8 - 1) / (cb / 8);
+	u32 NL = room < 64 ? (u32)room : 64;
+	const u32 bpos0 = (u32)bpos_abs & 7;
+	/* the limit, relative to the staged span; lanes whose piece starts at or
+	 * after it have nothing to do */
+	u32 lim = 0x7FFFFFFFu;
+	if (limit_abs - 8 * byte0 < 0x40000000ull) {
+		lim = (u32)(limit_abs - 8 * byte0);
+		const u32 need = lim > bpos0 ? (lim - bpos0 + cb - 1) / cb : 1;
+		NL = need < NL ? need : NL;
+	}
+	{
+		const u32 nw = (NL * (cb / 8) + 80) / 8;
+		for (u32 w = lane; w < nw; w += 64) {
+			const u64 pos = byte0 + 8 * w;
+			*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
+						  load_in(inp, in_n, pos);
+		}
+		wave_sync();
+	}
+	const lu8 *span = stage;
+	struct par_long pll, plo;
+	par_long_init(&pll, &S->lit, LIT_TB + 1);
+	par_long_init(&plo, &S->off, OFF_TB + 1);
+	u32 cend = bpos0 + (lane + 1) * cb;
+	cend = cend < lim ? cend : lim;
+	u32 start = bpos0 + lane * cb, end = 0;
+	u32 nbytes = 0, ntok = 0;
+	bool eob = false, dirty = lane < NL;
+	u32 K = NL - 1;
+	bool has_eob = false;
+
+	for (u32 pass = 0; pass < 64; pass++) {
+		struct par_bits b;
+		bool run = dirty;
+		const bool keep = MODE == SM_MARK && (pass != 0 || lane == 0);
+		pb_init(&b, span, start);
+		if (dirty) {
+			nbytes = 0;
+			ntok = 0;
+			eob = false;
+		}
+		while (__ballot(run)) {
+			run = run && PB_POS(b) < cend;
+			pb_refill(&b, span);
+			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
+			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
+					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+			if (run) {
+				u32 used = t.used;
+				if (t.kind == K_EOB) {
+					if (!warm) {
+						eob = true;
+						run = false;
+					}
+				} else {
+					if (keep && ntok < PAR_LANECAP)
+						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
+							0x80000000u | t.length | (t.dist << 9) : t.lit;
+					nbytes += t.kind == K_LEN ? t.length : 1;
+					ntok++;
+					if (two) {
+						if (keep && ntok < PAR_LANECAP)
+							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
+						nbytes++;
+						ntok++;
+						used += e1 & 15;
+					}
+				}
+				b.buf >>= used;
+				b.cnt -= used;
+			}
+		}
+		if (dirty)
+			end = PB_POS(b);
+		u32 ns = __builtin_amdgcn_update_dpp(end, end, 0x138, 0xF, 0xF, false);
+		if (lane == 0)
+			ns = bpos0;
+		dirty = (ns != start || (pass == 0 && lane != 0)) && lane < NL;
+		start = ns;
+		const u64 dm = __ballot(dirty), em = __ballot(eob);
+		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
+		if (em & exact) {
+			K = (u32)__builtin_ctzll(em & exact);
+			has_eob = true;
+			break;
+		}
+		if (!dm)
+			break;
+	}
+	bool valid = lane <= K;
+	u32 tcnt = valid ? ntok : 0;
+	u32 tbase = wave_scan_incl(tcnt) - tcnt;
+	{
+		u64 vm = __ballot(valid);
+		const u64 over = __ballot(lane <= K && ntok > PAR_LANECAP);
+		if (over)
+			vm &= (1ull << __builtin_ctzll(over)) - 1;
+		const u32 nv = __builtin_popcountll(vm);
+		if (nv == 0)
+			return PAR_STOP;
+		if (nv - 1 < K) {
+			K = nv - 1;
+			has_eob = false;
+		}
+		valid = lane <= K;
+	}
+	const u32 bcnt = valid ? nbytes : 0;
+	const u32 obase = wave_scan_incl(bcnt) - bcnt;
+	const u32 total_tok = bcast_lane(tbase + tcnt, K);
+	const u64 total_bytes = bcast_lane(obase + bcnt, K);
+	const u64 end_bits = (u64)bcast_lane(end, K) + 8 * byte0;
+	if (end_bits > 8 * in_n)
+		return PAR_STOP;
+	*bpos_ret = end_bits;
+	*out_ret = out0 + total_bytes;
+	if (MODE != SM_MARK || warm)
+		return has_eob ? PAR_EOB : PAR_OK;
+
+	lu8 *mk = stage + PAR_STAGE_BYTES;
+	lu16 *tb = (lu16 *)(mk + 256);
+	const u32 own_cnt = valid ? tcnt : 0;
+	tb[lane] = (u16)tbase;
+	wave_sync();
+	{
+		lu32 *tk = (lu32 *)stage;
+		lu16 *R = (lu16 *)((lu32 *)stage + 256);
+		u64 gbase = out0;
+		u64 flushed = out0;
+		u32 g = 0;
+		bool bad = false;
+		uint4 tq_next = tok_fetch(tokS, mk, tb, tbase, own_cnt, 0, total_tok, lane);
+		while (g < total_tok) {
+			const u32 ti0 = g + 4 * lane;
+			const uint4 tq = tq_next;
+			const u32 tw4[4] = { tq.x, tq.y, tq.z, tq.w };
+			u32 len4[4], lsum = 0;
+#pragma unroll
+			for (u32 j = 0; j < 4; j++) {
+				len4[j] = ti0 + j >= total_tok ? 0 :
+					  (tw4[j] >> 31) ? (tw4[j] & 0x1FF) : 1;
+				lsum += len4[j];
+			}
+			const u32 incl0 = wave_scan_incl(lsum);
+			const bool fits = ti0 < total_tok && incl0 <= PAR_GBYTES;
+			const u32 cnt = __builtin_popcountll(__ballot(fits));
+			const u32 gtot = bcast_lane(incl0, cnt - 1);
+			if (g + 4 * cnt < total_tok)
+				tq_next = tok_fetch(tokS, mk, tb, tbase, own_cnt,
+						    g + 4 * cnt, total_tok, lane);
+			for (u32 b0 = lane; b0 < gtot; b0 += 64)
+				R[b0] = 0;
+			wave_sync();
+			if (lane < cnt) {
+				u32 o = incl0 - lsum;
+#pragma unroll
+				for (u32 j = 0; j < 4; j++) {
+					tk[4 * lane + j] = tw4[j];
+					if (len4[j])
+						R[o] = (u16)(4 * lane + j + 1);
+					o += len4[j];
+				}
+			}
+			wave_sync();
+			const u32 gb = (u32)gbase;
+			u32 ring_rel = PAR_RW - gtot;
+			if (gbase - ring_lo < ring_rel)
+				ring_rel = (u32)(gbase - ring_lo);
+			/* bytes of this chunk in front of the group (a source further
+			 * back is in front of the chunk: a marker), and of the stream */
+			const u64 in_chunk64 = gbase - chunk_abs;
+			const u32 in_chunk = in_chunk64 < 0x10000 ? (u32)in_chunk64 : 0x10000u;
+			const u32 in_stream = gbase < 0x10000 ? (u32)gbase : 0x10000u;
+			enum { SB = 4 };
+			u32 carry = 0;
+			for (u32 s0 = 0; s0 < gtot; s0 += 64 * SB) {
+				u32 own[SB], vfar[SB];
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					own[k] = bi < gtot ? R[bi] : 0;
+				}
+#define DPP_MAX(k, ctrl, rm, bc)                                               \
+	do {                                                                   \
+		u32 t_ = __builtin_amdgcn_update_dpp(0, own[k], ctrl, rm, 0xF, bc); \
+		own[k] = own[k] > t_ ? own[k] : t_;                            \
+	} while (0)
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x111, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x112, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x114, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x118, 0xF, true);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x142, 0xA, false);
+#pragma unroll
+				for (u32 k = 0; k < SB; k++)
+					DPP_MAX(k, 0x143, 0xC, false);
+#undef DPP_MAX
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					own[k] = own[k] > carry ? own[k] : carry;
+					carry = bcast_lane(own[k], 63);
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane;
+					own[k] = bi < gtot ? tk[own[k] - 1] : 0;
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane, tw = own[k];
+					const u32 dist = (tw >> 9) & 0xFFFF;
+					const bool before = (tw >> 31) && dist > bi;
+					const u32 back = dist - bi;	/* bytes in front of the group */
+					const bool outside = before && back > in_chunk;
+					const bool far = before && !outside && back > ring_rel;
+					bad |= before && back > in_stream;
+					vfar[k] = 0x10000;	/* not a symbol: no far source */
+					if (outside)
+						vfar[k] = 0x8000u | (32768u - (back - in_chunk));
+					if (__ballot(far)) {
+						/* (store -> load visibility inside a wave: see
+						 * par_round() and tools/hwtest_global_visibility.hip) */
+						if (far)
+							vfar[k] = sym[gbase - back];
+					}
+				}
+				u32 root[SB];
+				bool any_intra = false;
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 tw = own[k], dist = (tw >> 9) & 0xFFFF;
+					const bool intra = (tw >> 31) && dist <= lane;
+					root[k] = intra ? lane - dist : lane;
+					any_intra |= intra;
+				}
+				if (__ballot(any_intra)) {
+					for (;;) {
+						bool ch = false;
+#pragma unroll
+						for (u32 k = 0; k < SB; k++) {
+							const u32 pp = (u32)__builtin_amdgcn_ds_bpermute(
+									(int)(root[k] << 2), (int)root[k]);
+							ch |= pp != root[k];
+							root[k] = pp;
+						}
+						if (!__ballot(ch))
+							break;
+					}
+				}
+#pragma unroll
+				for (u32 k = 0; k < SB; k++) {
+					const u32 bi = s0 + 64 * k + lane, tw = own[k];
+					const u32 dist = (tw >> 9) & 0xFFFF;
+					const bool match = (tw >> 31) != 0;
+					const u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
+					u32 v = match ? wv : tw & 0xFF;
+					v = vfar[k] < 0x10000 ? vfar[k] : v;
+					if (__ballot(root[k] != lane))
+						v = (u32)__builtin_amdgcn_ds_bpermute((int)(root[k] << 2), (int)v);
+					if (bi < gtot)
+						win[(gb + bi) & (PAR_RW - 1)] = (u16)v;
+				}
+			}
+			wave_sync();
+			gbase += gtot;
+			flushed = flush_ring16(sym, win, flushed, gbase, lane);
+			g += 4 * cnt;
+		}
+		if (flushed < gbase && lane == 0)
+			sym[flushed] = win[(u32)flushed & (PAR_RW - 1)];
+		wave_sync();
+		if (__ballot(bad))
+			*bad_ret = 1;
+	}
+	return has_eob ? PAR_EOB : PAR_OK;
+}
+
+/* stage `nbytes` (a multiple of 8) of input from byte0 on, zeros past the end */
+static __device__ __forceinline__ void
+stage_input(lu8 *stage, const u8 *inp, u64 in_n, u64 byte0, u32 nbytes, u32 lane)
+{
+	for (u32 w = lane; w < nbytes / 8; w += 64) {
+		const u64 pos = byte0 + 8 * w;
+		*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
+					  load_in(inp, in_n, pos);
+	}
+	wave_sync();
+}
+
+/*
+ * A block header at bit `pos` (lib/decompress_template.h:72-245, :313-326):
+ * lane 0 parses it from a staged copy, all lanes build the tables.
+ * Returns 0: Huffman block, tables ready, *pos_ret = first token;
+ *         1: stored block, *pos_ret = bit after the 3 header bits;
+ *         2: not a valid header.
+ */
+#define HDR_STAGE 704u	/* 17 + 57 + 316 x 14 bits at most, + slack */
+static __device__ u32
+chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
+	     u32 *final_ret, u64 *pos_ret)
+{
+	stage_input(stage, inp, in_n, pos >> 3, HDR_STAGE, lane);
+	u32 r = 2, fin = 0, nlit = 0, noff = 0, used = 0;
+	if (lane == 0) {
+		struct par_bits b;
+		const u32 p0 = (u32)pos & 7;
+		pb_init(&b, stage, p0);
+		fin = (u32)b.buf & 1;
+		const u32 btype = ((u32)b.buf >> 1) & 3;
+		if (btype == 0) {
+			r = 1;
+			used = 3;
+		} else if (btype == 1) {
+			for (u32 i = 0; i < 320; i++)
+				S->lens[i] = i < 144 ? 8 : i < 256 ? 9 :
+					     i < 280 ? 7 : i < 288 ? 8 : 5;
+			nlit = 288;
+			noff = 32;
+			r = 0;
+			used = 3;
+		} else if (btype == 2) {
+			u8 plens[19];
+			nlit = 257 + (((u32)b.buf >> 3) & 31);
+			noff = 1 + (((u32)b.buf >> 8) & 31);
+			const u32 npre = 4 + (((u32)b.buf >> 13) & 15);
+			for (u32 i = 0; i < 19; i++)
+				plens[i] = 0;
+			plens[c_pre_perm[0]] = ((u32)b.buf >> 17) & 7;
+			b.buf >>= 20;
+			b.cnt -= 20;
+			pb_refill(&b, stage);
+			for (u32 i = 1; i < npre; i++) {
+				plens[c_pre_perm[i]] = (u32)b.buf & 7;
+				b.buf >>= 3;
+				b.cnt -= 3;
+			}
+			bool ok = build_precode(S->pre_tab, plens);
+			u32 i = 0;
+			const u32 total = nlit + noff;
+			while (ok && i < total) {
+				if (b.cnt < 14)
+					pb_refill(&b, stage);
+				const u32 e = S->pre_tab[(u32)b.buf & 127];
+				b.buf >>= e & 15;
+				b.cnt -= e & 15;
+				const u32 presym = e >> 4;
+				if (presym < 16) {
+					S->lens[i++] = (u8)presym;
+					continue;
+				}
+				u32 rep, val = 0;
+				if (presym == 16) {
+					if (i == 0) {
+						ok = false;
+						break;
+					}
+					val = S->lens[i - 1];
+					rep = 3 + ((u32)b.buf & 3);
+					b.buf >>= 2;
+					b.cnt -= 2;
+				} else if (presym == 17) {
+					rep = 3 + ((u32)b.buf & 7);
+					b.buf >>= 3;
+					b.cnt -= 3;
+				} else {
+					rep = 11 + ((u32)b.buf & 127);
+					b.buf >>= 7;
+					b.cnt -= 7;
+				}
+				for (u32 k = 0; k < rep; k++)
+					S->lens[i + k] = (u8)val;
+				i += rep;
+			}
+			if (ok && i == total) {
+				r = 0;
+				used = PB_POS(b) - p0;
+			}
+		}
+	}
+	r = bcast_first(r);
+	fin = bcast_first(fin);
+	nlit = bcast_first(nlit);
+	noff = bcast_first(noff);
+	used = bcast_first(used);
+	wave_sync();
+	if (r == 0) {
+		u32 s_lit, s_off;
+		bool ok = build_table_coop(S->lens + nlit, noff, OFF_TB, false, &S->off,
+					   S->off_sorted, lane, &s_off);
+		ok = build_table_coop(S->lens, nlit, LIT_TB, true, &S->lit,
+				      S->lit_sorted, lane, &s_lit) && ok;
+		wave_sync();
+		if (ok) {
+			fill_table(S->off_tab, OFF_TB, false, &S->off, S->off_sorted, s_off, lane);
+			fill_table(S->lit_tab, LIT_TB, true, &S->lit, S->lit_sorted, s_lit, lane);
+		} else {
+			r = 2;
+		}
+		wave_sync();
+	}
+	if (pos + used > 8 * in_n)
+		r = 2;
+	*final_ret = fin;
+	*pos_ret = pos + used;
+	return r;
+}
+
+/*
+ * Tokens one at a time (lane 0 decodes, the wave copies): what is left of a
+ * stream when fewer than 64 bytes of input remain, and whatever a round
+ * could not take.  Decodes from a staged window until the end of the block
+ * (PAR_EOB), the limit or the end of the window (PAR_OK: the caller goes on),
+ * or an error (PAR_STOP).
+ */
+template <int MODE> static __device__ u32
+chunk_seq(const u8 *inp, u64 in_n, const slds_t *S, lu8 *stage, u32 lane,
+	  u64 pos, u64 limit, u16 *__restrict__ sym, u64 out0, u64 chunk_abs,
+	  u64 *pos_ret, u64 *out_ret, u32 *bad_ret)
+{
+	const u64 byte0 = pos >> 3;
+	const u32 winbytes = 1024;
+	stage_input(stage, inp, in_n, byte0, winbytes, lane);
+	struct par_bits b;
+	pb_init(&b, stage, (u32)pos & 7);
+	u64 out = out0;
+	u32 ret = PAR_OK;
+	for (;;) {
+		/* lane 0's token, wave-uniform */
+		u32 kind = 0, lit = 0, length = 0, dist = 0, stop = 0;
+		if (lane == 0) {
+			if (PB_POS(b) > 8 * (winbytes - 32) || 8 * byte0 + PB_POS(b) >= limit) {
+				stop = 1;
+			} else {
+				pb_refill(&b, stage);
+				u32 e = S->lit_tab[(u32)b.buf & ((1u << LIT_TB) - 1)];
+				u32 cl = e & 15, pay = (e >> 4) & 0x3FF;
+				kind = e & 0xC000;
+				if (cl == 0) {
+					u32 sy = decode_long(&S->lit, S->lit_sorted, b.buf, &cl);
+					kind = sy < 256 ? K_LIT : sy == 256 ? K_EOB : K_LEN;
+					pay = sy < 256 ? sy : sy - 257;
+				}
+				b.buf >>= cl;
+				b.cnt -= cl;
+				lit = pay & 0xFF;
+				if (kind == K_LEN) {
+					u32 base, xb;
+					len_sym(pay & 31, &base, &xb);
+					length = base + ((u32)b.buf & ((1u << xb) - 1));
+					b.buf >>= xb;
+					b.cnt -= xb;
+					u32 e2 = S->off_tab[(u32)b.buf & ((1u << OFF_TB) - 1)];
+					u32 ol = e2 & 15, osym = e2 >> 4;
+					if (ol == 0)
+						osym = decode_long(&S->off, S->off_sorted, b.buf, &ol);
+					b.buf >>= ol;
+					b.cnt -= ol;
+					off_sym(osym & 31, &base, &xb);
+					dist = base + ((u32)b.buf & ((1u << xb) - 1));
+					b.buf >>= xb;
+					b.cnt -= xb;
+				}
+				if (8 * byte0 + PB_POS(b) > 8 * in_n)
+					stop = 2;	/* the token runs past the input */
+			}
+		}
+		stop = bcast_first(stop);
+		if (stop == 2) {
+			ret = PAR_STOP;
+			break;
+		}
+		if (stop)
+			break;
+		kind = bcast_first(kind);
+		if (kind == K_EOB) {
+			ret = PAR_EOB;
+			break;
+		}
+		if (kind == K_LIT) {
+			if (MODE == SM_MARK && lane == 0)
+				sym[out] = (u16)lit;
+			out++;
+			continue;
+		}
+		length = bcast_first(length);
+		dist = bcast_first(dist);
+		if (MODE == SM_MARK && dist > out) {
+			*bad_ret = 1;
+		} else if (MODE == SM_MARK) {
+			__threadfence();	/* the symbols stored so far, by any lane */
+			/* byte k of the match is the byte (k mod dist) of the `dist`
+			 * bytes in front of it: all sources are older than the match */
+			const u64 in_chunk = out - chunk_abs;
+			for (u32 k0 = 0; k0 < length; k0 += 64) {
+				const u32 k = k0 + lane;
+				if (k < length) {
+					const u32 back = dist - k % dist;	/* 1..dist */
+					u16 v;
+					if (back > in_chunk)
+						v = (u16)(0x8000u | (32768u - (back - (u32)in_chunk)));
+					else
+						v = sym[out - back];
+					sym[out + k] = v;
+				}
+			}
+		}
+		out += length;
+	}
+	*pos_ret = 8 * byte0 + bcast_first(PB_POS(b));
+	*out_ret = out;
+	if (MODE == SM_MARK)
+		__threadfence();
+	return ret;
+}
+
+/* one chunk on one wave */
+template <int MODE> static __device__ void
+chunk_run(const struct lda_stream_chunk *__restrict__ cd,
+	  struct lda_stream_res *__restrict__ rs, const u8 *__restrict__ inp,
+	  u64 in_n, u16 *__restrict__ sym, u32 *__restrict__ tok)
+{
+	const u32 lane = threadIdx.x;
+	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
+	shlds_t *SH = (shlds_t *)(S + 1);
+	lsym *win = (lsym *)(SH + 1);
+	lu8 *stage = (lu8 *)(win + PAR_RW);
+	const u32 kind = cd->kind;
+	const u64 limit = cd->limit_bit;
+	const u64 chunk_abs = MODE == SM_MARK ? cd->out_off : 0;
+	u64 hdr = cd->hdr_bit, pos = hdr, out = chunk_abs;
+	u64 start_exact = cd->start_bit;
+	u32 final_blk = 0, status = LDA_STREAM_OK, bad = 0, at_boundary = 0;
+	bool in_block = false, first = true;
+	u64 ring_lo = out;
+
+	if (kind != LDA_CHUNK_HEADER) {
+		/* inside a block: its tables, then the start */
+		u64 p2;
+		const u32 r = chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2);
+		if (r != 0 || cd->start_bit < p2) {
+			status = LDA_STREAM_ERR;
+		} else {
+			pos = cd->start_bit;
+			in_block = true;
+			if (kind == LDA_CHUNK_WARM) {
+				/* the first token boundary at or after target_bit */
+				const u64 target = cd->target_bit;
+				while (pos < target && status == LDA_STREAM_OK) {
+					u64 np = pos, no = 0;
+					const u32 pr = chunk_round<SM_COUNT>(
+						inp, in_n, S, SH, tok, win, stage, 0, lane, pos,
+						target, true, sym, 0, 0, &np, &no, &bad);
+					if (pr == PAR_STOP || np <= pos)
+						status = LDA_STREAM_ERR;
+					pos = np;
+				}
+				start_exact = pos;
+			}
+		}
+	}
+	while (status == LDA_STREAM_OK) {
+		if (!in_block) {
+			if (pos >= limit && !first) {
+				at_boundary = 1;
+				break;
+			}
+			first = false;
+			u64 p2;
+			hdr = pos;
+			const u32 r = chunk_header(inp, in_n, S, stage, lane, pos, &final_blk, &p2);
+			if (r == 2) {
+				status = LDA_STREAM_ERR;
+				break;
+			}
+			if (r == 1) {
+				/* stored: lib/decompress_template.h:247-285 */
+				const u64 bp = (p2 + 7) >> 3;
+				if (bp + 4 > in_n) {
+					status = LDA_STREAM_ERR;
+					break;
+				}
+				const u32 len = inp[bp] | ((u32)inp[bp + 1] << 8);
+				const u32 nlen = inp[bp + 2] | ((u32)inp[bp + 3] << 8);
+				if (len != (nlen ^ 0xFFFFu) || len > in_n - (bp + 4)) {
+					status = LDA_STREAM_ERR;
+					break;
+				}
+				if (MODE == SM_MARK) {
+					for (u32 k = lane; k < len; k += 64)
+						sym[out + k] = inp[bp + 4 + k];
+					__threadfence();
+				}
+				out += len;
+				ring_lo = out;
+				pos = 8 * (bp + 4 + len);
+				if (final_blk) {
+					status = LDA_STREAM_FINAL;
+					break;
+				}
+				continue;
+			}
+			pos = p2;
+			in_block = true;
+		}
+		/* tokens of the block, up to its end or the limit */
+		if (pos >= limit)
+			break;
+		u64 np = pos, no = out;
+		u32 pr = chunk_round<MODE>(inp, in_n, S, SH, tok, win, stage, ring_lo, lane,
+					   pos, limit, false, sym, out, chunk_abs, &np, &no, &bad);
+		if (pr == PAR_STOP) {
+			pr = chunk_seq<MODE>(inp, in_n, S, stage, lane, pos, limit, sym, out,
+					     chunk_abs, &np, &no, &bad);
+			ring_lo = no;	/* the mirror does not hold these bytes */
+			if (pr == PAR_STOP || (pr == PAR_OK && np <= pos && np < limit)) {
+				status = LDA_STREAM_ERR;
+				break;
+			}
+		}
+		pos = np;
+		out = no;
+		if (pr == PAR_EOB) {
+			in_block = false;
+			if (final_blk) {
+				status = LDA_STREAM_FINAL;
+				at_boundary = 1;
+				break;
+			}
+		}
+	}
+	if (lane == 0) {
+		rs->start_bit = start_exact;
+		rs->end_bit = pos;
+		rs->end_hdr_bit = in_block ? hdr : pos;
+		rs->nout = out - chunk_abs;
+		rs->status = status;
+		rs->flags = (at_boundary || !in_block ? LDA_RES_BOUNDARY : 0) |
+			    (bad ? LDA_RES_BAD_DIST : 0);
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
+			struct lda_stream_res *res, const u8 *inp, u64 in_n,
+			u32 *tokscratch)
+{
+	if (blockIdx.x < nchunks)
+		chunk_run<SM_COUNT>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, NULL,
+				    tokscratch);	/* (keeps no tokens) */
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+lda_stream_decode_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
+			 struct lda_stream_res *res, const u8 *inp, u64 in_n,
+			 u16 *sym, u32 *tokscratch)
+{
+	if (blockIdx.x < nchunks)
+		chunk_run<SM_MARK>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, sym,
+				   tokscratch + (size_t)blockIdx.x * PAR_SCRATCH);
+}
+
+extern "C" size_t lda_stream_chunk_lds(void)
+{
+	return STREAM_LDS;
+}
+
+extern "C" size_t lda_stream_tokcap(void)
+{
+	return PAR_SCRATCH;
+}
+
+/* ---------------- the block finder ---------------- */
+
+/* 64 bits of input at bit position p (zeros past the end) and the 64 after */
+static __device__ __forceinline__ void
+bits128(const u8 *inp, u64 in_n, u64 p, u64 *x0, u64 *x1)
+{
+	const u64 lo = load_in(inp, in_n, p >> 3), hi = load_in(inp, in_n, (p >> 3) + 8);
+	const u32 sh = (u32)p & 7;
+	*x0 = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+	*x1 = hi >> sh;
+}
+
+/*
+ * Stage A, one thread per bit offset: BTYPE = dynamic, HLIT <= 29, HDIST <= 29,
+ * and the precode lengths form a COMPLETE code (the compressors emit nothing
+ * else; incomplete ones are legal, rare, and found by the chain as ordinary
+ * misses).  About one offset in five hundred passes on compressed data.
+ */
+extern "C" __global__ void __launch_bounds__(256)
+lda_stream_find_a_kernel(const u8 *__restrict__ inp, u64 in_n, u64 nbits,
+			 u64 *__restrict__ queue, u32 *__restrict__ qcount, u32 qcap)
+{
+	const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+	bool pass = false;
+	if (p < nbits) {
+		u64 x0, x1;
+		bits128(inp, in_n, p, &x0, &x1);
+		const u32 h = (u32)x0;
+		if ((h & 6) == 4 && ((h >> 3) & 31) <= 29 && ((h >> 8) & 31) <= 29) {
+			const u32 npre = 4 + ((h >> 13) & 15);
+			u64 f = (x0 >> 17) | (x1 << 47);
+			f &= (1ull << (3 * npre)) - 1;
+			u32 kraft = 0;
+#pragma unroll
+			for (u32 i = 0; i < 19; i++)
+				kraft += (128u >> ((u32)(f >> (3 * i)) & 7)) & 127;
+			pass = kraft == 128;
+		}
+	}
+	const u64 m = __ballot(pass);
+	if (m) {
+		const u32 lane = lane_id();
+		u32 base = 0;
+		if (lane == (u32)__builtin_ctzll(m))
+			base = atomicAdd(qcount, (u32)__builtin_popcountll(m));
+		base = bcast_lane(base, (u32)__builtin_ctzll(m));
+		if (pass) {
+			const u32 at = base + __builtin_popcountll(m & ((1ull << lane) - 1));
+			if (at < qcap)
+				queue[at] = p;
+		}
+	}
+}
+
+/*
+ * Stage B, one thread per survivor: the code lengths decoded in full
+ * (decompress_template.h:150-245) and both codes checked for what
+ * build_decode_table() accepts and a compressor produces: the litlen code
+ * complete with an end-of-block symbol; the offset code complete, or a single
+ * 1-bit codeword, or empty.
+ */
+extern "C" __global__ void __launch_bounds__(64)
+lda_stream_find_b_kernel(const u8 *__restrict__ inp, u64 in_n,
+			 const u64 *__restrict__ queue, const u32 *__restrict__ qcount,
+			 u32 qcap, u64 *__restrict__ cand, u32 *__restrict__ ncand, u32 ccap)
+{
+	u32 nq = *qcount;
+	nq = nq < qcap ? nq : qcap;
+	const u32 idx = blockIdx.x * 64 + threadIdx.x;
+	if (idx >= nq)
+		return;
+	lu16 *tab = (lu16 *)(uintptr_t)(threadIdx.x * 256u);
+	const u64 p = queue[idx];
+	u64 x0, x1;
+	bits128(inp, in_n, p, &x0, &x1);
+	const u32 h = (u32)x0;
+	const u32 nlit = 257 + ((h >> 3) & 31), noff = 1 + ((h >> 8) & 31);
+	const u32 npre = 4 + ((h >> 13) & 15);
+	u64 f = (x0 >> 17) | (x1 << 47);
+	u8 plens[19];
+	for (u32 i = 0; i < 19; i++)
+		plens[i] = 0;
+	for (u32 i = 0; i < npre; i++)
+		plens[c_pre_perm[i]] = (u8)((f >> (3 * i)) & 7);
+	if (!build_precode(tab, plens))
+		return;
+	u64 bp = p + 17 + 3 * npre;	/* next bit to read */
+	u64 buf = 0;
+	u32 cnt = 0;
+	u32 i = 0, prev = 0, kl = 0, ko = 0, n_o = 0, eob_len = 0;
+	const u32 total = nlit + noff;
+	bool ok = true;
+	while (i < total) {
+		if (cnt < 14) {
+			buf = load_in(inp, in_n, bp >> 3) >> (bp & 7);
+			cnt = 56;	/* at least 57 valid bits */
+		}
+		const u32 e = tab[(u32)buf & 127];
+		u32 used = e & 15;
+		const u32 presym = e >> 4;
+		u32 rep = 1, val = presym;
+		if (presym >= 16) {
+			if (presym == 16) {
+				if (i == 0) {
+					ok = false;
+					break;
+				}
+				val = prev;
+				rep = 3 + ((u32)(buf >> used) & 3);
+				used += 2;
+			} else if (presym == 17) {
+				val = 0;
+				rep = 3 + ((u32)(buf >> used) & 7);
+				used += 3;
+			} else {
+				val = 0;
+				rep = 11 + ((u32)(buf >> used) & 127);
+				used += 7;
+			}
+		}
+		buf >>= used;
+		cnt -= used;
+		bp += used;
+		if (i + rep > total) {
+			ok = false;
+			break;
+		}
+		if (val) {
+			const u32 w = 32768u >> val;
+			const u32 n1 = i < nlit ? (rep < nlit - i ? rep : nlit - i) : 0;
+			kl += n1 * w;
+			ko += (rep - n1) * w;
+			n_o += rep - n1;
+			if (i <= 256 && 256 < i + n1)
+				eob_len = val;
+		}
+		prev = val;
+		i += rep;
+	}
+	if (!ok || bp > 8 * in_n)
+		return;
+	if (kl != 32768 || eob_len == 0)
+		return;
+	if (!(ko == 32768 || (ko == 16384 && n_o == 1) || ko == 0))
+		return;
+	const u32 at = atomicAdd(ncand, 1u);
+	if (at < ccap)
+		cand[at] = p;
+}
+
+/* ---------------- markers -> bytes ---------------- */
+
+/*
+ * The window chain: chunk after chunk, the last min(length, 32 KiB) symbols
+ * of chunk c are settled against the 32 KiB in front of it (held in LDS) and
+ * written to the output; they are the window of chunk c + 1.  One workgroup;
+ * the symbols of the next chunk are requested before this one's are settled.
+ */
+extern "C" __global__ void __launch_bounds__(1024)
+lda_stream_window_kernel(u32 nchunks, const u64 *__restrict__ out_off /*[nchunks + 1]*/,
+			 const u16 *__restrict__ sym, u8 *__restrict__ out,
+			 u32 *__restrict__ err)
+{
+	__shared__ u8 W[2][32768];
+	const u32 tid = threadIdx.x;
+	u32 cur = 0, bad = 0;
+	u16 nx[32];
+	/* tail of chunk c: symbols [t0, e) with e - t0 = min(len, 32768) */
+	auto load_tail = [&](u32 c) {
+		const u64 s = out_off[c], e = out_off[c + 1];
+		const u64 t0 = e - s > 32768 ? e - 32768 : s;
+		const u32 n = (u32)(e - t0);
+#pragma unroll
+		for (u32 k = 0; k < 32; k++) {
+			const u32 i = tid + 1024 * k;
+			nx[k] = i < n ? sym[t0 + i] : 0;
+		}
+	};
+	load_tail(0);
+	for (u32 c = 0; c < nchunks; c++) {
+		const u64 s = out_off[c], e = out_off[c + 1];
+		const u64 t0 = e - s > 32768 ? e - 32768 : s;
+		const u32 n = (u32)(e - t0);
+		/* window in front of the TAIL: for a long chunk the tail's markers
+		 * still refer to the window in front of the CHUNK; a marker w means
+		 * absolute position s - 32768 + w */
+		u16 v[32];
+#pragma unroll
+		for (u32 k = 0; k < 32; k++)
+			v[k] = nx[k];
+		if (c + 1 < nchunks)
+			load_tail(c + 1);
+		const u8 *Wc = W[cur];
+		u8 *Wn = W[cur ^ 1];
+		/* positions before the stream's first byte */
+		const u32 lowest = s < 32768 ? 32768 - (u32)s : 0;
+#pragma unroll
+		for (u32 k = 0; k < 32; k++) {
+			const u32 i = tid + 1024 * k;
+			if (i < n) {
+				u32 b = v[k];
+				if (b & 0x8000) {
+					const u32 w = b & 0x7FFF;
+					if (w < lowest) {
+						bad = 1;
+						b = 0;
+					} else {
+						b = Wc[w];
+					}
+				}
+				Wn[32768 - n + i] = (u8)b;
+				out[t0 + i] = (u8)b;
+			}
+			/* a short chunk keeps the end of the old window */
+			if (i < 32768 - n)
+				Wn[i] = Wc[i + n];
+		}
+		__syncthreads();
+		cur ^= 1;
+	}
+	if (bad)
+		*err = 1;
+}
+
+/* everything in front of a chunk's tail, 8 symbols per thread */
+extern "C" __global__ void __launch_bounds__(256)
+lda_stream_resolve_kernel(u32 nchunks, const u64 *__restrict__ out_off,
+			  const u16 *__restrict__ sym, u8 *__restrict__ out,
+			  u32 *__restrict__ err)
+{
+	const u32 c = blockIdx.y;
+	if (c >= nchunks)
+		return;
+	const u64 s = out_off[c], e = out_off[c + 1];
+	if (e - s <= 32768)
+		return;		/* all of it is tail */
+	const u64 t0 = e - 32768;
+	const u32 lowest = s < 32768 ? 32768 - (u32)s : 0;
+	const u8 *win = out + s - 32768;	/* (never read below `lowest`) */
+	for (u64 i = s + 8 * ((u64)blockIdx.x * 256 + threadIdx.x); i < t0;
+	     i += 8ull * 256 * gridDim.x) {
+		u64 r = 0;
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			if (i + k < t0) {
+				u32 b = sym[i + k];
+				if (b & 0x8000) {
+					const u32 w = b & 0x7FFF;
+					if (w < lowest) {
+						*err = 1;
+						b = 0;
+					} else {
+						b = win[w];
+					}
+				}
+				r |= (u64)(b & 0xFF) << (8 * k);
+			}
+		}
+		if (i + 8 <= t0) {
+			__builtin_memcpy(out + i, &r, 8);
+		} else {
+			for (u32 k = 0; i + k < t0; k++)
+				out[i + k] = (u8)(r >> (8 * k));
+		}
+	}
+}

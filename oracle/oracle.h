@@ -57,6 +57,23 @@ int oracle_gzip_decompress(const void *in, size_t in_nbytes,
 			   void *out, size_t out_avail,
 			   size_t *actual_in, size_t *actual_out);
 
+/*
+ * The block structure of a raw DEFLATE stream, for testing the product's
+ * block finder: decodes like oracle_deflate_decompress() and records every
+ * block header reached (bit position of BFINAL, BTYPE | 4 * BFINAL, output
+ * bytes before it).  Returns the number of blocks (may exceed cap; only cap
+ * are stored); *result = the decoder's result code.
+ */
+struct oracle_block {
+	uint64_t bit;
+	uint64_t out_pos;
+	uint32_t type;
+	uint32_t pad;
+};
+size_t oracle_deflate_block_map(const void *in, size_t in_nbytes, void *out,
+				size_t out_avail, struct oracle_block *blocks,
+				size_t cap, int *result);
+
 /* compress bounds (pure functions of n) */
 size_t oracle_deflate_compress_bound(size_t n);
 size_t oracle_zlib_compress_bound(size_t n);

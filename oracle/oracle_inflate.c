@@ -169,6 +169,32 @@ static const uint8_t off_extra[32] = {
 	0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10,
 	10, 11, 11, 12, 12, 13, 13, 13, 13 };
 
+/*
+ * Block map (test infrastructure for the parallel single-stream decoder's
+ * block finder): while a trace is installed, every block header the decoder
+ * reaches is recorded - bit position of its BFINAL bit, BTYPE, bytes of
+ * output before it.
+ */
+static __thread struct oracle_block *trace_blocks;
+static __thread size_t trace_cap, trace_n;
+
+size_t oracle_deflate_block_map(const void *in, size_t in_nbytes, void *out,
+				size_t out_avail, struct oracle_block *blocks,
+				size_t cap, int *result)
+{
+	int r;
+
+	trace_blocks = blocks;
+	trace_cap = cap;
+	trace_n = 0;
+	r = oracle_deflate_decompress(in, in_nbytes, out, out_avail, NULL,
+				      &(size_t){ 0 });
+	trace_blocks = NULL;
+	if (result)
+		*result = r;
+	return trace_n;
+}
+
 int oracle_deflate_decompress(const void *in_, size_t in_nbytes,
 			      void *out_, size_t out_avail,
 			      size_t *actual_in, size_t *actual_out)
@@ -188,8 +214,19 @@ int oracle_deflate_decompress(const void *in_, size_t in_nbytes,
 		/* next_block: decompress_template.h:72-83 */
 		if (!refill(&b))
 			return ORACLE_BAD_DATA;
+		if (trace_blocks) {
+			if (trace_n < trace_cap) {
+				trace_blocks[trace_n].bit = b.consumed;
+				trace_blocks[trace_n].out_pos = outpos;
+			}
+		}
 		final = (int)getbits(&b, 1);
 		type = getbits(&b, 2);
+		if (trace_blocks) {
+			if (trace_n < trace_cap)
+				trace_blocks[trace_n].type = type | (final ? 4u : 0u);
+			trace_n++;
+		}
 
 		if (type == 0) {
 			/* stored: decompress_template.h:247-285 */

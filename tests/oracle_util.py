@@ -35,6 +35,22 @@ class Oracle:
             fn.restype = c_uint32
             fn.argtypes = [c_uint32, c_char_p, SZ]
 
+    def block_map(self, data, out_avail, cap=1 << 16):
+        """Blocks of a raw DEFLATE stream: [(bit, out_pos, btype, final)],
+        and the decoder's result code."""
+        class Blk(ctypes.Structure):
+            _fields_ = [("bit", ctypes.c_uint64), ("out_pos", ctypes.c_uint64),
+                        ("type", c_uint32), ("pad", c_uint32)]
+        fn = self.lib.oracle_deflate_block_map
+        fn.restype = SZ
+        fn.argtypes = [c_char_p, SZ, c_void_p, SZ, c_void_p, SZ, POINTER(c_int)]
+        out = ctypes.create_string_buffer(max(out_avail, 1))
+        blocks = (Blk * cap)()
+        res = c_int(0)
+        n = fn(bytes(data), len(data), out, out_avail, blocks, cap, ctypes.byref(res))
+        return [(b.bit, b.out_pos, b.type & 3, b.type >> 2)
+                for b in blocks[:min(n, cap)]], res.value
+
     def decompress_ex(self, fmt, data, out_avail, want_actual_out=True):
         out = ctypes.create_string_buffer(max(out_avail, 1))
         ai, ao = SZ(0), SZ(0)

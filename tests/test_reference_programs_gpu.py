@@ -45,7 +45,9 @@ def test_reference_slow_decompression_program():
     exe = os.path.join(DIR, "test_slow_decompression")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/reftests not built")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    # (the reference skips its performance tests unless asked: test_util.c:53-59)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, INCLUDE_PERF_TESTS="1"))
     out = r.stdout + r.stderr
     print(out[-600:])
     assert "static huffman, libdeflate" in out, out[-2000:]

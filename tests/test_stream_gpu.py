@@ -1,0 +1,199 @@
+"""ONE large stream on many waves (csrc/inflate_stream.hip, host_stream.hip)
+through the reference's single-buffer calls, libdeflate_*_decompress[_ex]
+(libdeflate.h:242-315) - what programs/gzip.c:187-303 and the 1 MiB chunks of
+programs/benchmark.c:543-544 hand to the library.  Streams compressed by the
+real reference (zlib where oracle/_ref did not travel); every byte, actual_in /
+actual_out and every result code against the oracle, and
+libdeflate_amd_stream_stats() says which path answered."""
+import os
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from libdeflate_amd import binding
+from tests import datagen, oracle_util, streams
+
+pytestmark = pytest.mark.gpu
+WBITS = {"deflate": -15, "zlib": 15, "gzip": 31}
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from libdeflate_amd import api
+    d = api.Decompressor()
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def comp():
+    ref = oracle_util.load_ref()
+    if ref is not None:
+        return lambda fmt, lvl, d: ref.compress(fmt, lvl, d)
+    return lambda fmt, lvl, d: streams._zcompress(fmt, min(lvl, 9), d)
+
+
+def _data(kind, n, seed):
+    if kind == "text":
+        return datagen.text_chunk(n, seed)
+    return b"".join(datagen.chunk(i, 65536, seed) for i in range((n + 65535) // 65536))[:n]
+
+
+@pytest.mark.parametrize("mib,level,kind", [
+    (1, 1, "text"), (1, 6, "mix"), (1, 12, "text"),
+    (4, 1, "mix"), (4, 6, "text"), (4, 12, "mix"),
+    (16, 1, "text"), (16, 6, "text"), (16, 6, "mix"), (16, 12, "text")])
+def test_large_streams(dec, comp, mib, level, kind):
+    n = mib << 20
+    data = _data(kind, n, 0x51000 + mib + level)
+    fmt = ("gzip", "zlib", "deflate")[(mib + level) % 3]
+    z = comp(fmt, level, data)
+    r = dec.decompress_ex(fmt, z, n)
+    st = binding.stream_stats()
+    assert r[:3] == (0, len(z), n), (r[:3], st)
+    assert r[3] == data
+    assert st["parallel"] == 1, st
+    assert st["bytes"] == n
+    # exact fill (actual_out_nbytes_ret = NULL) and trailing bytes
+    r2 = dec.decompress(fmt, z + b"\x00\x01\x02", n, False)
+    assert r2[0] == 0 and r2[2] == data
+    assert binding.stream_stats()["parallel"] == 1
+    print(f"{mib} MiB {kind} L{level} {fmt}: {st}")
+
+
+def test_sixteen_mib_rate(dec, comp):
+    """a 16 MiB reference-compressed gzip stream through
+    libdeflate_gzip_decompress, host to host, at one core's rate or better."""
+    n = 16 << 20
+    data = datagen.text_chunk(n, 0x51777)
+    z = comp("gzip", 6, data)
+    out = np.zeros(n, dtype=np.uint8)
+    from ctypes import c_size_t, c_void_p, byref
+    lib = binding.load()
+    zin = np.frombuffer(z, dtype=np.uint8)
+    best = 1e9
+    for _ in range(5):
+        ao = c_size_t(0)
+        t0 = time.perf_counter()
+        r = lib.libdeflate_gzip_decompress(dec._h, zin.ctypes.data_as(c_void_p), zin.size,
+                                           out.ctypes.data_as(c_void_p), n, byref(ao))
+        best = min(best, time.perf_counter() - t0)
+        assert r == 0 and ao.value == n
+    assert out.tobytes() == data
+    st = binding.stream_stats()
+    assert st["parallel"] == 1, st
+    print(f"16 MiB gzip L6 text, host to host: {best * 1e3:.2f} ms = {n / best / 1e9:.2f} GB/s; {st}")
+    assert n / best / 1e9 >= 1.2
+
+
+def test_result_codes_of_damaged_large_streams(dec, comp, oracle):
+    n = 3 << 20
+    data = _data("mix", n, 0x52000)
+    for fmt in ("deflate", "gzip", "zlib"):
+        z = comp(fmt, 6, data)
+        rng = np.random.default_rng(7)
+        variants = [("ok", z, n), ("short", z, n + 1), ("nospace", z, n - 1),
+                    ("trunc1", z[:len(z) // 3], n), ("trunc2", z[:-9], n),
+                    ("trunc3", z[:-1], n)]
+        for k in range(6):
+            b = bytearray(z)
+            pos = int(rng.integers(0, len(b)))
+            b[pos] ^= 1 << int(rng.integers(0, 8))
+            variants.append((f"flip{k}@{pos}", bytes(b), n))
+        b = bytearray(z)
+        b[-5] ^= 0x40       # footer (or, raw: the stream's last bytes)
+        variants.append(("footer", bytes(b), n))
+        for name, s, avail in variants:
+            for want in (True, False):
+                got = dec.decompress_ex(fmt, s, avail, want)
+                exp = oracle.decompress_ex(fmt, s, avail, want)
+                assert got[0] == exp[0], (fmt, name, want, got[:3], exp[:3], binding.stream_stats())
+                if exp[0] == 0:
+                    assert got[1] == exp[1] and got[3] == exp[3], (fmt, name, want)
+                    if want:
+                        assert got[2] == exp[2]
+
+
+def _static_block_stream(data):
+    """ONE static Huffman block holding `data` as literals."""
+    w = streams.BitWriter()
+    w.put(1, 1)
+    w.put(1, 2)
+    for b in data:
+        streams._static_lit(w, b)
+    streams._static_lit(w, 256)
+    return w.finish()
+
+
+def test_streams_the_finder_cannot_enter(dec, oracle):
+    """Stored-only, static-only and one-giant-block streams have no dynamic
+    block header to find (or only one): chunk 0 walks them, or the sequential
+    kernel answers; the bytes and codes are the oracle's either way."""
+    rnd = datagen.random_chunk(2 << 20, 5)
+    stored = streams._zcompress("deflate", 0, rnd)
+    r = dec.decompress_ex("deflate", stored, len(rnd))
+    print("stored-only:", binding.stream_stats())
+    assert r == (0, len(stored), len(rnd), rnd)
+    txt = datagen.text_chunk(1 << 20, 9)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    fixed = co.compress(txt) + co.flush()
+    r = dec.decompress_ex("deflate", fixed, len(txt))
+    print("static blocks:", binding.stream_stats())
+    assert r == (0, len(fixed), len(txt), txt)
+    giant = _static_block_stream(txt[:200000])
+    r = dec.decompress_ex("deflate", giant, 200000)
+    print("one static block:", binding.stream_stats())
+    assert r == (0, len(giant), 200000, txt[:200000])
+    # one dynamic block as large as zlib makes them, then the same bytes twice
+    co = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+    big = datagen.lowentropy_chunk(600000, 3)
+    z = co.compress(big) + co.flush()
+    r = dec.decompress_ex("deflate", z, len(big))
+    print("zlib memLevel 9:", binding.stream_stats())
+    assert r == (0, len(z), len(big), big)
+    zeros = bytes(8 << 20)
+    z = streams._zcompress("gzip", 9, zeros)
+    r = dec.decompress_ex("gzip", z, len(zeros))
+    print("8 MiB of zeros:", binding.stream_stats())
+    assert r == (0, len(z), len(zeros), zeros)
+
+
+def test_small_chunks_everything_through_the_stream_path(dec, oracle, comp, monkeypatch):
+    """Every stream, however small, through the many-wave path with 4 KiB
+    chunks: the chunk kernels' edge cases (a stream shorter than a round, the
+    last bytes of the input, empty blocks, tiny blocks) against the oracle."""
+    monkeypatch.setenv("LDA_STREAM_PAR_MIN", "0")
+    monkeypatch.setenv("LDA_STREAM_CHUNK", "4096")
+    binding.reload_env()
+    cases = streams.random_cases(31, 120, compress=comp,
+                                 sizes=[0, 1, 5, 100, 1000, 5000, 20000, 70000, 300000])
+    cases += [(f, s, a, w, t) for f, s, a, w, t in streams.garbage_cases(32, 60)]
+    for s, want in streams.stored_then_match_streams():
+        cases.append(("deflate", s, len(want), True, "stored_then_match"))
+    for name, s, want in streams.parallel_round_streams():
+        cases.append(("deflate", s, len(want), True, name))
+    for s in (streams.empty_static_blocks(), streams.empty_dynamic_blocks()):
+        cases.append(("deflate", s, 10000, True, "slow"))
+    npar = 0
+    for fmt, s, avail, want, tag in cases:
+        got = dec.decompress_ex(fmt, s, avail, want)
+        npar += binding.stream_stats()["parallel"]
+        exp = oracle.decompress_ex(fmt, s, avail, want)
+        assert got[0] == exp[0], (tag, fmt, got[:3], exp[:3], binding.stream_stats())
+        if exp[0] == 0:
+            assert got[1] == exp[1] and got[3] == exp[3], (tag, fmt, binding.stream_stats())
+            if want:
+                assert got[2] == exp[2]
+    print(f"{npar} of {len(cases)} cases were answered by the many-wave path")
+    assert npar >= len(cases) // 8
+
+
+def test_switch_off(dec, comp, monkeypatch):
+    data = datagen.text_chunk(1 << 20, 77)
+    z = comp("gzip", 6, data)
+    monkeypatch.setenv("LDA_NO_STREAM_PAR", "1")
+    binding.reload_env()
+    assert dec.decompress_ex("gzip", z, len(data)) == (0, len(z), len(data), data)
+    assert binding.stream_stats()["parallel"] == 0
