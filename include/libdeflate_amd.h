@@ -354,11 +354,12 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
  * 7 output does not fill, 8 decode pass disagrees, 9 device, 10 too many
  * repairs); [2] bit offsets that passed the first filter of the block finder;
  * [3] block starts found; [4] chunks planned; [5] repairs; [6] chunks decoded;
- * [7] bytes produced.
+ * [7] bytes produced; [8..13] host-side microseconds of: copy in, block finder,
+ * count pass + chain, decode + window + resolve, checksum, copy out.
  */
-#define LIBDEFLATE_AMD_STREAM_STATS 8
+#define LIBDEFLATE_AMD_STREAM_STATS 16
 LIBDEFLATEAPI void
-libdeflate_amd_stream_stats(uint64_t *out /* [8] */);
+libdeflate_amd_stream_stats(uint64_t *out /* [16] */);
 
 /*
  * A gzip buffer of SEVERAL members (concatenated .gz files, pigz -i, BGZF).

@@ -131,10 +131,11 @@ def reload_env():
 def stream_stats():
     """libdeflate_amd_stream_stats: what the last single-buffer decompress
     call of this thread did (see include/libdeflate_amd.h)."""
-    out = (c_uint64 * 8)()
+    out = (c_uint64 * 16)()
     load().libdeflate_amd_stream_stats(out)
     keys = ("parallel", "why_not", "filter_a", "blocks_found", "chunks_planned",
-            "repairs", "chunks_decoded", "bytes")
+            "repairs", "chunks_decoded", "bytes", "us_in", "us_find", "us_count",
+            "us_decode", "us_sum", "us_out")
     return dict(zip(keys, [int(v) for v in out]))
 
 

@@ -38,7 +38,7 @@ struct DeviceCtx {
 	/* the kernels' dynamic-LDS limits are raised once per device (setting
 	 * them again is harmless, so a race between two first calls only repeats
 	 * it); part of the context so that no table is indexed by a device id */
-	std::atomic<bool> deflate_attr_set{false}, inflate_attr_set{false};
+	std::atomic<bool> deflate_attr_set{false}, inflate_attr_set{false}, stream_attr_set{false};
 };
 
 /* context of the calling thread's current device; nullptr (+error) if none */

@@ -115,6 +115,8 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->tokens.release();
 	d->sin.release();
 	d->schunks.release();
+	d->srepair.release();
+	d->swin.release();
 	d->ssym.release();
 	d->sout.release();
 	d->pinned.release();

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <map>
 #include <vector>
 
 #include "host_objects.h"
@@ -110,6 +112,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 {
 	uint64_t *S = g_stats;
 	memset(g_stats, 0, sizeof(g_stats));
+	/* host-side phase clock: S[8..13] = microseconds of copy in, find, count +
+	 * chain, decode + window + resolve, checksum, copy out */
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](int slot) {
+		const auto now = std::chrono::steady_clock::now();
+		S[slot] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(now - t_last).count();
+		t_last = now;
+	};
 	DeviceCtx *ctx = device_ctx();
 	const EnvCfg &env = env_cfg();
 	if (!ctx || env.no_stream_par || in_nbytes < env.stream_par_min) {
@@ -147,6 +157,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		if (copy_in_packed(&d->pinned, sin, 1, ins, &in_nbytes, off, s_copy) != LIBDEFLATE_AMD_OK)
 			return false;
 	}
+	lap(8);
 	uint64_t *d_queue = (uint64_t *)(sin + q_at), *d_cand = (uint64_t *)(sin + c_at);
 	uint32_t *d_cnt = (uint32_t *)(sin + cnt_at);	/* [0] queue, [1] candidates, [2] error flag */
 	ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
@@ -172,6 +183,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		S[3] = nc;
 	}
 
+	lap(9);
 	/* ---- plan ---- */
 	uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk : raw_n / 512;
 	T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 4096), 65536);
@@ -201,16 +213,28 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		}
 	};
 	{
-		/* block starts: the stream's first bit, then the candidates that are
-		 * not too close to the chunk start before them */
-		std::vector<std::pair<uint64_t, bool>> starts;
-		starts.push_back({ 0, !cands.empty() && cands[0] == 0 });
-		for (uint64_t c : cands)
-			if (c >= starts.back().first + T / 2)
-				starts.push_back({ c, true });
-		for (size_t i = 0; i < starts.size(); i++)
-			add_block(starts[i].first, i + 1 < starts.size() ? starts[i + 1].first : raw_bits,
-				  starts[i].second);
+		/* block starts: the stream's first bit, then the candidates.  A block's
+		 * inner chunks end at the next candidate whatever becomes of it; a small
+		 * block close behind a chunk start gets no chunk of its own (the chunk
+		 * in front of it walks through), so chunk starts are at least T / 8
+		 * apart however small the blocks are */
+		std::vector<uint64_t> cs;
+		bool first_dynamic = false;
+		for (uint64_t c : cands) {
+			if (c == 0)
+				first_dynamic = true;
+			else
+				cs.push_back(c);
+		}
+		uint64_t last_at = 0;
+		add_block(0, cs.empty() ? raw_bits : cs[0], first_dynamic);
+		for (size_t i = 0; i < cs.size(); i++) {
+			const uint64_t next = i + 1 < cs.size() ? cs[i + 1] : raw_bits;
+			if (cs[i] - last_at < T / 8 && next - cs[i] < T / 2)
+				continue;
+			add_block(cs[i], next, true);
+			last_at = cs[i];
+		}
 	}
 	for (size_t i = 0; i < plan.size(); i++)
 		plan[i].c.limit_bit = i + 1 < plan.size() ? plan[i + 1].at : raw_bits;
@@ -219,9 +243,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 
 	/* ---- count ---- */
 	const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
-	const size_t rep_at = res_at + align_up((size_t)np * sizeof(lda_stream_res) + 64, 64);
-	const size_t off_at = rep_at + 256;
-	uint8_t *sch = (uint8_t *)d->schunks.reserve(off_at + ((size_t)np + 2) * 8 + 64);
+	uint8_t *sch = (uint8_t *)d->schunks.reserve(
+		res_at + align_up((size_t)np * sizeof(lda_stream_res) + 64, 64));
 	if (!sch)
 		return false;
 	lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
@@ -238,77 +261,148 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			      hipMemcpyDeviceToHost, s_comp));
 	ST_TRY(hipStreamSynchronize(s_comp));
 
-	/* ---- chain ---- */
+	/* ---- chain ----
+	 * Every counted chunk is a pool entry keyed by its exact start state.  The
+	 * walk from chunk 0 follows end state -> start state; where an end state
+	 * has no chunk starting there (a block the finder does not look for, a
+	 * false candidate, a warm-up that did not fall in step) a REPAIR chunk is
+	 * counted from that state up to the next planned start.  Repairs are made
+	 * for every open end in the pool at once, one launch per round, so the
+	 * number of host round trips is the longest run of consecutive breaks, not
+	 * the number of breaks. */
 	std::vector<lda_stream_chunk> acc;	/* accepted chunks, exact starts */
 	std::vector<lda_stream_res> accr;
 	{
-		lda_stream_chunk cur = hc[0];
-		lda_stream_res r = hr[0];
-		size_t next = 1;	/* first planned chunk not yet passed */
-		uint32_t repairs = 0;
-		const uint32_t max_repairs = 24 + np / 8;
-		for (;;) {
-			if (r.status == LDA_STREAM_ERR) {
-				S[1] = WHY_ERRCHUNK;
-				return false;
-			}
-			cur.start_bit = r.start_bit;
-			if (cur.kind == LDA_CHUNK_WARM)
-				cur.kind = LDA_CHUNK_EXACT;
-			acc.push_back(cur);
-			accr.push_back(r);
-			if (r.status == LDA_STREAM_FINAL)
-				break;
-			if (r.end_bit >= raw_bits) {
-				S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
-				return false;
-			}
-			/* the planned chunk that starts exactly where this one ended */
-			const bool bnd = r.flags & LDA_RES_BOUNDARY;
-			size_t j = next;
-			bool found = false;
-			while (j < np && plan[j].at <= r.end_bit) {
-				const lda_stream_chunk &c = hc[j];
-				const lda_stream_res &q = hr[j];
-				if (bnd ? (c.kind == LDA_CHUNK_HEADER && c.hdr_bit == r.end_bit) :
-					  (c.kind == LDA_CHUNK_WARM && q.status != LDA_STREAM_ERR &&
-					   q.start_bit == r.end_bit && c.hdr_bit == r.end_hdr_bit)) {
-					found = true;
+		typedef std::pair<uint64_t, uint64_t> key_t;	/* (start_bit * 2 + boundary, header) */
+		std::map<key_t, uint32_t> by_start;
+		std::vector<lda_stream_chunk> pc(hc);
+		std::vector<lda_stream_res> pr(hr);
+		auto start_key = [&](uint32_t i) -> key_t {
+			if (pc[i].kind == LDA_CHUNK_HEADER)
+				return key_t(pc[i].hdr_bit * 2 + 1, pc[i].hdr_bit);
+			return key_t(pr[i].start_bit * 2, pc[i].hdr_bit);
+		};
+		auto end_key = [&](uint32_t i) -> key_t {
+			const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
+			return key_t(pr[i].end_bit * 2 + (bnd ? 1 : 0), bnd ? pr[i].end_bit : pr[i].end_hdr_bit);
+		};
+		for (uint32_t i = 0; i < np; i++)
+			if (pc[i].kind == LDA_CHUNK_HEADER || pr[i].status != LDA_STREAM_ERR)
+				by_start.emplace(start_key(i), i);
+		std::vector<uint64_t> ats(np);
+		for (uint32_t i = 0; i < np; i++)
+			ats[i] = plan[i].at;
+		std::vector<uint32_t> path;
+		uint32_t repairs = 0, first_open = 0;
+		const uint32_t max_repairs = 64 + 2 * np;
+		bool closed = false;
+		for (int round = 0; round < 16 && !closed; round++) {
+			path.clear();
+			uint32_t cur = 0;
+			for (;;) {
+				path.push_back(cur);
+				if (pr[cur].status == LDA_STREAM_ERR) {
+					S[1] = WHY_ERRCHUNK;
+					return false;
+				}
+				if (pr[cur].status == LDA_STREAM_FINAL) {
+					closed = true;
 					break;
 				}
-				j++;
+				if (pr[cur].end_bit >= raw_bits || path.size() > pc.size()) {
+					S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
+					return false;
+				}
+				auto it = by_start.find(end_key(cur));
+				if (it == by_start.end())
+					break;
+				cur = it->second;
 			}
-			if (found) {
-				cur = hc[j];
-				r = hr[j];
-				next = j + 1;
-				continue;
+			if (closed)
+				break;
+			if (getenv("LDA_STREAM_DEBUG")) {
+				const uint32_t e = path.back();
+				const uint64_t eb = pr[e].end_bit;
+				auto nx = std::upper_bound(ats.begin(), ats.end(), eb);
+				size_t j = nx - ats.begin();
+				fprintf(stderr, "round %d: walk of %zu stops after chunk %u (kind %u hdr %llu start %llu) "
+					"end %llu bnd %u endhdr %llu status %u nout %llu\n", round, path.size(), e, pc[e].kind,
+					(unsigned long long)pc[e].hdr_bit, (unsigned long long)pr[e].start_bit,
+					(unsigned long long)eb, pr[e].flags & 1, (unsigned long long)pr[e].end_hdr_bit,
+					pr[e].status, (unsigned long long)pr[e].nout);
+				for (size_t k = j ? j - 1 : 0; k < j + 2 && k < np; k++)
+					fprintf(stderr, "   planned %zu: kind %u at %llu hdr %llu ws %llu -> start %llu end %llu status %u\n",
+						k, hc[k].kind, (unsigned long long)plan[k].at, (unsigned long long)hc[k].hdr_bit,
+						(unsigned long long)hc[k].start_bit, (unsigned long long)hr[k].start_bit,
+						(unsigned long long)hr[k].end_bit, hr[k].status);
 			}
-			/* repair: count from the exact end state up to the next planned start */
-			if (++repairs > max_repairs) {
-				S[1] = WHY_REPAIRS;
-				S[5] = repairs;
-				return false;
+			/* repairs for every open end (entries added in earlier rounds
+			 * were looked at then: start at first_open) */
+			std::vector<lda_stream_chunk> rc;
+			const uint32_t npool = (uint32_t)pc.size();
+			std::map<key_t, int> asked;
+			for (uint32_t i = first_open; i < npool; i++) {
+				if (pr[i].status != LDA_STREAM_OK || pr[i].end_bit >= raw_bits)
+					continue;
+				const key_t k = end_key(i);
+				if (by_start.count(k) || asked.count(k))
+					continue;
+				asked[k] = 1;
+				const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
+				lda_stream_chunk c = {};
+				c.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
+				c.hdr_bit = bnd ? pr[i].end_bit : pr[i].end_hdr_bit;
+				c.start_bit = c.target_bit = pr[i].end_bit;
+				auto nx = std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit);
+				c.limit_bit = nx == ats.end() ? raw_bits : *nx;
+				rc.push_back(c);
 			}
-			next = j;
-			lda_stream_chunk rc = {};
-			rc.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
-			rc.hdr_bit = r.end_hdr_bit;
-			rc.start_bit = rc.target_bit = r.end_bit;
-			rc.limit_bit = j < np ? plan[j].at : raw_bits;
-			lda_stream_chunk *d_rc = (lda_stream_chunk *)(sch + rep_at);
-			lda_stream_res *d_rr = (lda_stream_res *)(sch + rep_at + 128);
-			lda_stream_res rr;
-			ST_TRY(hipMemcpyAsync(d_rc, &rc, sizeof(rc), hipMemcpyHostToDevice, s_comp));
-			if (!launch_count(s_comp, 1, d_rc, d_rr, d_raw, raw_n))
-				return false;
-			ST_TRY(hipMemcpyAsync(&rr, d_rr, sizeof(rr), hipMemcpyDeviceToHost, s_comp));
-			ST_TRY(hipStreamSynchronize(s_comp));
-			cur = rc;
-			r = rr;
+			/* the open end of the walk is always among them (round 0 looks at
+			 * all entries; later rounds at the new ones, and the walk can only
+			 * have stopped at a new one) */
+			first_open = npool;
+			repairs += (uint32_t)rc.size();
 			S[5] = repairs;
+			if (rc.empty() || repairs > max_repairs) {
+				S[1] = rc.empty() ? WHY_CHAIN : WHY_REPAIRS;
+				return false;
+			}
+			const uint32_t nr = (uint32_t)rc.size();
+			uint8_t *rp = (uint8_t *)d->srepair.reserve(
+				(size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 128);
+			if (!rp)
+				return false;
+			lda_stream_chunk *d_rc = (lda_stream_chunk *)rp;
+			lda_stream_res *d_rr = (lda_stream_res *)(rp + align_up((size_t)nr * sizeof(lda_stream_chunk), 64));
+			std::vector<lda_stream_res> rr(nr);
+			ST_TRY(hipMemcpyAsync(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk),
+					      hipMemcpyHostToDevice, s_comp));
+			if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, raw_n))
+				return false;
+			ST_TRY(hipMemcpyAsync(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res),
+					      hipMemcpyDeviceToHost, s_comp));
+			ST_TRY(hipStreamSynchronize(s_comp));
+			for (uint32_t i = 0; i < nr; i++) {
+				pc.push_back(rc[i]);
+				pr.push_back(rr[i]);
+				by_start.emplace(start_key(npool + i), npool + i);
+			}
+		}
+		if (!closed) {
+			S[1] = WHY_CHAIN;
+			return false;
+		}
+		for (uint32_t i : path) {
+			lda_stream_chunk c = pc[i];
+			if (c.kind == LDA_CHUNK_WARM) {
+				c.kind = LDA_CHUNK_EXACT;
+				c.start_bit = pr[i].start_bit;
+			}
+			acc.push_back(c);
+			accr.push_back(pr[i]);
 		}
 	}
+	lap(10);
 	const uint32_t na = (uint32_t)acc.size();
 	S[6] = na;
 	std::vector<uint64_t> offs(na + 1);
@@ -340,7 +434,15 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			std::min<size_t>(na, BATCH) * lda_stream_tokcap() * 4 + 64);
 		if (!d_sym || !d_out || !d_tok)
 			return false;
-		uint64_t *d_off = (uint64_t *)(sch + off_at);
+		/* (the accepted chain may hold more chunks than were planned) */
+		const size_t res2_at = align_up((size_t)na * sizeof(lda_stream_chunk) + 64, 64);
+		const size_t off2_at = res2_at + align_up((size_t)na * sizeof(lda_stream_res) + 64, 64);
+		sch = (uint8_t *)d->schunks.reserve(off2_at + ((size_t)na + 2) * 8 + 64);
+		if (!sch)
+			return false;
+		d_chunks = (lda_stream_chunk *)sch;
+		d_res = (lda_stream_res *)(sch + res2_at);
+		uint64_t *d_off = (uint64_t *)(sch + off2_at);
 		ST_TRY(hipMemcpyAsync(d_chunks, acc.data(), (size_t)na * sizeof(lda_stream_chunk),
 				      hipMemcpyHostToDevice, s_comp));
 		ST_TRY(hipMemcpyAsync(d_off, offs.data(), ((size_t)na + 1) * 8,
@@ -351,8 +453,33 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					   lda_stream_chunk_lds(), s_comp, nk, d_chunks + lo,
 					   d_res + lo, d_raw, raw_n, d_sym, d_tok);
 		}
-		hipLaunchKernelGGL(lda_stream_window_kernel, dim3(1), dim3(1024), 0, s_comp, na,
-				   d_off, d_sym, d_out, d_cnt + 2);
+		{
+			/* the window chain as a two-level scan over groups of chunks:
+			 * 2 x per_group + groups steps instead of one per chunk */
+			uint32_t per_group = 4;
+			while ((uint64_t)per_group * per_group * 4 < na)
+				per_group++;
+			const uint32_t groups = (na + per_group - 1) / per_group;
+			uint8_t *gw = (uint8_t *)d->swin.reserve((size_t)groups * 32768 * 3 + 64);
+			if (!gw)
+				return false;
+			uint16_t *d_gwin = (uint16_t *)gw;
+			uint8_t *d_fwin = gw + (size_t)groups * 65536;
+			if (!ctx->stream_attr_set.load(std::memory_order_acquire)) {
+				ST_TRY(hipFuncSetAttribute((const void *)lda_stream_window_kernel,
+							   hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+				ctx->stream_attr_set.store(true, std::memory_order_release);
+			}
+			if (groups > 1) {
+				hipLaunchKernelGGL(lda_stream_window_kernel, dim3(groups), dim3(1024), 65536,
+						   s_comp, na, per_group, 0u, d_off, d_sym, d_out, d_gwin,
+						   d_fwin, d_cnt + 2);
+				hipLaunchKernelGGL(lda_stream_window_link_kernel, dim3(1), dim3(1024), 0,
+						   s_comp, groups, d_gwin, d_fwin);
+			}
+			hipLaunchKernelGGL(lda_stream_window_kernel, dim3(groups), dim3(1024), 65536, s_comp,
+					   na, per_group, 2u, d_off, d_sym, d_out, d_gwin, d_fwin, d_cnt + 2);
+		}
 		{
 			uint64_t longest = 0;
 			for (uint32_t i = 0; i < na; i++)
@@ -381,6 +508,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		}
 	}
 
+	lap(11);
 	/* ---- footer: checksum of the output in pieces, combined on the host ---- */
 	const size_t consumed = (size_t)((end_bit + 7) / 8);
 	int32_t result = LIBDEFLATE_SUCCESS;
@@ -430,12 +558,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				result = LIBDEFLATE_BAD_DATA;
 		}
 	}
+	lap(12);
 	if (result == LIBDEFLATE_SUCCESS && total) {
 		void *outs[1] = { out };
 		const uint64_t nb[1] = { total }, off[1] = { 0 };
 		if (copy_out_packed(&d->pinned, d_out, 1, outs, nb, off, s_copy) != LIBDEFLATE_AMD_OK)
 			return false;
 	}
+	lap(13);
 	*res = result;
 	if (result == LIBDEFLATE_SUCCESS) {
 		*ain = hdr + consumed + ftr;

@@ -649,7 +649,7 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	u64 hdr = cd->hdr_bit, pos = hdr, out = chunk_abs;
 	u64 start_exact = cd->start_bit;
 	u32 final_blk = 0, status = LDA_STREAM_OK, bad = 0, at_boundary = 0;
-	bool in_block = false, first = true;
+	bool in_block = false, first = cd->kind == LDA_CHUNK_HEADER;	/* its own header is not a stop */
 	u64 ring_lo = out;
 
 	if (kind != LDA_CHUNK_HEADER) {
@@ -941,21 +941,49 @@ lda_stream_find_b_kernel(const u8 *__restrict__ inp, u64 in_n,
 /* ---------------- markers -> bytes ---------------- */
 
 /*
- * The window chain: chunk after chunk, the last min(length, 32 KiB) symbols
- * of chunk c are settled against the 32 KiB in front of it (held in LDS) and
- * written to the output; they are the window of chunk c + 1.  One workgroup;
- * the symbols of the next chunk are requested before this one's are settled.
+ * The window chain.  The last min(length, 32 KiB) symbols of chunk c - its
+ * TAIL - settled against the 32 KiB in front of the chunk are the window of
+ * chunk c + 1: a chain through all chunks, 32 Ki symbols per step.  It is cut
+ * into GROUPS of consecutive chunks and run as a two-level scan:
+ *
+ *   phase 0  every group but the last, side by side: the chain through the
+ *            group's chunks with a SYMBOLIC window - entry i of the window in
+ *            front of the group is the marker 0x8000 | i - leaves the window
+ *            behind the group in terms of the window in front of it;
+ *   phase 1  lda_stream_window_link_kernel, one workgroup, one step per
+ *            group: those symbolic windows turned into bytes, in order;
+ *   phase 2  every group side by side again, now from the real window in
+ *            front of it: the tails' bytes go to the output.
+ *
+ * The window is a ring in LDS indexed by the absolute output position (mod
+ * 32 Ki), 16 bits per entry; a step reads what its markers point at, then -
+ * behind a barrier - overwrites the ring with its own tail.
  */
 extern "C" __global__ void __launch_bounds__(1024)
-lda_stream_window_kernel(u32 nchunks, const u64 *__restrict__ out_off /*[nchunks + 1]*/,
+lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
+			 const u64 *__restrict__ out_off /*[nchunks + 1]*/,
 			 const u16 *__restrict__ sym, u8 *__restrict__ out,
+			 u16 *__restrict__ gwin /*[groups][32768]: phase 0 out */,
+			 const u8 *__restrict__ fwin /*[groups][32768]: phase 2 in */,
 			 u32 *__restrict__ err)
 {
-	__shared__ u8 W[2][32768];
-	const u32 tid = threadIdx.x;
-	u32 cur = 0, bad = 0;
+	lu16 *W = (lu16 *)(uintptr_t)0;		/* [32768], the launch's dynamic LDS */
+	const u32 tid = threadIdx.x, g = blockIdx.x;
+	const u32 c0 = g * per_group;
+	u32 c1 = c0 + per_group;
+	c1 = c1 < nchunks ? c1 : nchunks;
+	if (c0 >= nchunks || (phase == 0 && c1 >= nchunks))
+		return;		/* nobody needs the window behind the last group */
+	const u64 s0 = out_off[c0];
+	for (u32 i = tid; i < 32768; i += 1024) {
+		u32 v = 0x8000u | i;
+		if (phase != 0)
+			v = g ? fwin[(size_t)(g - 1) * 32768 + i] : 0;
+		W[((u32)s0 + i) & 32767] = (u16)v;
+	}
+	__syncthreads();
+	u32 bad = 0;
 	u16 nx[32];
-	/* tail of chunk c: symbols [t0, e) with e - t0 = min(len, 32768) */
 	auto load_tail = [&](u32 c) {
 		const u64 s = out_off[c], e = out_off[c + 1];
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
@@ -966,50 +994,79 @@ lda_stream_window_kernel(u32 nchunks, const u64 *__restrict__ out_off /*[nchunks
 			nx[k] = i < n ? sym[t0 + i] : 0;
 		}
 	};
-	load_tail(0);
-	for (u32 c = 0; c < nchunks; c++) {
+	load_tail(c0);
+	for (u32 c = c0; c < c1; c++) {
 		const u64 s = out_off[c], e = out_off[c + 1];
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
 		const u32 n = (u32)(e - t0);
-		/* window in front of the TAIL: for a long chunk the tail's markers
-		 * still refer to the window in front of the CHUNK; a marker w means
-		 * absolute position s - 32768 + w */
 		u16 v[32];
 #pragma unroll
 		for (u32 k = 0; k < 32; k++)
 			v[k] = nx[k];
-		if (c + 1 < nchunks)
+		if (c + 1 < c1)
 			load_tail(c + 1);
-		const u8 *Wc = W[cur];
-		u8 *Wn = W[cur ^ 1];
-		/* positions before the stream's first byte */
+		/* a marker w of this chunk is the position s - 32768 + w; the ones
+		 * below `lowest` lie before the stream's first byte */
 		const u32 lowest = s < 32768 ? 32768 - (u32)s : 0;
 #pragma unroll
 		for (u32 k = 0; k < 32; k++) {
 			const u32 i = tid + 1024 * k;
-			if (i < n) {
-				u32 b = v[k];
-				if (b & 0x8000) {
-					const u32 w = b & 0x7FFF;
-					if (w < lowest) {
-						bad = 1;
-						b = 0;
-					} else {
-						b = Wc[w];
-					}
+			if (i < n && (v[k] & 0x8000)) {
+				const u32 w = v[k] & 0x7FFF;
+				if (phase != 0 && w < lowest) {
+					bad = 1;
+					v[k] = 0;
+				} else {
+					v[k] = W[((u32)s + w) & 32767];
 				}
-				Wn[32768 - n + i] = (u8)b;
-				out[t0 + i] = (u8)b;
 			}
-			/* a short chunk keeps the end of the old window */
-			if (i < 32768 - n)
-				Wn[i] = Wc[i + n];
+		}
+		__syncthreads();
+#pragma unroll
+		for (u32 k = 0; k < 32; k++) {
+			const u32 i = tid + 1024 * k;
+			if (i < n) {
+				W[((u32)t0 + i) & 32767] = v[k];
+				if (phase != 0)
+					out[t0 + i] = (u8)v[k];
+			}
+		}
+		__syncthreads();
+	}
+	if (phase == 0) {
+		const u64 e1 = out_off[c1];
+		for (u32 i = tid; i < 32768; i += 1024)
+			gwin[(size_t)g * 32768 + i] = W[((u32)e1 + i) & 32767];
+	}
+	if (bad)
+		*err = 1;
+}
+
+/* phase 1: the symbolic window behind group g, settled against the bytes
+ * behind group g - 1 (nothing in front of group 0: a marker there points
+ * before the stream and is caught, with its position, in phase 2) */
+extern "C" __global__ void __launch_bounds__(1024)
+lda_stream_window_link_kernel(u32 groups, const u16 *__restrict__ gwin,
+			      u8 *__restrict__ fwin)
+{
+	__shared__ u8 F[2][32768];
+	const u32 tid = threadIdx.x;
+	u32 cur = 0;
+	for (u32 g = 0; g + 1 < groups; g++) {
+		const u16 *src = gwin + (size_t)g * 32768;
+		u8 *dst = fwin + (size_t)g * 32768;
+#pragma unroll 8
+		for (u32 k = 0; k < 32; k++) {
+			const u32 i = tid + 1024 * k;
+			u32 b = src[i];
+			if (b & 0x8000)
+				b = g ? F[cur][b & 0x7FFF] : 0;
+			F[cur ^ 1][i] = (u8)b;
+			dst[i] = (u8)b;
 		}
 		__syncthreads();
 		cur ^= 1;
 	}
-	if (bad)
-		*err = 1;
 }
 
 /* everything in front of a chunk's tail, 8 symbols per thread */

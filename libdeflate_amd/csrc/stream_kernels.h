@@ -58,8 +58,11 @@ lda_stream_find_b_kernel(const uint8_t *inp, uint64_t in_n, const uint64_t *queu
 			 const uint32_t *qcount, uint32_t qcap, uint64_t *cand,
 			 uint32_t *ncand, uint32_t ccap);
 extern "C" __global__ void
-lda_stream_window_kernel(uint32_t nchunks, const uint64_t *out_off, const uint16_t *sym,
-			 uint8_t *out, uint32_t *err);
+lda_stream_window_kernel(uint32_t nchunks, uint32_t per_group, uint32_t phase,
+			 const uint64_t *out_off, const uint16_t *sym, uint8_t *out,
+			 uint16_t *gwin, const uint8_t *fwin, uint32_t *err);
+extern "C" __global__ void
+lda_stream_window_link_kernel(uint32_t groups, const uint16_t *gwin, uint8_t *fwin);
 extern "C" __global__ void
 lda_stream_resolve_kernel(uint32_t nchunks, const uint64_t *out_off, const uint16_t *sym,
 			  uint8_t *out, uint32_t *err);

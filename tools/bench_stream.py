@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""bench_stream.py [MiB ...] - libdeflate_gzip_decompress on ONE reference-
+compressed stream per call (host pointers in and out), the shape of
+programs/gzip.c:187-303: GB/s host to host and the host-side phase times of the
+many-wave path (libdeflate_amd_stream_stats).  A tuning aid."""
+import os
+import sys
+import time
+from ctypes import byref, c_size_t, c_void_p
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from tests import datagen, oracle_util, streams  # noqa: E402
+
+
+def main():
+    from libdeflate_amd import api, binding
+    sizes = [float(a) for a in sys.argv[1:] if not a.startswith("-")] or [1, 4, 16, 64]
+    kind = "mix" if "--mix" in sys.argv else "text"
+    level = 6
+    ref = oracle_util.load_ref()
+    d = api.Decompressor()
+    lib = binding.load()
+    for mib in sizes:
+        n = int(mib * (1 << 20))
+        if kind == "text":
+            data = datagen.text_chunk(n, 0x0E110200)
+        else:
+            data = b"".join(datagen.chunk(i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
+        z = ref.compress("gzip", level, data) if ref else streams._zcompress("gzip", level, data)
+        zin = np.frombuffer(z, dtype=np.uint8)
+        out = np.zeros(n, dtype=np.uint8)
+        best, st = 1e9, None
+        for _ in range(6):
+            ao = c_size_t(0)
+            t0 = time.perf_counter()
+            r = lib.libdeflate_gzip_decompress(d._h, zin.ctypes.data_as(c_void_p), zin.size,
+                                               out.ctypes.data_as(c_void_p), n, byref(ao))
+            dt = time.perf_counter() - t0
+            assert r == 0 and ao.value == n
+            if dt < best:
+                best, st = dt, binding.stream_stats()
+        assert out.tobytes() == data
+        ph = {k: v for k, v in st.items() if k.startswith("us_")}
+        print(f"{mib:g} MiB {kind} L{level}: {best * 1e3:.2f} ms = {n / best / 1e9:.2f} GB/s "
+              f"parallel={st['parallel']} chunks={st['chunks_decoded']} repairs={st['repairs']} {ph}")
+
+
+if __name__ == "__main__":
+    main()
