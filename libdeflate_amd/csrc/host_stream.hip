@@ -144,9 +144,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 
 	/* ---- input to the device; the finder's queues behind it ---- */
 	const uint64_t nbits = raw_bits > 80 ? raw_bits - 80 : 0;	/* a header needs its bits */
-	const uint32_t qcap = (uint32_t)std::min<uint64_t>(nbits / 64 + 1024, 1u << 28);
+	/* about one offset in 500 passes the first filter on compressed data and a
+	 * real block is rarely under a few hundred bits; a queue that overflows
+	 * only loses entry points */
+	const uint32_t qcap = (uint32_t)std::min<uint64_t>(nbits / 128 + 4096, 1u << 28);
+	const uint32_t ccap = (uint32_t)std::min<uint64_t>(nbits / 512 + 4096, 1u << 26);
 	const size_t in_at = 64, q_at = align_up(in_at + in_nbytes + 64, 64);
-	const size_t c_at = q_at + (size_t)qcap * 8, cnt_at = c_at + (size_t)qcap * 8;
+	const size_t c_at = q_at + (size_t)qcap * 8, cnt_at = c_at + (size_t)ccap * 8;
 	uint8_t *sin = (uint8_t *)d->sin.reserve(cnt_at + 64);
 	if (!sin)
 		return false;
@@ -166,12 +170,12 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nbits + 255) / 256)),
 				   dim3(256), 0, s_comp, d_raw, raw_n, nbits, d_queue, d_cnt, qcap);
 		hipLaunchKernelGGL(lda_stream_find_b_kernel, dim3((qcap + 63) / 64), dim3(64), 16384,
-				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, qcap);
+				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
 		ST_TRY(hipGetLastError());
 		uint32_t cnt[2];
 		ST_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s_comp));
 		ST_TRY(hipStreamSynchronize(s_comp));
-		const uint32_t nc = std::min(cnt[1], qcap);
+		const uint32_t nc = std::min(cnt[1], ccap);
 		cands.resize(nc);
 		if (nc) {
 			ST_TRY(hipMemcpyAsync(cands.data(), d_cand, (size_t)nc * 8,
@@ -382,6 +386,20 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			ST_TRY(hipMemcpyAsync(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res),
 					      hipMemcpyDeviceToHost, s_comp));
 			ST_TRY(hipStreamSynchronize(s_comp));
+			if (getenv("LDA_STREAM_DEBUG")) {
+				const auto now = std::chrono::steady_clock::now();
+				uint64_t span = 0, si = 0;
+				for (uint32_t i = 0; i < nr; i++)
+					if (rr[i].end_bit - rc[i].start_bit > span) {
+						span = rr[i].end_bit - rc[i].start_bit;
+						si = i;
+					}
+				fprintf(stderr, "   round %d: %u repairs, %lld us since the last lap; longest %llu bits "
+					"(kind %u start %llu limit %llu status %u nout %llu)\n", round, nr,
+					(long long)std::chrono::duration_cast<std::chrono::microseconds>(now - t_last).count(),
+					(unsigned long long)span, rc[si].kind, (unsigned long long)rc[si].start_bit,
+					(unsigned long long)rc[si].limit_bit, rr[si].status, (unsigned long long)rr[si].nout);
+			}
 			for (uint32_t i = 0; i < nr; i++) {
 				pc.push_back(rc[i]);
 				pr.push_back(rr[i]);

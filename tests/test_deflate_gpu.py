@@ -560,6 +560,20 @@ def test_input_over_4gib(ref):
         back.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(ai), ctypes.byref(ao))
     assert (res, ai.value, ao.value) == (0, r, n)
     assert np.array_equal(back, data)
+    # and back through this library: a stream of more than 4 GiB is decoded by
+    # the many-wave path (the one-wave kernels index a stream with 32 bits)
+    from libdeflate_amd import binding
+    back[:] = 0
+    d = api.Decompressor()
+    ai, ao = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    res = d._lib.libdeflate_gzip_decompress_ex(
+        d._h, out.ctypes.data_as(ctypes.c_void_p), r,
+        back.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(ai), ctypes.byref(ao))
+    st = binding.stream_stats()
+    d.close()
+    assert (res, ai.value, ao.value) == (0, r, n), st
+    assert st["parallel"] == 1, st
+    assert np.array_equal(back, data)
 
 
 @pytest.mark.parametrize("level", [1, 6, 9, 12])
