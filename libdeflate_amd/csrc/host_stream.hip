@@ -167,8 +167,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
 	std::vector<uint64_t> cands;
 	if (nbits) {
-		hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nbits + 255) / 256)),
-				   dim3(256), 0, s_comp, d_raw, raw_n, nbits, d_queue, d_cnt, qcap);
+		for (uint64_t b0 = 0; b0 < nbits; b0 += 1ull << 31) {
+			const uint64_t nb = std::min<uint64_t>(nbits - b0, 1ull << 31);
+			hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nb + 255) / 256)),
+					   dim3(256), 0, s_comp, d_raw, raw_n, b0, nbits, d_queue, d_cnt, qcap);
+		}
 		hipLaunchKernelGGL(lda_stream_find_b_kernel, dim3((qcap + 63) / 64), dim3(64), 16384,
 				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
 		ST_TRY(hipGetLastError());

@@ -807,10 +807,12 @@ bits128(const u8 *inp, u64 in_n, u64 p, u64 *x0, u64 *x1)
  * misses).  About one offset in five hundred passes on compressed data.
  */
 extern "C" __global__ void __launch_bounds__(256)
-lda_stream_find_a_kernel(const u8 *__restrict__ inp, u64 in_n, u64 nbits,
+lda_stream_find_a_kernel(const u8 *__restrict__ inp, u64 in_n, u64 bit0, u64 nbits,
 			 u64 *__restrict__ queue, u32 *__restrict__ qcount, u32 qcap)
 {
-	const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+	/* (a launch covers at most 2^31 offsets from bit0 on: the threads of a
+	 * grid are counted in 32 bits) */
+	const u64 p = bit0 + (u64)blockIdx.x * 256 + threadIdx.x;
 	bool pass = false;
 	if (p < nbits) {
 		u64 x0, x1;

@@ -51,7 +51,7 @@ lda_stream_decode_kernel(uint32_t nchunks, const struct lda_stream_chunk *chunks
 			 struct lda_stream_res *res, const uint8_t *inp, uint64_t in_n,
 			 uint16_t *sym, uint32_t *tokscratch);
 extern "C" __global__ void
-lda_stream_find_a_kernel(const uint8_t *inp, uint64_t in_n, uint64_t nbits,
+lda_stream_find_a_kernel(const uint8_t *inp, uint64_t in_n, uint64_t bit0, uint64_t nbits,
 			 uint64_t *queue, uint32_t *qcount, uint32_t qcap);
 extern "C" __global__ void
 lda_stream_find_b_kernel(const uint8_t *inp, uint64_t in_n, const uint64_t *queue,

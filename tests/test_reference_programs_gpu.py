@@ -50,10 +50,12 @@ def test_reference_slow_decompression_program():
                        env=dict(os.environ, INCLUDE_PERF_TESTS="1"))
     out = r.stdout + r.stderr
     print(out[-600:])
-    assert "static huffman, libdeflate" in out, out[-2000:]
     if r.returncode != 0:
+        # (what the program printed before abort() sits in its stdout buffer;
+        # reaching a speed assertion means the 100 result checks before it held)
         failed = [ln for ln in out.splitlines() if "Assertion failed" in ln]
-        assert failed and all("t < tz" in ln or "t < 4 * tz" in ln for ln in failed), failed
+        assert failed and all("t < tz" in ln or "t < 4 * tz" in ln for ln in failed), \
+            (failed, out[-1000:])
 
 
 @pytest.mark.parametrize("args", [["-6"], ["-6", "-s", "65536"], ["-1", "-g"],
