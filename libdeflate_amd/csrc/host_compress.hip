@@ -11,6 +11,7 @@
 #include <string.h>
 #include <atomic>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "host_objects.h"
@@ -432,11 +433,58 @@ static size_t large_fail(const char *what)
 	return 0;
 }
 
+/* host memory <-> a device range through the object's pinned pair, cut into
+ * pieces of 1 MiB so that the packing threads share the memcpy */
+static int span_in(struct libdeflate_compressor *c, uint8_t *d_base, uint64_t d_off,
+		   const uint8_t *src, size_t n, hipStream_t st)
+{
+	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
+	std::vector<const void *> ins(np);
+	std::vector<size_t> nb(np);
+	std::vector<uint64_t> off(np);
+	for (size_t i = 0; i < np; i++) {
+		ins[i] = src + i * P;
+		nb[i] = i + 1 < np ? P : n - i * P;
+		off[i] = d_off + i * P;
+	}
+	return copy_in_packed(&c->pinned, d_base, np, ins.data(), nb.data(), off.data(), st);
+}
+
+static int span_out(struct libdeflate_compressor *c, const uint8_t *d_base, uint64_t d_off,
+		    uint8_t *dst, size_t n, hipStream_t st)
+{
+	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
+	std::vector<void *> outs(np);
+	std::vector<uint64_t> nb(np), off(np);
+	for (size_t i = 0; i < np; i++) {
+		outs[i] = dst + i * P;
+		nb[i] = i + 1 < np ? P : n - i * P;
+		off[i] = d_off + i * P;
+	}
+	return copy_out_packed(&c->pinned, d_base, np, outs.data(), nb.data(), off.data(), st);
+}
+
+/*
+ * The segments go through in SLICES of up to 32 MiB of input on the object's
+ * two streams, like the host-pointer batches: while the kernels of slice k
+ * (deflate of its segments, their checksums, the compaction of their streams)
+ * run on the compute stream, the host packs slice k + 1 into the pinned
+ * staging and sends it, and brings the compacted streams of slice k - 1 back.
+ * Nothing runs on the null stream and nothing waits for the whole device.
+ */
 static size_t compress_large(struct libdeflate_compressor *c, int format,
 			     const uint8_t *in, size_t n, uint8_t *out,
 			     size_t out_avail)
 {
-	const size_t S = LDA_SEG_BYTES;
+	/* sub-ranges of 64 KiB; an input that would not fill the CUs with those
+	 * is cut finer (more blocks and sync markers: ~1 % larger at 16 KiB) */
+	size_t S = LDA_SEG_BYTES;
+	if (env_cfg().seg_bytes)
+		S = env_cfg().seg_bytes;
+	else if (n <= ((size_t)4 << 20))
+		S = 16384;
+	else if (n <= ((size_t)8 << 20))
+		S = 32768;
 	const size_t tile = lda_deflate_tile();
 	/* usable window is 32 KiB minus two tiles (the kernel inserts one tile
 	 * ahead) and the lookahead; whole tiles */
@@ -450,89 +498,144 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 
 	if (out_avail <= hdr + ftr)
 		return 0;
-	/* device layout: [5 u64 arrays + u32 seg_info + u32 sums + compaction
-	 * offsets][input][slots][the slots' used parts back to back] */
-	const size_t ncmp = libdeflate_amd_compact_offsets_len(nseg);
-	size_t desc_bytes = align_up(nseg * (5 * 8 + 4 + 4) + 64 + ncmp * 8, 64);
-	size_t in_at = desc_bytes, out_at = align_up(in_at + n + 64, 64);
-	size_t pk_at = align_up(out_at + nseg * slot + 64, 64);
+	DeviceCtx *ctx = device_ctx();
+	if (!ctx || !c->streams.ensure())
+		return large_fail("streams");
+	hipStream_t s_copy = c->streams.copy, s_comp = c->streams.comp;
+	const size_t per_slice = std::max<size_t>(1, ((size_t)32 << 20) / S);
+	const size_t ns = (nseg + per_slice - 1) / per_slice;
+	/* device layout: [7 u64 rows: in_off in_n out_off out_av out_n piece_off
+	 * piece_n][seg_info u32][sums u32][compaction offsets of every slice]
+	 * [input][slots][the slots' used parts, slice after slice] */
+	std::vector<size_t> cmp_pos(ns + 1);
+	cmp_pos[0] = 0;
+	for (size_t k = 0; k < ns; k++)
+		cmp_pos[k + 1] = cmp_pos[k] + libdeflate_amd_compact_offsets_len(
+			std::min(per_slice, nseg - k * per_slice));
+	const size_t ncmp = cmp_pos[ns];
+	const size_t desc_bytes = align_up(nseg * (7 * 8 + 4 + 4) + 64, 64);
+	const size_t cmp_at = desc_bytes, in_at = align_up(cmp_at + ncmp * 8 + 64, 64);
+	const size_t out_at = align_up(in_at + n + 64, 64);
+	const size_t pk_at = align_up(out_at + nseg * slot + 64, 64);
 	uint8_t *st = (uint8_t *)c->stage.reserve(pk_at + nseg * slot + 64);
 	if (!st) {
 		complain("libdeflate_*_compress (device memory)", LIBDEFLATE_AMD_OOM);
 		return 0;
 	}
-	std::vector<uint64_t> d64(5 * nseg);
-	std::vector<uint32_t> d32(2 * nseg);
+	{	/* the kernels' scratch for the largest launch, before any is queued */
+		const size_t g = std::min<size_t>(std::min(per_slice, nseg), (size_t)ctx->num_cus);
+		if (!c->scratch.reserve(g * lda_deflate_seq_words() * 8 + 16 + std::min(per_slice, nseg) * 4)) {
+			complain("libdeflate_*_compress (device memory)", LIBDEFLATE_AMD_OOM);
+			return 0;
+		}
+	}
+	std::vector<uint64_t> d64(7 * nseg);
+	std::vector<uint32_t> d32(nseg);
 	uint64_t *in_off = &d64[0], *in_n = &d64[nseg], *out_off = &d64[2 * nseg],
-		 *out_av = &d64[3 * nseg];
+		 *out_av = &d64[3 * nseg], *pc_off = &d64[5 * nseg], *pc_n = &d64[6 * nseg];
 	for (size_t i = 0; i < nseg; i++) {
-		size_t dict = i ? D : 0, len = i + 1 < nseg ? S : n - i * S;
+		const size_t dict = i ? std::min(D, i * S) / tile * tile : 0;
+		const size_t len = i + 1 < nseg ? S : n - i * S;
 		in_off[i] = in_at + i * S - dict;
 		in_n[i] = dict + len;
 		out_off[i] = out_at + i * slot;
 		out_av[i] = slot;
+		pc_off[i] = in_at + i * S;
+		pc_n[i] = len;
 		d32[i] = (uint32_t)dict | (i + 1 == nseg ? 0x80000000u : 0);
 	}
 	uint64_t *d_desc = (uint64_t *)st;
-	uint32_t *d_seg = (uint32_t *)(st + 5 * 8 * nseg);
+	uint32_t *d_seg = (uint32_t *)(st + 7 * 8 * nseg);
 	uint32_t *d_sums = d_seg + nseg;
-	uint64_t *d_cmp = (uint64_t *)(st + align_up(nseg * (5 * 8 + 4 + 4), 64));
-	if (hipMemcpy(d_desc, d64.data(), 4 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
-	    hipMemcpy(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice) != hipSuccess ||
-	    hipMemcpy(st + in_at, in, n, hipMemcpyHostToDevice) != hipSuccess)
+	uint64_t *d_cmp = (uint64_t *)(st + cmp_at);
+	/* what comes back per slice, in pinned memory: sizes, sums, the total */
+	uint64_t *h_back = (uint64_t *)c->meta.ensure(nseg * 12 + ns * 8 + 64);
+	if (!h_back)
+		return large_fail("pinned memory");
+	uint64_t *h_out_n = h_back, *h_tot = h_back + nseg;
+	uint32_t *h_sums = (uint32_t *)(h_back + nseg + ns);
+	if (hipMemcpyAsync(d_desc, d64.data(), 7 * 8 * nseg, hipMemcpyHostToDevice, s_copy) != hipSuccess ||
+	    hipMemcpyAsync(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice, s_copy) != hipSuccess)
 		return large_fail("copy in");
-	int rc = compress_batch_impl(c, LIBDEFLATE_AMD_DEFLATE, nseg, st, d_desc,
-				     d_desc + nseg, st, d_desc + 2 * nseg,
-				     d_desc + 3 * nseg, d_desc + 4 * nseg, NULL, d_seg);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return large_fail("kernel launch");
-	if (ftr) {
-		/* per-piece checksums of the pieces themselves (no dictionary) */
-		std::vector<uint64_t> po(2 * nseg);
-		for (size_t i = 0; i < nseg; i++) {
-			po[i] = in_at + i * S;
-			po[nseg + i] = i + 1 < nseg ? S : n - i * S;
+	std::vector<hipEvent_t> ev_done(ns, nullptr);
+	size_t total = hdr;	/* bytes of the output so far */
+	bool fits = true, failed = false;
+	auto cleanup = [&]() {
+		(void)hipStreamSynchronize(s_comp);
+		(void)hipStreamSynchronize(s_copy);
+		for (size_t k = 0; k < ns; k++)
+			if (ev_done[k])
+				(void)hipEventDestroy(ev_done[k]);
+	};
+	auto drain = [&](size_t k) -> bool {
+		const size_t lo = k * per_slice, nk = std::min(per_slice, nseg - lo);
+		if (hipEventSynchronize(ev_done[k]) != hipSuccess)
+			return false;
+		for (size_t i = lo; i < lo + nk; i++)
+			if (h_out_n[i] == 0)
+				fits = false;	/* a segment did not fit its slot: cannot happen within the bound */
+		const size_t tk = (size_t)h_tot[k];
+		if (!fits || total + tk + ftr > out_avail) {
+			fits = false;
+			return true;
 		}
-		/* reuse the in_off / in_n rows after the kernel has consumed them */
-		if (hipDeviceSynchronize() != hipSuccess ||
-		    hipMemcpy(d_desc, po.data(), 2 * 8 * nseg, hipMemcpyHostToDevice) != hipSuccess)
-			return large_fail("checksum setup");
-		rc = format == LIBDEFLATE_AMD_GZIP ?
-			libdeflate_amd_crc32_batch(nseg, st, d_desc, d_desc + nseg,
-						   NULL, d_sums, NULL) :
-			libdeflate_amd_adler32_batch(nseg, st, d_desc, d_desc + nseg,
-						     NULL, d_sums, NULL);
-		if (rc != LIBDEFLATE_AMD_OK)
-			return large_fail("checksum");
+		if (tk && span_out(c, st, pk_at + lo * slot, out + total, tk, s_copy) != LIBDEFLATE_AMD_OK)
+			return false;
+		total += tk;
+		return true;
+	};
+	for (size_t k = 0; k < ns && fits && !failed; k++) {
+		const size_t lo = k * per_slice, nk = std::min(per_slice, nseg - lo);
+		const size_t a = lo * S, b = std::min(n, (lo + nk) * S);
+		/* (returns when the slice - and, the first time, the descriptors -
+		 * are on the device) */
+		if (span_in(c, st, in_at + a, in + a, b - a, s_copy) != LIBDEFLATE_AMD_OK) {
+			failed = true;
+			break;
+		}
+		int rc = compress_batch_impl(c, LIBDEFLATE_AMD_DEFLATE, nk, st, d_desc + lo,
+					     d_desc + nseg + lo, st, d_desc + 2 * nseg + lo,
+					     d_desc + 3 * nseg + lo, d_desc + 4 * nseg + lo, s_comp,
+					     d_seg + lo);
+		if (rc == LIBDEFLATE_AMD_OK && ftr)
+			rc = format == LIBDEFLATE_AMD_GZIP ?
+				libdeflate_amd_crc32_batch(nk, st, d_desc + 5 * nseg + lo,
+							   d_desc + 6 * nseg + lo, NULL, d_sums + lo, s_comp) :
+				libdeflate_amd_adler32_batch(nk, st, d_desc + 5 * nseg + lo,
+							     d_desc + 6 * nseg + lo, NULL, d_sums + lo, s_comp);
+		if (rc == LIBDEFLATE_AMD_OK)
+			rc = libdeflate_amd_compact_batch(nk, st, d_desc + 2 * nseg + lo,
+							  d_desc + 4 * nseg + lo, st + pk_at + lo * slot,
+							  d_cmp + cmp_pos[k], s_comp);
+		if (rc != LIBDEFLATE_AMD_OK ||
+		    hipMemcpyAsync(h_out_n + lo, d_desc + 4 * nseg + lo, nk * 8, hipMemcpyDeviceToHost,
+				   s_comp) != hipSuccess ||
+		    hipMemcpyAsync(h_tot + k, d_cmp + cmp_pos[k] + nk, 8, hipMemcpyDeviceToHost,
+				   s_comp) != hipSuccess ||
+		    (ftr && hipMemcpyAsync(h_sums + lo, d_sums + lo, nk * 4, hipMemcpyDeviceToHost,
+					   s_comp) != hipSuccess) ||
+		    hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming) != hipSuccess ||
+		    hipEventRecord(ev_done[k], s_comp) != hipSuccess) {
+			failed = true;
+			break;
+		}
+		if (k && !drain(k - 1))
+			failed = true;
 	}
-	/* the segments' streams back to back on the device (prefix sum + one
-	 * gather copy), then ONE transfer to the caller's buffer - not a
-	 * blocking copy per segment */
-	rc = libdeflate_amd_compact_batch(nseg, st, d_desc + 2 * nseg, d_desc + 4 * nseg,
-					  st + pk_at, d_cmp, NULL);
-	if (rc != LIBDEFLATE_AMD_OK)
-		return large_fail("compaction");
-	if (hipMemcpy(&d64[4 * nseg], d_desc + 4 * nseg, 8 * nseg, hipMemcpyDeviceToHost) != hipSuccess ||
-	    (ftr && hipMemcpy(&d32[nseg], d_sums, 4 * nseg, hipMemcpyDeviceToHost) != hipSuccess))
-		return large_fail("copy out");
-	size_t total = hdr + ftr;
-	for (size_t i = 0; i < nseg; i++) {
-		if (d64[4 * nseg + i] == 0)
-			return 0;
-		total += d64[4 * nseg + i];
-	}
-	if (total > out_avail)
+	if (!failed && fits && !drain(ns - 1))
+		failed = true;
+	cleanup();
+	if (failed)
+		return large_fail("segmented compress");
+	if (!fits || total + ftr > out_avail)
 		return 0;
-	const size_t at = total - ftr;
-	if (hipMemcpy(out + hdr, st + pk_at, at - hdr, hipMemcpyDeviceToHost) != hipSuccess)
-		return large_fail("copy out");
+	const size_t at = total;
+	total += ftr;
 	if (format == LIBDEFLATE_AMD_GZIP) {
 		/* lib/gzip_compress.c:44-79 */
 		uint32_t crc = 0;
-		for (size_t i = 0; i < nseg; i++) {
-			size_t len = i + 1 < nseg ? S : n - i * S;
-			crc = i ? crc32_concat(crc, d32[nseg + i], len) : d32[nseg];
-		}
+		for (size_t i = 0; i < nseg; i++)
+			crc = i ? crc32_concat(crc, h_sums[i], pc_n[i]) : h_sums[0];
 		const uint8_t xfl = c->level < 2 ? 4 : c->level >= 8 ? 2 : 0;
 		const uint8_t h[10] = { 0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 0xFF };
 		memcpy(out, h, 10);
@@ -544,10 +647,8 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	} else if (format == LIBDEFLATE_AMD_ZLIB) {
 		/* lib/zlib_compress.c:45-72 */
 		uint32_t ad = 1;
-		for (size_t i = 0; i < nseg; i++) {
-			size_t len = i + 1 < nseg ? S : n - i * S;
-			ad = i ? adler32_concat(ad, d32[nseg + i], len) : d32[nseg];
-		}
+		for (size_t i = 0; i < nseg; i++)
+			ad = i ? adler32_concat(ad, h_sums[i], pc_n[i]) : h_sums[0];
 		uint32_t fl = c->level < 2 ? 0 : c->level < 6 ? 1 : c->level < 8 ? 2 : 3;
 		uint32_t hw = (0x78u << 8) | (fl << 6);
 		hw |= 31 - (hw % 31);

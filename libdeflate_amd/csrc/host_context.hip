@@ -58,6 +58,11 @@ static EnvCfg read_env()
 		if (v >= 1 && v <= 16)
 			c.inflate_waves_per_cu = v;
 	}
+	if (const char *e = getenv("LDA_SEG_BYTES")) {
+		size_t v = (size_t)strtoull(e, nullptr, 0);
+		if (v >= 8192 && v <= 65536 && v % 4096 == 0)
+			c.seg_bytes = v;
+	}
 	c.no_stream_par = getenv("LDA_NO_STREAM_PAR") != nullptr;
 	if (const char *e = getenv("LDA_STREAM_PAR_MIN"))
 		c.stream_par_min = (size_t)strtoull(e, nullptr, 0);

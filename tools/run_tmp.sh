@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python -m pytest tests/test_deflate_gpu.py -q -k "over_4gib" 2>&1 | tail -5 > gpurun_out/r04_t3.log
-python -m pytest tests -m gpu -q --deselect tests/test_deflate_gpu.py::test_input_over_4gib --deselect tests/test_stream_gpu.py 2>&1 | tail -8 >> gpurun_out/r04_t3.log
-LIBDEFLATE_AMD_LIB=$R/libdeflate_amd/libdeflate_amd_prof.so python tools/microbench.py deflate --chunks 4096 --level 6 > gpurun_out/r04_prof6.log 2>&1
-cat gpurun_out/r04_t3.log; cat gpurun_out/r04_prof6.log
+for a in "1 32" "4 16" "16 8" "64 6" "256 4" "1024 3"; do python tools/bench_single_api.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log; done
+LDA_HOST_THREADS=8 python tools/bench_single_api.py 256 4 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log
+LDA_HOST_THREADS=1 python tools/bench_single_api.py 256 4 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log
+cat gpurun_out/r04_cl2.log
