@@ -147,43 +147,115 @@ def cpu_info():
     return model, cores
 
 
-def cpu_baseline(chunks, fmt, level):
+def _gen_range(args):
+    lo, hi, size, seed, mix4k = args
+    from tests import datagen
+    mix = datagen.MIX4K if mix4k else datagen.MIX64K
+    return b"".join(datagen.chunk(i, size, seed, mix) for i in range(lo, hi))
+
+
+def gen_chunks(count, size, seed, mix4k=False):
+    """`count` DISTINCT chunks (chunk i: kind i mod 8, seed + i; SURVEY.md
+    8(d)), generated by the host's cores side by side and kept in /tmp for
+    the next run."""
+    import concurrent.futures as cf
+    path = f"/tmp/lda_bench_{seed:x}_{count}_{size}_{int(mix4k)}.bin"
+    blob = None
+    if os.path.exists(path) and os.path.getsize(path) == count * size:
+        blob = open(path, "rb").read()
+    else:
+        nw = max(1, min(usable_cores(), 32))
+        per = max(1, (count + 4 * nw - 1) // (4 * nw))
+        jobs = [(lo, min(lo + per, count), size, seed, mix4k) for lo in range(0, count, per)]
+        try:
+            with cf.ProcessPoolExecutor(nw) as ex:
+                blob = b"".join(ex.map(_gen_range, jobs))
+        except (OSError, RuntimeError):
+            blob = b"".join(_gen_range(j) for j in jobs)
+        try:
+            with open(path + ".tmp", "wb") as f:
+                f.write(blob)
+            os.replace(path + ".tmp", path)
+        except OSError:
+            pass
+    return [blob[i * size:(i + 1) * size] for i in range(count)]
+
+
+def ref_verify(torch, ref, fmt, chunks, comp, c_off, c_n, first, distinct):
+    """Every DISTINCT compressed stream of a batch decoded by the real
+    reference (oracle/_ref), outside the timed region: chunk i of the batch is
+    chunks[(first + i) % len(chunks)], so the first `distinct` streams cover
+    them all.  Returns how many were checked."""
+    import ctypes
+    import numpy as np
+    k = min(distinct, c_n.numel())
+    sizes = c_n[:k].cpu().numpy()
+    offs = c_off[:k].cpu().numpy()
+    hi = int(offs[k - 1] + sizes[k - 1])
+    host = comp[:hi].cpu().numpy()
+    size = len(chunks[0])
+    out = ctypes.create_string_buffer(size)
+    ai, ao = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    fn = getattr(ref.lib, f"libdeflate_{fmt}_decompress_ex")
+    for i in range(k):
+        z = host[int(offs[i]):int(offs[i]) + int(sizes[i])]
+        r = fn(ref._d, z.ctypes.data_as(ctypes.c_char_p), int(sizes[i]), out, size,
+               ctypes.byref(ai), ctypes.byref(ao))
+        assert r == 0 and ai.value == int(sizes[i]) and ao.value == size, \
+            ("the reference rejects stream", i, r)
+        assert out.raw == chunks[(first + i) % len(chunks)], ("reference decodes other bytes", i)
+    return k
+
+
+def cpu_baseline(chunks, fmt, level, mode="rt", only_t1=False):
     """Reference libdeflate (oracle/_ref) on this box's host cores through
     oracle/cpu_bench.c (pthreads, one compressor + decompressor per thread,
     clock_gettime, best of 3 after a warm-up): T = all cores, >= 0.5 s of
-    work per thread and pass, and T = 1."""
+    work per thread and pass, and T = 1.  mode: rt (compress + decompress,
+    `value` = round trip), c, d (decompress only: `value` = decompress)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cpu_bench")
     if not os.path.exists(exe):
         return None
     model, cores = cpu_info()
     size = len(chunks[0])
+    chunks = chunks[:max(1, min(len(chunks), (32 << 20) // size))]   # the sample's distinct chunks
     out = {}
     with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
         # >= 0.5 s of work per thread and pass (the reference does ~125 MB/s
         # per core of an EPYC 9575F at level 6, round trip ~110 MB/s)
         per_thread = max(8, int(72e6 // size)) if level >= 5 else max(16, int(160e6 // size))
+        if size > (1 << 20):
+            per_thread = max(2, int(72e6 // size))
         count_all = per_thread * cores      # chunk i = file chunk i mod len(chunks)
         for c in chunks:
             f.write(c)
         f.flush()
-        for key, t, cnt in (("all", cores, count_all), ("t1", 1, min(count_all, per_thread * 2))):
+        runs = [("all", cores, count_all), ("t1", 1, min(count_all, per_thread * 2))]
+        if only_t1:
+            runs = [("all", 1, per_thread)]
+        for key, t, cnt in runs:
             r = subprocess.run([exe, f.name, str(size), str(cnt), fmt, str(level),
-                                str(t), "3"], capture_output=True, text=True,
+                                str(t), "3", mode], capture_output=True, text=True,
                                timeout=300)
             if r.returncode != 0:
                 return {"error": (r.stderr or r.stdout)[-200:]}
             out[key] = json.loads(r.stdout)
-    a, t1 = out["all"], out["t1"]
-    return {"value": a["MBps"], "unit": "MB/s", "cores": a["threads"],
+    a, t1 = out["all"], out.get("t1", out["all"])
+    key = {"rt": "MBps", "c": "compress_MBps", "d": "decompress_MBps"}[mode]
+    what = {"rt": "compress+decompress round trip", "c": "compress only",
+            "d": "decompress only (streams compressed by the reference itself)"}[mode]
+    return {"value": a[key], "unit": "MB/s", "cores": a["threads"],
             "kind": "reference",
-            "sample": f"{a['chunks']} of the same {size}-byte chunks ({fmt} level "
-                      f"{level} compress+decompress round trip, statically "
+            "sample": f"{a['chunks']} chunks drawn from {len(chunks)} distinct {size}-byte "
+                      f"chunks of the same batch ({fmt} level {level} {what}, statically "
                       f"partitioned over {a['threads']} threads, best of 3 passes "
                       f"after a warm-up, {a['wall_s']:.2f} s per pass)",
-            "compress_MBps": a["compress_MBps"],
-            "decompress_MBps": a["decompress_MBps"],
-            "t1": {"value": t1["MBps"], "compress_MBps": t1["compress_MBps"],
-                   "decompress_MBps": t1["decompress_MBps"], "chunks": t1["chunks"]},
+            "compress_MBps": a["compress_MBps"] if mode != "d" else None,
+            "decompress_MBps": a["decompress_MBps"] if mode != "c" else None,
+            "t1": {"value": t1[key],
+                   "compress_MBps": t1["compress_MBps"] if mode != "d" else None,
+                   "decompress_MBps": t1["decompress_MBps"] if mode != "c" else None,
+                   "chunks": t1["chunks"]},
             "cpu_model": model, "host_cores": cores,
             "host_cpus_online": os.cpu_count(),
             "harness": "oracle/cpu_bench.c (pthreads, clock_gettime)"}
@@ -289,10 +361,13 @@ def roundtrip_config(torch, dist, world, rank, dev, stream, api, shard, chunks,
     assert bool((res == 0).all()), "a chunk failed to decompress"
     assert torch.equal(out, data), "round trip is not byte-exact"
     assert bool((c_n > 0).all()) and bool((c_n <= comp_c.bound(fmt, size)).all())
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    nref = ref_verify(torch, ref, fmt, chunks, comp, c_off, c_n, first, len(chunks)) if ref else 0
     U = count * size
     C = int(c_n.sum().item())
     r = {"elapsed": elapsed, "t_comp": tm.span(0, 1), "t_dec": tm.span(1, 2),
-         "U": U, "C": C, "verdict": verdict,
+         "U": U, "C": C, "verdict": verdict, "nref": nref,
          "tensors": (data, in_off, in_n, comp, c_off, c_av, c_n, out, res, comp_c, dec)}
     return r
 
@@ -413,7 +488,7 @@ def end_to_end(torch, dev, stream, api, tensors, slices=8):
 
 
 def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
-                    shard, chunks, total, fmt, level, steps, scaling):
+                    shard, chunks, total, fmt, level, steps, scaling, cpu=True):
     """A non-headline BASELINE config: compress + decompress of `total`
     chunks (strong: partitioned over the ranks; weak: `total` per rank)."""
     if scaling == "strong":
@@ -427,7 +502,8 @@ def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
     ms = r["elapsed"] / steps * 1e3
     del r["tensors"]
     torch.cuda.empty_cache()
-    return {"workload": workload, "scaling": scaling, "n_gpus": world,
+    return {"cpu_baseline": cpu_baseline(chunks, fmt, level) if cpu and rank == 0 else None,
+            "workload": workload, "scaling": scaling, "n_gpus": world,
             "chunks_total": int(round(U / len(chunks[0]))),
             "verdicts": {"chunks": int(r["verdict"][0]), "failed": int(r["verdict"][1])},
             "steps": steps, "ms_per_step": round(ms, 3),
@@ -436,7 +512,10 @@ def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
             "decompress_MBps": round(U / td / 1e6, 1),
             "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3),
             "compressed_ratio": round(C / U, 4),
-            "verified": "round trip byte-exact on every rank",
+            "verified": "round trip byte-exact on every rank; " +
+                        (f"every distinct compressed stream ({r['nref']} per rank) decoded by "
+                         "the real reference (oracle/_ref) to the original bytes"
+                         if r["nref"] else "oracle/_ref not on this box"),
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "compress": {"achieved": round((U + C) / world / tc / 1e9, 2),
                                       "frac": round((U + C) / world / tc / 1e9 / HBM_PEAK_GBS, 5)},
@@ -444,7 +523,7 @@ def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
                                         "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5)}}}
 
 
-def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, steps):
+def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, steps, cpu=True):
     """BASELINE configs[3]: `total` gzip streams pre-compressed by the
     reference (oracle/_ref) at level 6 OUTSIDE the timed region, contiguous
     shard per rank, decompress-only in exact-fill mode
@@ -454,8 +533,8 @@ def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, step
     ref = oracle_util.load_ref()
     if ref is None:
         return {"skipped": "oracle/_ref/libdeflate_ref.so not built"}
-    distinct = 256
-    chunks = datagen.batch(distinct, CHUNK, 0x0E110004, distinct=distinct)
+    distinct = min(4096, total)
+    chunks = gen_chunks(distinct, CHUNK, 0x0E110004)
     streams = [ref.compress("gzip", 6, c) for c in chunks]
     lo, hi = shard.partition(total, world, rank)
     n = hi - lo
@@ -499,9 +578,10 @@ def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, step
     U, C, td = all_sum(torch, dist, dev, n * CHUNK, int(in_n.sum().item()), tm.span(0, 1))
     td /= world
     ms = elapsed / steps * 1e3
-    r = {"workload": f"configs[3]: decompress-only, {total} gzip streams of 64 KiB "
-                     "chunks compressed by the reference at level 6, contiguous "
-                     "shard per rank",
+    r = {"cpu_baseline": cpu_baseline(chunks, "gzip", 6, "d") if cpu and rank == 0 else None,
+         "workload": f"configs[3]: decompress-only, {total} gzip streams of 64 KiB "
+                     f"chunks ({distinct} distinct) compressed by the reference at level 6, "
+                     "contiguous shard per rank",
          "scaling": "strong", "n_gpus": world, "steps": steps,
          "streams_total": int(round(U / CHUNK)),
          "verdicts": {"chunks": int(verdict[0]), "failed": int(verdict[1])},
@@ -517,6 +597,75 @@ def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, step
     del d_in, d_blob, out, want
     torch.cuda.empty_cache()
     return r
+
+
+def single_stream(mib=16, cpu=True):
+    """ONE large buffer through the reference's own
+    single-buffer calls (host pointers in and out, the shape of
+    programs/gzip.c:149-303): libdeflate_gzip_decompress on a stream the
+    REFERENCE compressed at level 6, libdeflate_gzip_compress on the same
+    text; best of 5 calls after a warm-up, buffers reused like
+    programs/benchmark.c does.  Beside it the reference itself on one host
+    core (one call is one thread there).  Host to host: PCIe and the staging
+    copies are inside the timed calls."""
+    import ctypes
+    import numpy as np
+    from libdeflate_amd import api, binding
+    from tests import datagen, oracle_util
+    ref = oracle_util.load_ref()
+    if ref is None:
+        return {"skipped": "oracle/_ref/libdeflate_ref.so not built"}
+    n = mib << 20
+    data = datagen.text_chunk(n, 0x0E110006)
+    zref = np.frombuffer(ref.compress("gzip", LEVEL, data), dtype=np.uint8)
+    src = np.frombuffer(data, dtype=np.uint8)
+    back = np.zeros(n, dtype=np.uint8)
+    c, d = api.Compressor(LEVEL), api.Decompressor()
+    lib = binding.load()
+    bound = c.bound("gzip", n)
+    zout = np.zeros(bound, dtype=np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ao = ctypes.c_size_t(0)
+    t_d = t_c = 1e9
+    zn = 0
+    for it in range(6):
+        t0 = time.perf_counter()
+        r = lib.libdeflate_gzip_decompress(d._h, P(zref), zref.size, P(back), n, ctypes.byref(ao))
+        t1 = time.perf_counter()
+        zn = lib.libdeflate_gzip_compress(c._h, P(src), n, P(zout), bound)
+        t2 = time.perf_counter()
+        assert r == 0 and ao.value == n and zn
+        if it:
+            t_d, t_c = min(t_d, t1 - t0), min(t_c, t2 - t1)
+    st = None
+    lib.libdeflate_gzip_decompress(d._h, P(zref), zref.size, P(back), n, ctypes.byref(ao))
+    st = binding.stream_stats()
+    assert back.tobytes() == data, "single-stream decompress differs"
+    rr = ref.decompress_ex("gzip", zout[:zn].tobytes(), n)
+    assert rr[0] == 0 and rr[3] == data, "the reference rejects the segmented stream"
+    cpu = cpu_baseline([data], "gzip", LEVEL, only_t1=True) if cpu else None
+    out = {"workload": f"one {mib} MiB enwik-style buffer, gzip level {LEVEL}: "
+                       "libdeflate_gzip_decompress of the reference's stream and "
+                       "libdeflate_gzip_compress, host pointers in and out, one call each",
+           "decompress_MBps": round(n / t_d / 1e6, 1), "decompress_ms": round(t_d * 1e3, 3),
+           "compress_MBps": round(n / t_c / 1e6, 1), "compress_ms": round(t_c * 1e3, 3),
+           "compressed_ratio": round(zn / n, 4),
+           "reference_ratio": round(zref.size / n, 4),
+           "decompress_path": {k: st[k] for k in ("parallel", "blocks_found", "chunks_decoded",
+                                                    "repairs", "us_in", "us_find", "us_count",
+                                                    "us_decode", "us_sum", "us_out")},
+           "verified": "decompressed bytes equal the original; the compressed stream "
+                       "decoded by the real reference to the original",
+           "cpu_baseline": None}
+    if cpu and "t1" in cpu:
+        out["cpu_baseline"] = {
+            "kind": "reference", "cores": 1, "unit": "MB/s",
+            "decompress_MBps": cpu["t1"]["decompress_MBps"],
+            "compress_MBps": cpu["t1"]["compress_MBps"],
+            "sample": f"the same {mib} MiB buffer, one thread (a single-buffer call of the "
+                      "reference runs on one core), oracle/cpu_bench.c, best of 3",
+            "cpu_model": cpu["cpu_model"]}
+    return out
 
 
 def main():
@@ -568,8 +717,8 @@ def main():
     stream = torch.cuda.current_stream()
     n = a.chunks
     # 64 KiB chunk mix (5 text, binary, low-entropy,
-    # random per 8); 256 distinct chunks per rank are generated and tiled
-    chunks = datagen.batch(256, CHUNK, 0x0E110003 + rank * 100003, distinct=256)
+    # random per 8), every chunk of a rank's batch with its own seed
+    chunks = gen_chunks(n, CHUNK, 0x0E110003 + rank * 100003)
 
     head = roundtrip_config(torch, dist, world, rank, dev, stream, api, shard,
                             chunks, n, 0, FMT, LEVEL, a.steps, a.warmup)
@@ -587,17 +736,19 @@ def main():
             "l1", "configs[1]: 4096 x 64 KiB raw DEFLATE buffers, level 1, "
             "compress then decompress, per GPU", torch, dist, world, rank, dev,
             stream, api, shard,
-            datagen.batch(256, CHUNK, 0x0E110002 + rank * 100003, distinct=256),
-            a.chunks, "deflate", 1, 3, "weak")
+            gen_chunks(a.chunks, CHUNK, 0x0E110002 + rank * 100003),
+            a.chunks, "deflate", 1, 3, "weak", cpu=not a.no_cpu)
         extras["configs[3]"] = extra_inflate(torch, dist, world, rank, dev, stream,
-                                             api, shard, a.streams, 3)
+                                             api, shard, a.streams, 3, cpu=not a.no_cpu)
         extras["configs[4]"] = extra_roundtrip(
             "zlib4k", f"configs[4]: {a.blocks} x 4 KiB zlib buffers "
             "(filesystem-block mix), level 9, compress then decompress, "
             "partitioned over the GPUs", torch, dist, world, rank, dev, stream,
             api, shard,
-            datagen.batch(2048, 4096, 0x0E110005, mix=datagen.MIX4K, distinct=2048),
-            a.blocks, "zlib", 9, 2, "strong")
+            gen_chunks(min(a.blocks, 16384), 4096, 0x0E110005, mix4k=True),
+            a.blocks, "zlib", 9, 2, "strong", cpu=not a.no_cpu)
+        if rank == 0:
+            extras["single_stream"] = single_stream(cpu=not a.no_cpu)
 
     if rank == 0:
         total_chunks, n_fail = head["verdict"]
@@ -611,7 +762,8 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (seeded 64 KiB chunk mix: 5 text, 1 binary, "
-                    "1 low-entropy, 1 random per 8; 256 distinct chunks tiled)",
+                    f"1 low-entropy, 1 random per 8; {n} distinct chunks per GPU, "
+                    "chunk i seeded base + i)",
             "config": {"workload": "configs[2]: 4096 x 64 KiB gzip buffers, "
                        "level 6 + CRC-32, compress then decompress, per GPU",
                        "chunks_per_gpu": n, "chunk_bytes": CHUNK,
@@ -622,6 +774,10 @@ def main():
             "decompress_MBps": round(U * world / t_dec / 1e6, 1),
             "compressed_ratio": round(C / U, 4),
             "verdicts": {"chunks": int(total_chunks), "failed": int(n_fail)},
+            "verified": "round trip byte-exact on every rank (torch.equal over the batch); " +
+                        (f"all {head['nref']} compressed streams of rank 0 decoded by the real "
+                         "reference (oracle/_ref) to the original bytes, outside the timed region"
+                         if head["nref"] else "oracle/_ref not on this box"),
             "roofline": {
                 "bound": "hbm", "kernel": "lda_deflate_batch_kernel",
                 "achieved": round((U + C) / t_comp / 1e9, 2),

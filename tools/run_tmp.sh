@@ -1,7 +1,17 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-for a in "1 32" "4 16" "16 8" "64 6" "256 4" "1024 3"; do python tools/bench_single_api.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log; done
-LDA_HOST_THREADS=8 python tools/bench_single_api.py 256 4 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log
-LDA_HOST_THREADS=1 python tools/bench_single_api.py 256 4 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_cl2.log
-cat gpurun_out/r04_cl2.log
+( time python bench.py ) > gpurun_out/r04_bench1.json 2> gpurun_out/r04_bench1.err
+tail -5 gpurun_out/r04_bench1.err
+python -m pytest tests/test_bench_multirank_gpu.py -q -x 2>&1 | tail -3
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r04_bench1.json') if x.startswith('{')]
+d=json.loads(l[0])
+print(d['value'], d['ms_per_step'], d['compress_MBps'], d['decompress_MBps'], d['roofline']['frac'], d['verified'])
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+for k,v in d['configs'].items():
+    print(k, {kk:vv for kk,vv in v.items() if kk in ('ms_per_step','compress_MBps','decompress_MBps','compress_ms','decompress_ms','kernel_ms','verified')})
+    cb=v.get('cpu_baseline'); print('   cpu', cb and {kk:cb[kk] for kk in cb if kk in ('value','cores','compress_MBps','decompress_MBps','t1')})
+print(d.get('end_to_end'))
+PY
