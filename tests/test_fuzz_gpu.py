@@ -26,3 +26,16 @@ def test_fuzz_deflate_roundtrip():
     from tools import fuzz_deflate
     n, bad = fuzz_deflate.run(list(range(BASE, BASE + 200)), BUDGET_S, log=lambda *a, **k: None)
     assert n >= 24 and bad == 0, (n, bad)
+
+
+def test_fuzz_stream_path_against_oracle():
+    """tools/fuzz_stream.py: every single-buffer decompress through the
+    many-wave path (forced on for all sizes, random chunk sizes): streams of
+    every producer and block kind, damaged variants, streams stored inside
+    streams; result codes and bytes against the oracle."""
+    from tools import fuzz_stream
+    msgs = []
+    n, bad, npar = fuzz_stream.run(list(range(BASE + 500, BASE + 540)), BUDGET_S,
+                                   log=lambda *a, **k: msgs.append(a))
+    assert bad == 0, msgs[-5:]
+    assert n >= 40 and npar >= n // 6, (n, npar)
