@@ -169,20 +169,28 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	if (nbits) {
 		for (uint64_t b0 = 0; b0 < nbits; b0 += 1ull << 31) {
 			const uint64_t nb = std::min<uint64_t>(nbits - b0, 1ull << 31);
-			hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nb + 255) / 256)),
+			/* (a workgroup of four waves takes 16 windows of 4 x 64 bytes) */
+			hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nb + 32767) / 32768)),
 					   dim3(256), 0, s_comp, d_raw, raw_n, b0, nbits, d_queue, d_cnt, qcap);
 		}
-		hipLaunchKernelGGL(lda_stream_find_b_kernel, dim3((qcap + 63) / 64), dim3(64), 16384,
+		hipLaunchKernelGGL(lda_stream_find_b_kernel,
+				   dim3(std::min<unsigned>((qcap + 63) / 64, 8u * (unsigned)ctx->num_cus)), dim3(64), 16384,
 				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
 		ST_TRY(hipGetLastError());
+		/* the counts and the first candidates in one round trip (a stream
+		 * of a few MiB has a few hundred) */
+		const uint32_t first = std::min<uint32_t>(ccap, 2048);
 		uint32_t cnt[2];
+		cands.resize(first);
 		ST_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s_comp));
+		ST_TRY(hipMemcpyAsync(cands.data(), d_cand, (size_t)first * 8,
+				      hipMemcpyDeviceToHost, s_comp));
 		ST_TRY(hipStreamSynchronize(s_comp));
 		const uint32_t nc = std::min(cnt[1], ccap);
 		cands.resize(nc);
-		if (nc) {
-			ST_TRY(hipMemcpyAsync(cands.data(), d_cand, (size_t)nc * 8,
-					      hipMemcpyDeviceToHost, s_comp));
+		if (nc > first) {
+			ST_TRY(hipMemcpyAsync(cands.data() + first, d_cand + first,
+					      (size_t)(nc - first) * 8, hipMemcpyDeviceToHost, s_comp));
 			ST_TRY(hipStreamSynchronize(s_comp));
 		}
 		std::sort(cands.begin(), cands.end());
@@ -192,8 +200,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 
 	lap(9);
 	/* ---- plan ---- */
-	uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk : raw_n / 512;
-	T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 4096), 65536);
+	/* chunks of a few KiB of input: up to about two thousand for a stream that
+	 * has them (a wave slot each on 256 CUs, one launch of the decode pass),
+	 * never under 2 KiB (the warm-up in front of an inner chunk is 1 KiB) */
+	uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk : raw_n / 1536;
+	T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 2048), 65536);
 	const uint64_t OV = 8192, HDRSAFE = 4608;
 	std::vector<planned> plan;
 	auto add_block = [&](uint64_t start, uint64_t next, bool dynamic) {

@@ -801,47 +801,92 @@ bits128(const u8 *inp, u64 in_n, u64 p, u64 *x0, u64 *x1)
 }
 
 /*
- * Stage A, one thread per bit offset: BTYPE = dynamic, HLIT <= 29, HDIST <= 29,
- * and the precode lengths form a COMPLETE code (the compressors emit nothing
- * else; incomplete ones are legal, rare, and found by the chain as ordinary
- * misses).  About one offset in five hundred passes on compressed data.
+ * Stage A: BTYPE = dynamic, HLIT <= 29, HDIST <= 29, and the precode lengths
+ * form a COMPLETE code (the compressors emit nothing else; incomplete ones
+ * are legal, rare, and found by the chain as ordinary misses).  About one
+ * offset in five hundred passes on compressed data.  A wave takes 64 bytes =
+ * 512 bit offsets: every lane tests the eight offsets of its byte for the
+ * cheap part (one in nine passes), the survivors are queued in LDS and the
+ * Kraft sum of the precode is then evaluated with all lanes busy.
+ * (a launch covers at most 2^31 offsets from bit0 on: the threads of a grid
+ * are counted in 32 bits)
  */
+static __device__ __forceinline__ bool precode_complete(u64 x0, u64 x1)
+{
+	const u32 h = (u32)x0;
+	const u32 npre = 4 + ((h >> 13) & 15);
+	u64 f = (x0 >> 17) | (x1 << 47);
+	f &= (1ull << (3 * npre)) - 1;
+	u32 kraft = 0;
+#pragma unroll
+	for (u32 i = 0; i < 19; i++)
+		kraft += (128u >> ((u32)(f >> (3 * i)) & 7)) & 127;
+	return kraft == 128;
+}
+
+#define FIND_A_WINDOWS 16	/* 2048-offset windows per workgroup */
 extern "C" __global__ void __launch_bounds__(256)
 lda_stream_find_a_kernel(const u8 *__restrict__ inp, u64 in_n, u64 bit0, u64 nbits,
 			 u64 *__restrict__ queue, u32 *__restrict__ qcount, u32 qcap)
 {
-	/* (a launch covers at most 2^31 offsets from bit0 on: the threads of a
-	 * grid are counted in 32 bits) */
-	const u64 p = bit0 + (u64)blockIdx.x * 256 + threadIdx.x;
-	bool pass = false;
-	if (p < nbits) {
-		u64 x0, x1;
-		bits128(inp, in_n, p, &x0, &x1);
-		const u32 h = (u32)x0;
-		if ((h & 6) == 4 && ((h >> 3) & 31) <= 29 && ((h >> 8) & 31) <= 29) {
-			const u32 npre = 4 + ((h >> 13) & 15);
-			u64 f = (x0 >> 17) | (x1 << 47);
-			f &= (1ull << (3 * npre)) - 1;
-			u32 kraft = 0;
+	__shared__ u16 wq[4][512];
+	__shared__ u64 found[512];	/* the workgroup's survivors: ONE atomic on the global counter */
+	__shared__ u32 nfound, gbase;
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0)
+		nfound = 0;
+	__syncthreads();
+	for (u32 win = 0; win < FIND_A_WINDOWS; win++) {
+		const u64 byte = (bit0 >> 3) +
+				 (((u64)blockIdx.x * FIND_A_WINDOWS + win) * 4 + wave) * 64 + lane;
+		if (8 * (byte - lane) >= nbits)
+			break;		/* (uniform per wave) */
+		const u64 w0 = load_in(inp, in_n, byte);	/* the 17 header bits of its 8 offsets */
+		u32 nq = 0;
 #pragma unroll
-			for (u32 i = 0; i < 19; i++)
-				kraft += (128u >> ((u32)(f >> (3 * i)) & 7)) & 127;
-			pass = kraft == 128;
+		for (u32 k = 0; k < 8; k++) {
+			const u32 h = (u32)(w0 >> k);	/* k + 17 <= 64 */
+			const bool ok = 8 * byte + k < nbits && (h & 6) == 4 &&
+					((h >> 3) & 31) <= 29 && ((h >> 8) & 31) <= 29;
+			const u64 m = __ballot(ok);
+			if (ok)
+				wq[wave][nq + __builtin_popcountll(m & ((1ull << lane) - 1))] =
+					(u16)(8 * lane + k);
+			nq += __builtin_popcountll(m);
 		}
-	}
-	const u64 m = __ballot(pass);
-	if (m) {
-		const u32 lane = lane_id();
-		u32 base = 0;
-		if (lane == (u32)__builtin_ctzll(m))
-			base = atomicAdd(qcount, (u32)__builtin_popcountll(m));
-		base = bcast_lane(base, (u32)__builtin_ctzll(m));
-		if (pass) {
-			const u32 at = base + __builtin_popcountll(m & ((1ull << lane) - 1));
-			if (at < qcap)
-				queue[at] = p;
+		wave_sync();
+		for (u32 q0 = 0; q0 < nq; q0 += 64) {
+			bool pass = false;
+			u64 p = 0;
+			if (q0 + lane < nq) {
+				p = 8 * (byte - lane) + wq[wave][q0 + lane];
+				u64 x0, x1;
+				bits128(inp, in_n, p, &x0, &x1);
+				pass = precode_complete(x0, x1);
+			}
+			const u64 m = __ballot(pass);
+			if (m) {
+				u32 base = 0;
+				if (lane == (u32)__builtin_ctzll(m))
+					base = atomicAdd(&nfound, (u32)__builtin_popcountll(m));
+				base = bcast_lane(base, (u32)__builtin_ctzll(m));
+				if (pass) {
+					const u32 at = base + __builtin_popcountll(m & ((1ull << lane) - 1));
+					if (at < 512)
+						found[at] = p;
+				}
+			}
 		}
+		wave_sync();
 	}
+	__syncthreads();
+	const u32 nf = nfound < 512 ? nfound : 512;
+	if (threadIdx.x == 0)
+		gbase = nf ? atomicAdd(qcount, nf) : 0;
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < nf; i += 256)
+		if (gbase + i < qcap)
+			queue[gbase + i] = found[i];
 }
 
 /*
@@ -851,6 +896,10 @@ lda_stream_find_a_kernel(const u8 *__restrict__ inp, u64 in_n, u64 bit0, u64 nbi
  * complete with an end-of-block symbol; the offset code complete, or a single
  * 1-bit codeword, or empty.
  */
+static __device__ void
+find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
+	   u64 *__restrict__ cand, u32 *__restrict__ ncand, u32 ccap);
+
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_find_b_kernel(const u8 *__restrict__ inp, u64 in_n,
 			 const u64 *__restrict__ queue, const u32 *__restrict__ qcount,
@@ -858,11 +907,16 @@ lda_stream_find_b_kernel(const u8 *__restrict__ inp, u64 in_n,
 {
 	u32 nq = *qcount;
 	nq = nq < qcap ? nq : qcap;
-	const u32 idx = blockIdx.x * 64 + threadIdx.x;
-	if (idx >= nq)
-		return;
 	lu16 *tab = (lu16 *)(uintptr_t)(threadIdx.x * 256u);
-	const u64 p = queue[idx];
+	/* (a fixed grid walks the queue: its length is only known on the device) */
+	for (u32 idx = blockIdx.x * 64 + threadIdx.x; idx < nq; idx += gridDim.x * 64)
+		find_b_one(inp, in_n, queue[idx], tab, cand, ncand, ccap);
+}
+
+static __device__ void
+find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
+	   u64 *__restrict__ cand, u32 *__restrict__ ncand, u32 ccap)
+{
 	u64 x0, x1;
 	bits128(inp, in_n, p, &x0, &x1);
 	const u32 h = (u32)x0;
@@ -986,15 +1040,21 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 	__syncthreads();
 	u32 bad = 0;
 	u16 nx[32];
+	/* (32 symbols per thread at most; the loops run in blocks of 8 and skip
+	 * the blocks a short tail does not reach: the branch is uniform) */
+#define TAIL_BLOCKS(n_, body)                                                  \
+	_Pragma("unroll") for (u32 kb = 0; kb < 4; kb++)                       \
+		if (kb * 8192u < (n_)) {                                       \
+			_Pragma("unroll") for (u32 k = 8 * kb; k < 8 * kb + 8; k++) { body } \
+		}
 	auto load_tail = [&](u32 c) {
 		const u64 s = out_off[c], e = out_off[c + 1];
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
 		const u32 n = (u32)(e - t0);
-#pragma unroll
-		for (u32 k = 0; k < 32; k++) {
+		TAIL_BLOCKS(n, {
 			const u32 i = tid + 1024 * k;
 			nx[k] = i < n ? sym[t0 + i] : 0;
-		}
+		})
 	};
 	load_tail(c0);
 	for (u32 c = c0; c < c1; c++) {
@@ -1002,16 +1062,13 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
 		const u32 n = (u32)(e - t0);
 		u16 v[32];
-#pragma unroll
-		for (u32 k = 0; k < 32; k++)
-			v[k] = nx[k];
+		TAIL_BLOCKS(n, { v[k] = nx[k]; })
 		if (c + 1 < c1)
 			load_tail(c + 1);
 		/* a marker w of this chunk is the position s - 32768 + w; the ones
 		 * below `lowest` lie before the stream's first byte */
 		const u32 lowest = s < 32768 ? 32768 - (u32)s : 0;
-#pragma unroll
-		for (u32 k = 0; k < 32; k++) {
+		TAIL_BLOCKS(n, {
 			const u32 i = tid + 1024 * k;
 			if (i < n && (v[k] & 0x8000)) {
 				const u32 w = v[k] & 0x7FFF;
@@ -1022,19 +1079,19 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 					v[k] = W[((u32)s + w) & 32767];
 				}
 			}
-		}
+		})
 		__syncthreads();
-#pragma unroll
-		for (u32 k = 0; k < 32; k++) {
+		TAIL_BLOCKS(n, {
 			const u32 i = tid + 1024 * k;
 			if (i < n) {
 				W[((u32)t0 + i) & 32767] = v[k];
 				if (phase != 0)
 					out[t0 + i] = (u8)v[k];
 			}
-		}
+		})
 		__syncthreads();
 	}
+#undef TAIL_BLOCKS
 	if (phase == 0) {
 		const u64 e1 = out_off[c1];
 		for (u32 i = tid; i < 32768; i += 1024)
@@ -1054,17 +1111,37 @@ lda_stream_window_link_kernel(u32 groups, const u16 *__restrict__ gwin,
 	__shared__ u8 F[2][32768];
 	const u32 tid = threadIdx.x;
 	u32 cur = 0;
+	/* two symbols per load; the next group's are requested before this
+	 * one's are settled */
+	u32 nx[16];
+	if (groups > 1) {
+#pragma unroll
+		for (u32 k = 0; k < 16; k++)
+			nx[k] = ((const u32 *)gwin)[tid + 1024 * k];
+	}
 	for (u32 g = 0; g + 1 < groups; g++) {
-		const u16 *src = gwin + (size_t)g * 32768;
 		u8 *dst = fwin + (size_t)g * 32768;
-#pragma unroll 8
-		for (u32 k = 0; k < 32; k++) {
-			const u32 i = tid + 1024 * k;
-			u32 b = src[i];
-			if (b & 0x8000)
-				b = g ? F[cur][b & 0x7FFF] : 0;
-			F[cur ^ 1][i] = (u8)b;
-			dst[i] = (u8)b;
+		u32 v[16];
+#pragma unroll
+		for (u32 k = 0; k < 16; k++)
+			v[k] = nx[k];
+		if (g + 2 < groups) {
+			const u32 *src = (const u32 *)(gwin + (size_t)(g + 1) * 32768);
+#pragma unroll
+			for (u32 k = 0; k < 16; k++)
+				nx[k] = src[tid + 1024 * k];
+		}
+#pragma unroll
+		for (u32 k = 0; k < 16; k++) {
+			const u32 i = 2 * (tid + 1024 * k);
+			u32 b0 = v[k] & 0xFFFF, b1 = v[k] >> 16;
+			if (b0 & 0x8000)
+				b0 = g ? F[cur][b0 & 0x7FFF] : 0;
+			if (b1 & 0x8000)
+				b1 = g ? F[cur][b1 & 0x7FFF] : 0;
+			const u16 two = (u16)((b0 & 0xFF) | (b1 << 8));
+			*(u16 *)&F[cur ^ 1][i] = two;
+			*(u16 *)(dst + i) = two;
 		}
 		__syncthreads();
 		cur ^= 1;
