@@ -128,6 +128,12 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		    void *const *out, const uint64_t *nbytes,
 		    const uint64_t *off, hipStream_t st);
 
+/* one contiguous host range <-> device range, in 1 MiB pieces (see above) */
+int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src, size_t n,
+	    hipStream_t st);
+int span_out(PinnedPair *pp, const uint8_t *d_base, uint64_t d_off, uint8_t *dst, size_t n,
+	     hipStream_t st);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 /* checksum of A || B from the checksums of A and B and the length of B

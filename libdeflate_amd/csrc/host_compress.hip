@@ -433,37 +433,6 @@ static size_t large_fail(const char *what)
 	return 0;
 }
 
-/* host memory <-> a device range through the object's pinned pair, cut into
- * pieces of 1 MiB so that the packing threads share the memcpy */
-static int span_in(struct libdeflate_compressor *c, uint8_t *d_base, uint64_t d_off,
-		   const uint8_t *src, size_t n, hipStream_t st)
-{
-	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
-	std::vector<const void *> ins(np);
-	std::vector<size_t> nb(np);
-	std::vector<uint64_t> off(np);
-	for (size_t i = 0; i < np; i++) {
-		ins[i] = src + i * P;
-		nb[i] = i + 1 < np ? P : n - i * P;
-		off[i] = d_off + i * P;
-	}
-	return copy_in_packed(&c->pinned, d_base, np, ins.data(), nb.data(), off.data(), st);
-}
-
-static int span_out(struct libdeflate_compressor *c, const uint8_t *d_base, uint64_t d_off,
-		    uint8_t *dst, size_t n, hipStream_t st)
-{
-	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
-	std::vector<void *> outs(np);
-	std::vector<uint64_t> nb(np), off(np);
-	for (size_t i = 0; i < np; i++) {
-		outs[i] = dst + i * P;
-		nb[i] = i + 1 < np ? P : n - i * P;
-		off[i] = d_off + i * P;
-	}
-	return copy_out_packed(&c->pinned, d_base, np, outs.data(), nb.data(), off.data(), st);
-}
-
 /*
  * The segments go through in SLICES of up to 32 MiB of input on the object's
  * two streams, like the host-pointer batches: while the kernels of slice k
@@ -579,7 +548,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 			fits = false;
 			return true;
 		}
-		if (tk && span_out(c, st, pk_at + lo * slot, out + total, tk, s_copy) != LIBDEFLATE_AMD_OK)
+		if (tk && span_out(&c->pinned, st, pk_at + lo * slot, out + total, tk, s_copy) != LIBDEFLATE_AMD_OK)
 			return false;
 		total += tk;
 		return true;
@@ -589,7 +558,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 		const size_t a = lo * S, b = std::min(n, (lo + nk) * S);
 		/* (returns when the slice - and, the first time, the descriptors -
 		 * are on the device) */
-		if (span_in(c, st, in_at + a, in + a, b - a, s_copy) != LIBDEFLATE_AMD_OK) {
+		if (span_in(&c->pinned, st, in_at + a, in + a, b - a, s_copy) != LIBDEFLATE_AMD_OK) {
 			failed = true;
 			break;
 		}

@@ -5,7 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <thread>
+#include <vector>
 
 #include "host_common.h"
 #include "kernels.h"
@@ -254,6 +256,10 @@ int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
 		if (!pp->ensure(span))
 			return LIBDEFLATE_AMD_OOM;
 	}
+	/* a span goes through in at least four pieces, so that the DMA of one
+	 * pinned buffer runs beside the packing of the other */
+	const size_t lim = n > 1 ? std::min<size_t>(pp->cap, std::max<size_t>(
+		(size_t)2 << 20, (size_t)(off[n - 1] + in_nbytes[n - 1] - off[0]) / 4)) : pp->cap;
 	int b = 0;
 	bool used[2] = { false, false };
 	for (size_t i = 0; i < n;) {
@@ -266,7 +272,7 @@ int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
 		}
 		const uint64_t s0 = off[i];
 		size_t j = i;
-		while (j < n && off[j] + in_nbytes[j] - s0 <= pp->cap)
+		while (j < n && (j == i || off[j] + in_nbytes[j] - s0 <= lim))
 			j++;
 		if (used[b])
 			LDA_HIP_TRY(hipEventSynchronize(pp->ev[b]), LIBDEFLATE_AMD_NO_DEVICE);
@@ -300,6 +306,7 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		    void *const *out, const uint64_t *nbytes,
 		    const uint64_t *off, hipStream_t st)
 {
+	uint64_t span_all = 0;
 	{
 		uint64_t lo = 0, hi = 0;
 		bool any = false;
@@ -312,7 +319,10 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 			}
 		if (!pp->ensure(hi - lo))
 			return LIBDEFLATE_AMD_OOM;
+		span_all = hi - lo;
 	}
+	const size_t lim = n > 1 ? std::min<size_t>(pp->cap, std::max<size_t>((size_t)2 << 20,
+										    (size_t)span_all / 4)) : pp->cap;
 	struct slice { size_t i, j; uint64_t s0, span; int b; };
 	auto next_slice = [&](size_t i, int b, slice *s) {
 		while (i < n && nbytes[i] == 0)
@@ -329,7 +339,7 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 			s->span = nbytes[i];
 			return;
 		}
-		while (j < n && off[j] + nbytes[j] - s->s0 <= pp->cap) {
+		while (j < n && (j == i || off[j] + nbytes[j] - s->s0 <= lim)) {
 			if (nbytes[j])
 				s->span = off[j] + nbytes[j] - s->s0;
 			j++;
@@ -370,6 +380,38 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		cur = nxt;
 	}
 	return rc;
+}
+
+/* one contiguous host range <-> a device range through a pinned pair, cut into
+ * pieces of 1 MiB so that the packing threads share the memcpy and the DMA of
+ * one pinned buffer runs beside the memcpy of the other */
+int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src, size_t n,
+	    hipStream_t st)
+{
+	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
+	std::vector<const void *> ins(np);
+	std::vector<size_t> nb(np);
+	std::vector<uint64_t> off(np);
+	for (size_t i = 0; i < np; i++) {
+		ins[i] = src + i * P;
+		nb[i] = i + 1 < np ? P : n - i * P;
+		off[i] = d_off + i * P;
+	}
+	return copy_in_packed(pp, d_base, np, ins.data(), nb.data(), off.data(), st);
+}
+
+int span_out(PinnedPair *pp, const uint8_t *d_base, uint64_t d_off, uint8_t *dst, size_t n,
+	     hipStream_t st)
+{
+	const size_t P = (size_t)1 << 20, np = (n + P - 1) / P;
+	std::vector<void *> outs(np);
+	std::vector<uint64_t> nb(np), off(np);
+	for (size_t i = 0; i < np; i++) {
+		outs[i] = dst + i * P;
+		nb[i] = i + 1 < np ? P : n - i * P;
+		off[i] = d_off + i * P;
+	}
+	return copy_out_packed(pp, d_base, np, outs.data(), nb.data(), off.data(), st);
 }
 
 #define MAX_DEVICES 16

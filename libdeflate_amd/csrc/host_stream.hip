@@ -141,6 +141,40 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	if (!d->streams.ensure())
 		return false;
 	hipStream_t s_copy = d->streams.copy, s_comp = d->streams.comp;
+	/* The small transfers of every phase (descriptors down, results back) go
+	 * through pinned memory: from and to pageable memory each of them would
+	 * be staged by the runtime and cost a host-blocking round trip of its own.
+	 * pin_phase() sizes the arena (nothing may be in flight), up() / back()
+	 * queue a copy, pin_sync() waits and delivers what came back. */
+	uint8_t *pin_base = nullptr;
+	size_t pin_used = 0;
+	struct pending_t { void *dst; const void *src; size_t n; };
+	std::vector<pending_t> pin_pending;
+	auto pin_phase = [&](size_t need) -> bool {
+		pin_base = (uint8_t *)d->meta.ensure(need + 1024);
+		pin_used = 0;
+		return pin_base != nullptr;
+	};
+	auto up = [&](void *dev, const void *src, size_t n) -> hipError_t {
+		uint8_t *q = pin_base + pin_used;
+		pin_used += align_up(n, 64);
+		memcpy(q, src, n);
+		return hipMemcpyAsync(dev, q, n, hipMemcpyHostToDevice, s_comp);
+	};
+	auto back = [&](void *dst, const void *dev, size_t n) -> hipError_t {
+		uint8_t *q = pin_base + pin_used;
+		pin_used += align_up(n, 64);
+		pin_pending.push_back({ dst, q, n });
+		return hipMemcpyAsync(q, dev, n, hipMemcpyDeviceToHost, s_comp);
+	};
+	auto pin_sync = [&]() -> hipError_t {
+		const hipError_t e = hipStreamSynchronize(s_comp);
+		for (const pending_t &c : pin_pending)
+			memcpy(c.dst, c.src, c.n);
+		pin_pending.clear();
+		pin_used = 0;
+		return e;
+	};
 
 	/* ---- input to the device; the finder's queues behind it ---- */
 	const uint64_t nbits = raw_bits > 80 ? raw_bits - 80 : 0;	/* a header needs its bits */
@@ -155,12 +189,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	if (!sin)
 		return false;
 	uint8_t *d_raw = sin + in_at + hdr;
-	{
-		const void *ins[1] = { in };
-		const uint64_t off[1] = { in_at };
-		if (copy_in_packed(&d->pinned, sin, 1, ins, &in_nbytes, off, s_copy) != LIBDEFLATE_AMD_OK)
-			return false;
-	}
+	if (span_in(&d->pinned, sin, in_at, in, in_nbytes, s_copy) != LIBDEFLATE_AMD_OK)
+		return false;
 	lap(8);
 	uint64_t *d_queue = (uint64_t *)(sin + q_at), *d_cand = (uint64_t *)(sin + c_at);
 	uint32_t *d_cnt = (uint32_t *)(sin + cnt_at);	/* [0] queue, [1] candidates, [2] error flag */
@@ -182,16 +212,18 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		const uint32_t first = std::min<uint32_t>(ccap, 2048);
 		uint32_t cnt[2];
 		cands.resize(first);
-		ST_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s_comp));
-		ST_TRY(hipMemcpyAsync(cands.data(), d_cand, (size_t)first * 8,
-				      hipMemcpyDeviceToHost, s_comp));
-		ST_TRY(hipStreamSynchronize(s_comp));
+		if (!pin_phase(64 + (size_t)first * 8))
+			return false;
+		ST_TRY(back(cnt, d_cnt, 8));
+		ST_TRY(back(cands.data(), d_cand, (size_t)first * 8));
+		ST_TRY(pin_sync());
 		const uint32_t nc = std::min(cnt[1], ccap);
 		cands.resize(nc);
 		if (nc > first) {
-			ST_TRY(hipMemcpyAsync(cands.data() + first, d_cand + first,
-					      (size_t)(nc - first) * 8, hipMemcpyDeviceToHost, s_comp));
-			ST_TRY(hipStreamSynchronize(s_comp));
+			if (!pin_phase((size_t)(nc - first) * 8))
+				return false;
+			ST_TRY(back(cands.data() + first, d_cand + first, (size_t)(nc - first) * 8));
+			ST_TRY(pin_sync());
 		}
 		std::sort(cands.begin(), cands.end());
 		S[2] = cnt[0];
@@ -271,13 +303,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	for (uint32_t i = 0; i < np; i++)
 		hc[i] = plan[i].c;
 	std::vector<lda_stream_res> hr(np);
-	ST_TRY(hipMemcpyAsync(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk),
-			      hipMemcpyHostToDevice, s_comp));
+	if (!pin_phase((size_t)np * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
+		return false;
+	ST_TRY(up(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk)));
 	if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, raw_n))
 		return false;
-	ST_TRY(hipMemcpyAsync(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res),
-			      hipMemcpyDeviceToHost, s_comp));
-	ST_TRY(hipStreamSynchronize(s_comp));
+	ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
+	ST_TRY(pin_sync());
 
 	/* ---- chain ----
 	 * Every counted chunk is a pool entry keyed by its exact start state.  The
@@ -393,13 +425,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			lda_stream_chunk *d_rc = (lda_stream_chunk *)rp;
 			lda_stream_res *d_rr = (lda_stream_res *)(rp + align_up((size_t)nr * sizeof(lda_stream_chunk), 64));
 			std::vector<lda_stream_res> rr(nr);
-			ST_TRY(hipMemcpyAsync(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk),
-					      hipMemcpyHostToDevice, s_comp));
+			if (!pin_phase((size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
+				return false;
+			ST_TRY(up(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk)));
 			if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, raw_n))
 				return false;
-			ST_TRY(hipMemcpyAsync(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res),
-					      hipMemcpyDeviceToHost, s_comp));
-			ST_TRY(hipStreamSynchronize(s_comp));
+			ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
+			ST_TRY(pin_sync());
 			if (getenv("LDA_STREAM_DEBUG")) {
 				const auto now = std::chrono::steady_clock::now();
 				uint64_t span = 0, si = 0;
@@ -475,10 +507,10 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		d_chunks = (lda_stream_chunk *)sch;
 		d_res = (lda_stream_res *)(sch + res2_at);
 		uint64_t *d_off = (uint64_t *)(sch + off2_at);
-		ST_TRY(hipMemcpyAsync(d_chunks, acc.data(), (size_t)na * sizeof(lda_stream_chunk),
-				      hipMemcpyHostToDevice, s_comp));
-		ST_TRY(hipMemcpyAsync(d_off, offs.data(), ((size_t)na + 1) * 8,
-				      hipMemcpyHostToDevice, s_comp));
+		if (!pin_phase((size_t)na * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res) + 8) + 512))
+			return false;
+		ST_TRY(up(d_chunks, acc.data(), (size_t)na * sizeof(lda_stream_chunk)));
+		ST_TRY(up(d_off, offs.data(), ((size_t)na + 1) * 8));
 		for (size_t lo = 0; lo < na; lo += BATCH) {
 			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
 			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
@@ -526,10 +558,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		ST_TRY(hipGetLastError());
 		std::vector<lda_stream_res> dr(na);
 		uint32_t err = 0;
-		ST_TRY(hipMemcpyAsync(dr.data(), d_res, (size_t)na * sizeof(lda_stream_res),
-				      hipMemcpyDeviceToHost, s_comp));
-		ST_TRY(hipMemcpyAsync(&err, d_cnt + 2, 4, hipMemcpyDeviceToHost, s_comp));
-		ST_TRY(hipStreamSynchronize(s_comp));
+		ST_TRY(back(dr.data(), d_res, (size_t)na * sizeof(lda_stream_res)));
+		ST_TRY(back(&err, d_cnt + 2, 4));
+		ST_TRY(pin_sync());
 		bool same = err == 0;
 		for (uint32_t i = 0; i < na && same; i++)
 			same = dr[i].end_bit == accr[i].end_bit && dr[i].nout == accr[i].nout &&
@@ -561,14 +592,16 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			uint64_t *d_po = (uint64_t *)scr;
 			uint32_t *d_sums = (uint32_t *)(scr + npc * 16);
 			std::vector<uint32_t> sums(npc);
-			ST_TRY(hipMemcpyAsync(d_po, po.data(), npc * 16, hipMemcpyHostToDevice, s_comp));
+			if (!pin_phase(npc * 20 + 256))
+				return false;
+			ST_TRY(up(d_po, po.data(), npc * 16));
 			const int rc = format == LIBDEFLATE_AMD_GZIP ?
 				libdeflate_amd_crc32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp) :
 				libdeflate_amd_adler32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp);
 			if (rc != LIBDEFLATE_AMD_OK)
 				return false;
-			ST_TRY(hipMemcpyAsync(sums.data(), d_sums, npc * 4, hipMemcpyDeviceToHost, s_comp));
-			ST_TRY(hipStreamSynchronize(s_comp));
+			ST_TRY(back(sums.data(), d_sums, npc * 4));
+			ST_TRY(pin_sync());
 			for (size_t i = 0; i < npc; i++)
 				sum = i == 0 ? sums[0] :
 				      format == LIBDEFLATE_AMD_GZIP ?
@@ -592,9 +625,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	}
 	lap(12);
 	if (result == LIBDEFLATE_SUCCESS && total) {
-		void *outs[1] = { out };
-		const uint64_t nb[1] = { total }, off[1] = { 0 };
-		if (copy_out_packed(&d->pinned, d_out, 1, outs, nb, off, s_copy) != LIBDEFLATE_AMD_OK)
+		if (span_out(&d->pinned, d_out, 0, out, (size_t)total, s_copy) != LIBDEFLATE_AMD_OK)
 			return false;
 	}
 	lap(13);
