@@ -55,7 +55,7 @@ struct EnvCfg {
 	int host_threads = 4;		/* LDA_HOST_THREADS: packing threads of the host-pointer batches */
 	size_t seg_bytes = 0;		/* LDA_SEG_BYTES: sub-range of the segmented single-buffer compress (0 = by size) */
 	bool no_stream_par = false;	/* LDA_NO_STREAM_PAR: single streams stay on one wave */
-	size_t stream_par_min = 32768;	/* LDA_STREAM_PAR_MIN: smallest stream (bytes in) for the many-wave path */
+	size_t stream_par_min = 16384;	/* LDA_STREAM_PAR_MIN: smallest stream (bytes in) for the many-wave path */
 	size_t stream_chunk = 0;	/* LDA_STREAM_CHUNK: input bytes per chunk of that path (0 = by size) */
 };
 const EnvCfg &env_cfg();

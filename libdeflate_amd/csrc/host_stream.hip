@@ -204,7 +204,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					   dim3(256), 0, s_comp, d_raw, raw_n, b0, nbits, d_queue, d_cnt, qcap);
 		}
 		hipLaunchKernelGGL(lda_stream_find_b_kernel,
-				   dim3(std::min<unsigned>((qcap + 63) / 64, 8u * (unsigned)ctx->num_cus)), dim3(64), 16384,
+				   dim3(std::min<unsigned>((qcap + 63) / 64, 8u * (unsigned)ctx->num_cus)), dim3(64),
+				   lda_stream_find_b_lds(),
 				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
 		ST_TRY(hipGetLastError());
 		/* the counts and the first candidates in one round trip (a stream

@@ -58,6 +58,9 @@ typedef AS3 u16 lsym;
 
 #define SM_COUNT 1
 #define SM_MARK 2
+/* LDS of a wave of the block finder's second stage */
+#define FIND_B_TAB_BYTES 16384u		/* 64 precode tables of 128 u16 */
+#define FIND_B_LDS (FIND_B_TAB_BYTES + 64 * 72)	/* + a row of input per lane */
 
 /* LDS of one chunk wave: tables, shared tables, 16-bit output mirror, stage +
  * token map (the layout of lda_inflate_wave_kernel with a 16-bit mirror) */
@@ -788,6 +791,11 @@ extern "C" size_t lda_stream_tokcap(void)
 	return PAR_SCRATCH;
 }
 
+extern "C" size_t lda_stream_find_b_lds(void)
+{
+	return FIND_B_LDS;
+}
+
 /* ---------------- the block finder ---------------- */
 
 /* 64 bits of input at bit position p (zeros past the end) and the 64 after */
@@ -923,22 +931,64 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 	const u32 nlit = 257 + ((h >> 3) & 31), noff = 1 + ((h >> 8) & 31);
 	const u32 npre = 4 + ((h >> 13) & 15);
 	u64 f = (x0 >> 17) | (x1 << 47);
-	u8 plens[19];
-	for (u32 i = 0; i < 19; i++)
-		plens[i] = 0;
-	for (u32 i = 0; i < npre; i++)
-		plens[c_pre_perm[i]] = (u8)((f >> (3 * i)) & 7);
-	if (!build_precode(tab, plens))
-		return;
+	f &= (1ull << (3 * npre)) - 1;
+	/* The precode's decode table, from registers only (field i of f is the
+	 * length of symbol c_pre_perm[i]; the first stage has checked that the
+	 * code is complete): lengths counted in 5-bit fields, first codewords per
+	 * length in 8-bit fields, codewords handed out in symbol order.  (The
+	 * general build_precode() indexes small arrays with run-time values: they
+	 * live in scratch memory, a trip to memory per access.) */
+	{
+		u64 cntp = 0, nextp = 0;
+#pragma unroll
+		for (u32 i = 0; i < 19; i++)
+			cntp += 1ull << (5 * ((u32)(f >> (3 * i)) & 7));
+		u32 code = 0;
+#pragma unroll
+		for (u32 l = 1; l <= 7; l++) {
+			nextp |= (u64)code << (8 * l);
+			code = (code + ((u32)(cntp >> (5 * l)) & 31)) << 1;
+		}
+		/* position of symbol s in the permuted header order */
+		static constexpr u8 inv[19] = { 3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12,
+						14, 16, 18, 0, 1, 2 };
+#pragma unroll
+		for (u32 sy = 0; sy < 19; sy++) {
+			const u32 l = (u32)(f >> (3 * inv[sy])) & 7;
+			if (l) {
+				const u32 c = (u32)(nextp >> (8 * l)) & 0xFF;
+				nextp += 1ull << (8 * l);
+				const u32 rev = __brev(c) >> (32 - l);
+				for (u32 e = rev; e < 128; e += 1u << l)
+					tab[e] = ENTRY(0, sy, l);
+			}
+		}
+	}
 	u64 bp = p + 17 + 3 * npre;	/* next bit to read */
 	u64 buf = 0;
 	u32 cnt = 0;
 	u32 i = 0, prev = 0, kl = 0, ko = 0, n_o = 0, eob_len = 0;
 	const u32 total = nlit + noff;
 	bool ok = true;
+	/* the lane's next 72 bytes of input sit in its LDS row (nine loads in
+	 * flight at once, then ~60 code lengths without touching memory: a refill
+	 * from memory per four code lengths made this kernel wait 150 us for a
+	 * handful of candidates) */
+	lu64 *row = (lu64 *)(uintptr_t)(FIND_B_TAB_BYTES + threadIdx.x * 72u);
+	u64 row_byte = ~0ull;
 	while (i < total) {
 		if (cnt < 14) {
-			buf = load_in(inp, in_n, bp >> 3) >> (bp & 7);
+			u64 r = (bp >> 3) - row_byte;
+			if (row_byte == ~0ull || r > 56) {
+				row_byte = bp >> 3;
+#pragma unroll
+				for (u32 k = 0; k < 9; k++)
+					row[k] = load_in(inp, in_n, row_byte + 8 * k);
+				r = 0;
+			}
+			const u32 w = (u32)r >> 3, sh = 8 * ((u32)r & 7) + ((u32)bp & 7);
+			const u64 a = row[w], b = row[w + 1];
+			buf = sh ? (a >> sh) | (b << (64 - sh)) : a;
 			cnt = 56;	/* at least 57 valid bits */
 		}
 		const u32 e = tab[(u32)buf & 127];
@@ -979,6 +1029,12 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 			n_o += rep - n1;
 			if (i <= 256 && 256 < i + n1)
 				eob_len = val;
+			/* an over-subscribed code cannot recover: most false survivors
+			 * of the first stage end here within a dozen lengths */
+			if (kl > 32768 || ko > 32768) {
+				ok = false;
+				break;
+			}
 		}
 		prev = val;
 		i += rep;

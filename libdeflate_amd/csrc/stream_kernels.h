@@ -67,6 +67,7 @@ extern "C" __global__ void
 lda_stream_resolve_kernel(uint32_t nchunks, const uint64_t *out_off, const uint16_t *sym,
 			  uint8_t *out, uint32_t *err);
 extern "C" size_t lda_stream_chunk_lds(void);
+extern "C" size_t lda_stream_find_b_lds(void);
 extern "C" size_t lda_stream_tokcap(void);	/* u32 words of token scratch per decode wave */
 
 #endif /* LDA_STREAM_KERNELS_H */

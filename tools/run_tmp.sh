@@ -1,8 +1,11 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r04_t4.log
-python tools/bench_stream.py 1 16 64 2>&1 | grep -v amdgpu >> gpurun_out/r04_t4.log
-for a in "1 32" "16 8" "64 6"; do python tools/bench_single_api.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_t4.log; done
-python tools/bench_host_batch.py 2>&1 | grep -v amdgpu.ids | tail -4 >> gpurun_out/r04_t4.log
-cat gpurun_out/r04_t4.log
+python tools/bench_stream.py 0.125 1 16 2>&1 | grep -v amdgpu > gpurun_out/r04_bs10.log
+python -m pytest tests/test_stream_gpu.py -x -q 2>&1 | tail -2 >> gpurun_out/r04_bs10.log
+cd /tmp
+rm -rf $R/gpurun_out/trace_s2; mkdir -p $R/gpurun_out/trace_s2
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace_s2 -o s --output-format csv -- python $R/tools/bench_stream.py 0.125 > /dev/null 2>&1
+for f in $(find $R/gpurun_out/trace_s2 -name "*kernel_stats.csv"); do head -8 $f >> $R/gpurun_out/r04_bs10.log; done
+find $R/gpurun_out/trace_s2 -name "*_trace.csv" -delete
+cat $R/gpurun_out/r04_bs10.log
