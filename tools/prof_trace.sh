@@ -1,14 +1,22 @@
 #!/bin/bash
-# rocprofv3 kernel trace + stats of the default bench.py run (run via gpurun).
-# Writes gpurun_out/trace_rNN/ ; copy the *_kernel_stats.csv into profiles/.
+# rocprofv3 kernel trace + stats of one workload (run via gpurun).
+# usage: tools/prof_trace.sh <tag> [bench|small|opt|stream]
+# Writes gpurun_out/trace_<tag>_<what>/ ; copy the *_kernel_stats.csv into profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 tag=${1:-r01}
-rm -rf $R/gpurun_out/trace_$tag; mkdir -p $R/gpurun_out/trace_$tag
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace_$tag -o bench --output-format csv -- \
-    python $R/bench.py --steps 3 --warmup 1 --no-cpu --configs headline > $R/gpurun_out/trace_$tag/bench_stdout.log 2>&1 || true
-tail -2 $R/gpurun_out/trace_$tag/bench_stdout.log
-find $R/gpurun_out/trace_$tag -name "*kernel_stats.csv" | head -1 | xargs cat | head -12
+what=${2:-bench}
+case $what in
+  bench)  cmd="python $R/bench.py --steps 3 --warmup 1 --no-cpu --configs headline" ;;
+  small)  cmd="python $R/tools/microbench.py deflate --size 4096 --chunks 1048576 --level 9 --fmt zlib --iters 2" ;;
+  opt)    cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 12 --iters 2" ;;
+  stream) cmd="python $R/tools/bench_stream.py 16" ;;
+esac
+D=$R/gpurun_out/trace_${tag}_$what
+rm -rf $D; mkdir -p $D
+rocprofv3 --kernel-trace --stats -d $D -o $what --output-format csv -- $cmd > $D/stdout.log 2>&1 || true
+tail -2 $D/stdout.log
+find $D -name "*kernel_stats.csv" | head -1 | xargs cat | head -12
 # keep only the small summaries
-find $R/gpurun_out/trace_$tag -name "*kernel_trace.csv" -delete
+find $D -name "*kernel_trace.csv" -delete
