@@ -56,6 +56,7 @@ struct EnvCfg {
 	size_t seg_bytes = 0;		/* LDA_SEG_BYTES: sub-range of the segmented single-buffer compress (0 = by size) */
 	bool no_stream_par = false;	/* LDA_NO_STREAM_PAR: single streams stay on one wave */
 	size_t stream_par_min = 16384;	/* LDA_STREAM_PAR_MIN: smallest stream (bytes in) for the many-wave path */
+	size_t stream_window = 0;	/* LDA_STREAM_WINDOW: first input window of that path (0 = 4 MiB) */
 	size_t stream_chunk = 0;	/* LDA_STREAM_CHUNK: input bytes per chunk of that path (0 = by size) */
 };
 const EnvCfg &env_cfg();

@@ -68,6 +68,11 @@ static EnvCfg read_env()
 	c.no_stream_par = getenv("LDA_NO_STREAM_PAR") != nullptr;
 	if (const char *e = getenv("LDA_STREAM_PAR_MIN"))
 		c.stream_par_min = (size_t)strtoull(e, nullptr, 0);
+	if (const char *e = getenv("LDA_STREAM_WINDOW")) {
+		c.stream_window = (size_t)strtoull(e, nullptr, 0);
+		if (c.stream_window && c.stream_window < 32768)
+			c.stream_window = 32768;
+	}
 	if (const char *e = getenv("LDA_STREAM_CHUNK"))
 		c.stream_chunk = (size_t)strtoull(e, nullptr, 0);
 	return c;

@@ -176,298 +176,350 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		return e;
 	};
 
-	/* ---- input to the device; the finder's queues behind it ---- */
-	const uint64_t nbits = raw_bits > 80 ? raw_bits - 80 : 0;	/* a header needs its bits */
-	/* about one offset in 500 passes the first filter on compressed data and a
-	 * real block is rarely under a few hundred bits; a queue that overflows
-	 * only loses entry points */
-	const uint32_t qcap = (uint32_t)std::min<uint64_t>(nbits / 128 + 4096, 1u << 28);
-	const uint32_t ccap = (uint32_t)std::min<uint64_t>(nbits / 512 + 4096, 1u << 26);
-	const size_t in_at = 64, q_at = align_up(in_at + in_nbytes + 64, 64);
+	/*
+	 * The input is taken in WINDOWS (4 to 16 MiB of it, then four times as much
+	 * each time, up to all of it): copied to the device, searched for block starts,
+	 * planned, counted and chained - and when the chain reaches the stream's
+	 * final block inside a window, the rest of the input is never touched.  The
+	 * reference's callers hand the decompressor everything that is left of a
+	 * file (programs/gzip.c:236-299 loops over the members of a .gz that way):
+	 * without windows every call on a multi-member file would copy and search
+	 * the whole remainder.  A window that ends before the final block hands its
+	 * last accepted state (position, governing header) to the next one.
+	 */
+	/* (the first window by the output space: a stream rarely takes more input
+	 * than half of what it produces, so one that fits the caller's buffer
+	 * usually ends inside a window of out_avail / 2) */
+	const size_t W0 = env.stream_window ? env.stream_window :
+			  std::min<size_t>(std::max<size_t>(out_avail / 2, (size_t)4 << 20), (size_t)16 << 20);
+	const size_t in_at = 64;
+	/* [input][finder queue][candidates][counters]: sized for the whole input
+	 * (grow-only; a window never needs more than that) */
+	const uint64_t all_bits = raw_bits;
+	const uint32_t qcap = (uint32_t)std::min<uint64_t>(all_bits / 128 + 4096, 1u << 28);
+	const uint32_t ccap = (uint32_t)std::min<uint64_t>(all_bits / 512 + 4096, 1u << 26);
+	const size_t q_at = align_up(in_at + in_nbytes + 64, 64);
 	const size_t c_at = q_at + (size_t)qcap * 8, cnt_at = c_at + (size_t)ccap * 8;
 	uint8_t *sin = (uint8_t *)d->sin.reserve(cnt_at + 64);
 	if (!sin)
 		return false;
 	uint8_t *d_raw = sin + in_at + hdr;
-	if (span_in(&d->pinned, sin, in_at, in, in_nbytes, s_copy) != LIBDEFLATE_AMD_OK)
-		return false;
-	lap(8);
 	uint64_t *d_queue = (uint64_t *)(sin + q_at), *d_cand = (uint64_t *)(sin + c_at);
 	uint32_t *d_cnt = (uint32_t *)(sin + cnt_at);	/* [0] queue, [1] candidates, [2] error flag */
-	ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
-	std::vector<uint64_t> cands;
-	if (nbits) {
-		for (uint64_t b0 = 0; b0 < nbits; b0 += 1ull << 31) {
-			const uint64_t nb = std::min<uint64_t>(nbits - b0, 1ull << 31);
-			/* (a workgroup of four waves takes 16 windows of 4 x 64 bytes) */
-			hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nb + 32767) / 32768)),
-					   dim3(256), 0, s_comp, d_raw, raw_n, b0, nbits, d_queue, d_cnt, qcap);
-		}
-		hipLaunchKernelGGL(lda_stream_find_b_kernel,
-				   dim3(std::min<unsigned>((qcap + 63) / 64, 8u * (unsigned)ctx->num_cus)), dim3(64),
-				   lda_stream_find_b_lds(),
-				   s_comp, d_raw, raw_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
-		ST_TRY(hipGetLastError());
-		/* the counts and the first candidates in one round trip (a stream
-		 * of a few MiB has a few hundred) */
-		const uint32_t first = std::min<uint32_t>(ccap, 2048);
-		uint32_t cnt[2];
-		cands.resize(first);
-		if (!pin_phase(64 + (size_t)first * 8))
-			return false;
-		ST_TRY(back(cnt, d_cnt, 8));
-		ST_TRY(back(cands.data(), d_cand, (size_t)first * 8));
-		ST_TRY(pin_sync());
-		const uint32_t nc = std::min(cnt[1], ccap);
-		cands.resize(nc);
-		if (nc > first) {
-			if (!pin_phase((size_t)(nc - first) * 8))
-				return false;
-			ST_TRY(back(cands.data() + first, d_cand + first, (size_t)(nc - first) * 8));
-			ST_TRY(pin_sync());
-		}
-		std::sort(cands.begin(), cands.end());
-		S[2] = cnt[0];
-		S[3] = nc;
-	}
 
-	lap(9);
-	/* ---- plan ---- */
-	/* chunks of a few KiB of input: up to about two thousand for a stream that
-	 * has them (a wave slot each on 256 CUs, one launch of the decode pass),
-	 * never under 2 KiB (the warm-up in front of an inner chunk is 1 KiB) */
-	uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk : raw_n / 1536;
-	T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 2048), 65536);
-	const uint64_t OV = 8192, HDRSAFE = 4608;
-	std::vector<planned> plan;
-	auto add_block = [&](uint64_t start, uint64_t next, bool dynamic) {
-		planned p = {};
-		p.c.kind = LDA_CHUNK_HEADER;
-		p.c.hdr_bit = p.c.start_bit = p.c.target_bit = start;
-		p.at = start;
-		plan.push_back(p);
-		if (!dynamic)
-			return;
-		for (uint64_t P = start + T; P + T / 2 <= next; P += T) {
-			uint64_t ws = P > OV ? P - OV : 0;
-			if (ws < start + HDRSAFE)
-				ws = start + HDRSAFE;
-			if (ws + OV / 4 > P)
-				continue;
-			planned q = {};
-			q.c.kind = LDA_CHUNK_WARM;
-			q.c.hdr_bit = start;
-			q.c.start_bit = ws;
-			q.c.target_bit = P;
-			q.at = P;
-			plan.push_back(q);
-		}
-	};
-	{
-		/* block starts: the stream's first bit, then the candidates.  A block's
-		 * inner chunks end at the next candidate whatever becomes of it; a small
-		 * block close behind a chunk start gets no chunk of its own (the chunk
-		 * in front of it walks through), so chunk starts are at least T / 8
-		 * apart however small the blocks are */
-		std::vector<uint64_t> cs;
-		bool first_dynamic = false;
-		for (uint64_t c : cands) {
-			if (c == 0)
-				first_dynamic = true;
-			else
-				cs.push_back(c);
-		}
-		uint64_t last_at = 0;
-		add_block(0, cs.empty() ? raw_bits : cs[0], first_dynamic);
-		for (size_t i = 0; i < cs.size(); i++) {
-			const uint64_t next = i + 1 < cs.size() ? cs[i + 1] : raw_bits;
-			if (cs[i] - last_at < T / 8 && next - cs[i] < T / 2)
-				continue;
-			add_block(cs[i], next, true);
-			last_at = cs[i];
-		}
-	}
-	for (size_t i = 0; i < plan.size(); i++)
-		plan[i].c.limit_bit = i + 1 < plan.size() ? plan[i + 1].at : raw_bits;
-	const uint32_t np = (uint32_t)plan.size();
-	S[4] = np;
-
-	/* ---- count ---- */
-	const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
-	uint8_t *sch = (uint8_t *)d->schunks.reserve(
-		res_at + align_up((size_t)np * sizeof(lda_stream_res) + 64, 64));
-	if (!sch)
-		return false;
-	lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
-	lda_stream_res *d_res = (lda_stream_res *)(sch + res_at);
-	std::vector<lda_stream_chunk> hc(np);
-	for (uint32_t i = 0; i < np; i++)
-		hc[i] = plan[i].c;
-	std::vector<lda_stream_res> hr(np);
-	if (!pin_phase((size_t)np * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
-		return false;
-	ST_TRY(up(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk)));
-	if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, raw_n))
-		return false;
-	ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
-	ST_TRY(pin_sync());
-
-	/* ---- chain ----
-	 * Every counted chunk is a pool entry keyed by its exact start state.  The
-	 * walk from chunk 0 follows end state -> start state; where an end state
-	 * has no chunk starting there (a block the finder does not look for, a
-	 * false candidate, a warm-up that did not fall in step) a REPAIR chunk is
-	 * counted from that state up to the next planned start.  Repairs are made
-	 * for every open end in the pool at once, one launch per round, so the
-	 * number of host round trips is the longest run of consecutive breaks, not
-	 * the number of breaks. */
 	std::vector<lda_stream_chunk> acc;	/* accepted chunks, exact starts */
 	std::vector<lda_stream_res> accr;
-	{
-		typedef std::pair<uint64_t, uint64_t> key_t;	/* (start_bit * 2 + boundary, header) */
-		std::map<key_t, uint32_t> by_start;
-		std::vector<lda_stream_chunk> pc(hc);
-		std::vector<lda_stream_res> pr(hr);
-		auto start_key = [&](uint32_t i) -> key_t {
-			if (pc[i].kind == LDA_CHUNK_HEADER)
-				return key_t(pc[i].hdr_bit * 2 + 1, pc[i].hdr_bit);
-			return key_t(pr[i].start_bit * 2, pc[i].hdr_bit);
-		};
-		auto end_key = [&](uint32_t i) -> key_t {
-			const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
-			return key_t(pr[i].end_bit * 2 + (bnd ? 1 : 0), bnd ? pr[i].end_bit : pr[i].end_hdr_bit);
-		};
-		for (uint32_t i = 0; i < np; i++)
-			if (pc[i].kind == LDA_CHUNK_HEADER || pr[i].status != LDA_STREAM_ERR)
-				by_start.emplace(start_key(i), i);
-		std::vector<uint64_t> ats(np);
-		for (uint32_t i = 0; i < np; i++)
-			ats[i] = plan[i].at;
-		std::vector<uint32_t> path;
-		uint32_t repairs = 0, first_open = 0;
-		const uint32_t max_repairs = 64 + 2 * np;
-		bool closed = false;
-		for (int round = 0; round < 16 && !closed; round++) {
-			path.clear();
-			uint32_t cur = 0;
-			for (;;) {
-				path.push_back(cur);
-				if (pr[cur].status == LDA_STREAM_ERR) {
-					S[1] = WHY_ERRCHUNK;
-					return false;
-				}
-				if (pr[cur].status == LDA_STREAM_FINAL) {
-					closed = true;
-					break;
-				}
-				if (pr[cur].end_bit >= raw_bits || path.size() > pc.size()) {
-					S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
-					return false;
-				}
-				auto it = by_start.find(end_key(cur));
-				if (it == by_start.end())
-					break;
-				cur = it->second;
-			}
-			if (closed)
-				break;
-			if (getenv("LDA_STREAM_DEBUG")) {
-				const uint32_t e = path.back();
-				const uint64_t eb = pr[e].end_bit;
-				auto nx = std::upper_bound(ats.begin(), ats.end(), eb);
-				size_t j = nx - ats.begin();
-				fprintf(stderr, "round %d: walk of %zu stops after chunk %u (kind %u hdr %llu start %llu) "
-					"end %llu bnd %u endhdr %llu status %u nout %llu\n", round, path.size(), e, pc[e].kind,
-					(unsigned long long)pc[e].hdr_bit, (unsigned long long)pr[e].start_bit,
-					(unsigned long long)eb, pr[e].flags & 1, (unsigned long long)pr[e].end_hdr_bit,
-					pr[e].status, (unsigned long long)pr[e].nout);
-				for (size_t k = j ? j - 1 : 0; k < j + 2 && k < np; k++)
-					fprintf(stderr, "   planned %zu: kind %u at %llu hdr %llu ws %llu -> start %llu end %llu status %u\n",
-						k, hc[k].kind, (unsigned long long)plan[k].at, (unsigned long long)hc[k].hdr_bit,
-						(unsigned long long)hc[k].start_bit, (unsigned long long)hr[k].start_bit,
-						(unsigned long long)hr[k].end_bit, hr[k].status);
-			}
-			/* repairs for every open end (entries added in earlier rounds
-			 * were looked at then: start at first_open) */
-			std::vector<lda_stream_chunk> rc;
-			const uint32_t npool = (uint32_t)pc.size();
-			std::map<key_t, int> asked;
-			for (uint32_t i = first_open; i < npool; i++) {
-				if (pr[i].status != LDA_STREAM_OK || pr[i].end_bit >= raw_bits)
-					continue;
-				const key_t k = end_key(i);
-				if (by_start.count(k) || asked.count(k))
-					continue;
-				asked[k] = 1;
-				const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
-				lda_stream_chunk c = {};
-				c.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
-				c.hdr_bit = bnd ? pr[i].end_bit : pr[i].end_hdr_bit;
-				c.start_bit = c.target_bit = pr[i].end_bit;
-				auto nx = std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit);
-				c.limit_bit = nx == ats.end() ? raw_bits : *nx;
-				rc.push_back(c);
-			}
-			/* the open end of the walk is always among them (round 0 looks at
-			 * all entries; later rounds at the new ones, and the walk can only
-			 * have stopped at a new one) */
-			first_open = npool;
-			repairs += (uint32_t)rc.size();
-			S[5] = repairs;
-			if (rc.empty() || repairs > max_repairs) {
-				S[1] = rc.empty() ? WHY_CHAIN : WHY_REPAIRS;
+	/* where the next window's first chunk starts */
+	lda_stream_chunk carry = {};
+	carry.kind = LDA_CHUNK_HEADER;
+	size_t copied = 0;	/* bytes of the caller's buffer on the device */
+	uint64_t dev_n = 0;	/* raw bytes the kernels may read (the last window's) */
+	bool final_seen = false;
+	for (size_t W = W0; !final_seen; W = W < ((size_t)1 << 40) ? W * 4 : W) {
+		/* ---- this window's input ---- */
+		const size_t upto = std::min<size_t>(in_nbytes, std::max(copied, hdr) + W);
+		if (upto > copied) {
+			if (span_in(&d->pinned, sin, in_at + copied, in + copied, upto - copied, s_copy) !=
+			    LIBDEFLATE_AMD_OK)
 				return false;
+			copied = upto;
+		}
+		const bool whole = copied == in_nbytes;
+		/* raw bytes the kernels may read; chunks of a partial window end a few
+		 * KiB in front of that (a round stages up to 3 KiB ahead, a header 704
+		 * bytes) */
+		const uint64_t win_n = whole ? raw_n : copied - hdr;
+		dev_n = win_n;
+		const uint64_t R1 = whole ? raw_bits : 8 * (win_n > 8192 ? win_n - 8192 : 0);
+		S[14]++;
+		if (R1 <= carry.start_bit + 4096 && !whole)
+			continue;
+		lap(8);
+		/* ---- block starts in [carry, R1) ---- */
+		ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
+		std::vector<uint64_t> cands;
+		const uint64_t fb0 = carry.start_bit & ~(uint64_t)7;
+		const uint64_t nbits = R1 > 80 ? R1 - 80 : 0;	/* a header needs its bits */
+		if (nbits > fb0) {
+			for (uint64_t b0 = fb0; b0 < nbits; b0 += 1ull << 31) {
+				const uint64_t nb = std::min<uint64_t>(nbits - b0, 1ull << 31);
+				/* (a workgroup of four waves takes 16 windows of 4 x 64 bytes) */
+				hipLaunchKernelGGL(lda_stream_find_a_kernel, dim3((unsigned)((nb + 32767) / 32768)),
+						   dim3(256), 0, s_comp, d_raw, win_n, b0, nbits, d_queue, d_cnt, qcap);
 			}
-			const uint32_t nr = (uint32_t)rc.size();
-			uint8_t *rp = (uint8_t *)d->srepair.reserve(
-				(size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 128);
-			if (!rp)
+			hipLaunchKernelGGL(lda_stream_find_b_kernel,
+					   dim3(std::min<unsigned>((qcap + 63) / 64, 8u * (unsigned)ctx->num_cus)),
+					   dim3(64), lda_stream_find_b_lds(),
+					   s_comp, d_raw, win_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
+			ST_TRY(hipGetLastError());
+			/* the counts and the first candidates in one round trip (a stream
+			 * of a few MiB has a few hundred) */
+			const uint32_t first = std::min<uint32_t>(ccap, 2048);
+			uint32_t cnt[2];
+			cands.resize(first);
+			if (!pin_phase(64 + (size_t)first * 8))
 				return false;
-			lda_stream_chunk *d_rc = (lda_stream_chunk *)rp;
-			lda_stream_res *d_rr = (lda_stream_res *)(rp + align_up((size_t)nr * sizeof(lda_stream_chunk), 64));
-			std::vector<lda_stream_res> rr(nr);
-			if (!pin_phase((size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
-				return false;
-			ST_TRY(up(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk)));
-			if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, raw_n))
-				return false;
-			ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
+			ST_TRY(back(cnt, d_cnt, 8));
+			ST_TRY(back(cands.data(), d_cand, (size_t)first * 8));
 			ST_TRY(pin_sync());
-			if (getenv("LDA_STREAM_DEBUG")) {
-				const auto now = std::chrono::steady_clock::now();
-				uint64_t span = 0, si = 0;
-				for (uint32_t i = 0; i < nr; i++)
-					if (rr[i].end_bit - rc[i].start_bit > span) {
-						span = rr[i].end_bit - rc[i].start_bit;
-						si = i;
-					}
-				fprintf(stderr, "   round %d: %u repairs, %lld us since the last lap; longest %llu bits "
-					"(kind %u start %llu limit %llu status %u nout %llu)\n", round, nr,
-					(long long)std::chrono::duration_cast<std::chrono::microseconds>(now - t_last).count(),
-					(unsigned long long)span, rc[si].kind, (unsigned long long)rc[si].start_bit,
-					(unsigned long long)rc[si].limit_bit, rr[si].status, (unsigned long long)rr[si].nout);
+			const uint32_t nc = std::min(cnt[1], ccap);
+			cands.resize(nc);
+			if (nc > first) {
+				if (!pin_phase((size_t)(nc - first) * 8))
+					return false;
+				ST_TRY(back(cands.data() + first, d_cand + first, (size_t)(nc - first) * 8));
+				ST_TRY(pin_sync());
 			}
-			for (uint32_t i = 0; i < nr; i++) {
-				pc.push_back(rc[i]);
-				pr.push_back(rr[i]);
-				by_start.emplace(start_key(npool + i), npool + i);
+			std::sort(cands.begin(), cands.end());
+			S[2] += cnt[0];
+			S[3] += nc;
+		}
+		lap(9);
+
+		/* ---- plan ----
+		 * chunks of a few KiB of input: up to about two thousand for a window
+		 * that has them (a wave slot each on 256 CUs, one launch of the decode
+		 * pass), never under 2 KiB (the warm-up in front of an inner chunk is
+		 * 1 KiB) */
+		uint64_t T = env.stream_chunk ? (uint64_t)env.stream_chunk :
+						(R1 - carry.start_bit) / 8 / 1536;
+		T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 2048), 65536);
+		const uint64_t OV = 8192, HDRSAFE = 4608;
+		std::vector<planned> plan;
+		/* a block (or, for the carried-in state, what is left of one): its
+		 * first chunk, then inner chunks up to `next` */
+		auto add_block = [&](const lda_stream_chunk &first, uint64_t next, bool dynamic) {
+			planned p = {};
+			p.c = first;
+			p.at = first.start_bit;
+			plan.push_back(p);
+			if (!dynamic)
+				return;
+			const uint64_t start = first.start_bit;
+			const uint64_t safe = first.kind == LDA_CHUNK_HEADER ? start + HDRSAFE : start;
+			for (uint64_t P = start + T; P + T / 2 <= next; P += T) {
+				uint64_t ws = P > OV ? P - OV : 0;
+				if (ws < safe)
+					ws = safe;
+				if (ws + OV / 4 > P)
+					continue;
+				planned q = {};
+				q.c.kind = LDA_CHUNK_WARM;
+				q.c.hdr_bit = first.hdr_bit;
+				q.c.start_bit = ws;
+				q.c.target_bit = P;
+				q.at = P;
+				plan.push_back(q);
+			}
+		};
+		{
+			/* block starts: the carried-in state, then the candidates behind
+			 * it.  A block's inner chunks end at the next candidate whatever
+			 * becomes of it; a small block close behind a chunk start gets no
+			 * chunk of its own (the chunk in front of it walks through), so
+			 * chunk starts are at least T / 8 apart however small the blocks
+			 * are */
+			std::vector<uint64_t> cs;
+			bool carry_dynamic = carry.kind != LDA_CHUNK_HEADER;	/* inside a Huffman block */
+			for (uint64_t c : cands) {
+				if (c == carry.start_bit && carry.kind == LDA_CHUNK_HEADER)
+					carry_dynamic = true;
+				else if (c > carry.start_bit)
+					cs.push_back(c);
+			}
+			uint64_t last_at = carry.start_bit;
+			add_block(carry, cs.empty() ? R1 : cs[0], carry_dynamic);
+			for (size_t i = 0; i < cs.size(); i++) {
+				const uint64_t next = i + 1 < cs.size() ? cs[i + 1] : R1;
+				if (cs[i] - last_at < T / 8 && next - cs[i] < T / 2)
+					continue;
+				lda_stream_chunk b = {};
+				b.kind = LDA_CHUNK_HEADER;
+				b.hdr_bit = b.start_bit = b.target_bit = cs[i];
+				add_block(b, next, true);
+				last_at = cs[i];
 			}
 		}
-		if (!closed) {
-			S[1] = WHY_CHAIN;
+		for (size_t i = 0; i < plan.size(); i++)
+			plan[i].c.limit_bit = i + 1 < plan.size() ? plan[i + 1].at : R1;
+		const uint32_t np = (uint32_t)plan.size();
+		S[4] += np;
+
+		/* ---- count ---- */
+		const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
+		uint8_t *sch = (uint8_t *)d->schunks.reserve(
+			res_at + align_up((size_t)np * sizeof(lda_stream_res) + 64, 64));
+		if (!sch)
+			return false;
+		lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
+		lda_stream_res *d_res = (lda_stream_res *)(sch + res_at);
+		std::vector<lda_stream_chunk> hc(np);
+		for (uint32_t i = 0; i < np; i++)
+			hc[i] = plan[i].c;
+		std::vector<lda_stream_res> hr(np);
+		if (!pin_phase((size_t)np * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
+			return false;
+		ST_TRY(up(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk)));
+		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n))
+			return false;
+		ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
+		ST_TRY(pin_sync());
+
+		/* ---- chain ----
+		 * Every counted chunk is a pool entry keyed by its exact start state.
+		 * The walk from the window's first chunk follows end state -> start
+		 * state; where an end state has no chunk starting there (a block the
+		 * finder does not look for, a false candidate, a warm-up that did not
+		 * fall in step) a REPAIR chunk is counted from that state up to the
+		 * next planned start.  Repairs are made for every open end in the pool
+		 * at once, one launch per round, so the number of host round trips is
+		 * the longest run of consecutive breaks, not the number of breaks. */
+		{
+			typedef std::pair<uint64_t, uint64_t> key_t;	/* (start_bit * 2 + boundary, header) */
+			std::map<key_t, uint32_t> by_start;
+			std::vector<lda_stream_chunk> pc(hc);
+			std::vector<lda_stream_res> pr(hr);
+			auto start_key = [&](uint32_t i) -> key_t {
+				if (pc[i].kind == LDA_CHUNK_HEADER)
+					return key_t(pc[i].hdr_bit * 2 + 1, pc[i].hdr_bit);
+				return key_t(pr[i].start_bit * 2, pc[i].hdr_bit);
+			};
+			auto end_key = [&](uint32_t i) -> key_t {
+				const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
+				return key_t(pr[i].end_bit * 2 + (bnd ? 1 : 0), bnd ? pr[i].end_bit : pr[i].end_hdr_bit);
+			};
+			for (uint32_t i = 0; i < np; i++)
+				if (pc[i].kind == LDA_CHUNK_HEADER || pr[i].status != LDA_STREAM_ERR)
+					by_start.emplace(start_key(i), i);
+			std::vector<uint64_t> ats(np);
+			for (uint32_t i = 0; i < np; i++)
+				ats[i] = plan[i].at;
+			std::vector<uint32_t> path;
+			uint32_t repairs = 0, first_open = 0;
+			const uint32_t max_repairs = 64 + 2 * np;
+			bool closed = false;	/* the walk ended: final block, or the window's end */
+			for (int round = 0; round < 16 && !closed; round++) {
+				path.clear();
+				uint32_t cur = 0;
+				for (;;) {
+					if (pr[cur].status == LDA_STREAM_ERR) {
+						if (whole) {
+							S[1] = WHY_ERRCHUNK;
+							return false;
+						}
+						closed = true;	/* (it may only have run out of window) */
+						break;
+					}
+					path.push_back(cur);
+					if (pr[cur].status == LDA_STREAM_FINAL) {
+						closed = final_seen = true;
+						break;
+					}
+					if (pr[cur].end_bit >= R1 || path.size() > pc.size()) {
+						if (whole) {
+							S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
+							return false;
+						}
+						closed = true;
+						break;
+					}
+					auto it = by_start.find(end_key(cur));
+					if (it == by_start.end())
+						break;
+					cur = it->second;
+				}
+				if (closed)
+					break;
+				if (getenv("LDA_STREAM_DEBUG")) {
+					const uint32_t e = path.back();
+					fprintf(stderr, "round %d: walk of %zu stops after chunk %u (kind %u hdr %llu start %llu) "
+						"end %llu bnd %u endhdr %llu status %u nout %llu\n", round, path.size(), e,
+						pc[e].kind, (unsigned long long)pc[e].hdr_bit,
+						(unsigned long long)pr[e].start_bit, (unsigned long long)pr[e].end_bit,
+						pr[e].flags & 1, (unsigned long long)pr[e].end_hdr_bit, pr[e].status,
+						(unsigned long long)pr[e].nout);
+				}
+				/* repairs for every open end (entries added in earlier rounds
+				 * were looked at then: start at first_open) */
+				std::vector<lda_stream_chunk> rc;
+				const uint32_t npool = (uint32_t)pc.size();
+				std::map<key_t, int> asked;
+				for (uint32_t i = first_open; i < npool; i++) {
+					if (pr[i].status != LDA_STREAM_OK || pr[i].end_bit >= R1)
+						continue;
+					const key_t k = end_key(i);
+					if (by_start.count(k) || asked.count(k))
+						continue;
+					asked[k] = 1;
+					const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
+					lda_stream_chunk c = {};
+					c.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
+					c.hdr_bit = bnd ? pr[i].end_bit : pr[i].end_hdr_bit;
+					c.start_bit = c.target_bit = pr[i].end_bit;
+					auto nx = std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit);
+					c.limit_bit = nx == ats.end() ? R1 : *nx;
+					rc.push_back(c);
+				}
+				/* the open end of the walk is always among them (round 0 looks at
+				 * all entries; later rounds at the new ones, and the walk can only
+				 * have stopped at a new one) */
+				first_open = npool;
+				repairs += (uint32_t)rc.size();
+				S[5] += (uint32_t)rc.size();
+				if (rc.empty() || repairs > max_repairs) {
+					S[1] = rc.empty() ? WHY_CHAIN : WHY_REPAIRS;
+					return false;
+				}
+				const uint32_t nr = (uint32_t)rc.size();
+				uint8_t *rp = (uint8_t *)d->srepair.reserve(
+					(size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 128);
+				if (!rp)
+					return false;
+				lda_stream_chunk *d_rc = (lda_stream_chunk *)rp;
+				lda_stream_res *d_rr = (lda_stream_res *)(rp + align_up((size_t)nr * sizeof(lda_stream_chunk), 64));
+				std::vector<lda_stream_res> rr(nr);
+				if (!pin_phase((size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
+					return false;
+				ST_TRY(up(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk)));
+				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n))
+					return false;
+				ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
+				ST_TRY(pin_sync());
+				for (uint32_t i = 0; i < nr; i++) {
+					pc.push_back(rc[i]);
+					pr.push_back(rr[i]);
+					by_start.emplace(start_key(npool + i), npool + i);
+				}
+			}
+			if (!closed) {
+				S[1] = WHY_CHAIN;
+				return false;
+			}
+			for (uint32_t i : path) {
+				lda_stream_chunk c = pc[i];
+				if (c.kind == LDA_CHUNK_WARM) {
+					c.kind = LDA_CHUNK_EXACT;
+					c.start_bit = pr[i].start_bit;
+				}
+				acc.push_back(c);
+				accr.push_back(pr[i]);
+			}
+			if (!path.empty() && !final_seen) {
+				/* the next window goes on from where this one's chain ends */
+				const lda_stream_res &e = pr[path.back()];
+				const bool bnd = e.flags & LDA_RES_BOUNDARY;
+				carry = lda_stream_chunk();
+				carry.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
+				carry.hdr_bit = bnd ? e.end_bit : e.end_hdr_bit;
+				carry.start_bit = carry.target_bit = e.end_bit;
+			}
+		}
+		lap(10);
+		if (whole && !final_seen) {
+			S[1] = WHY_NOFINAL;
 			return false;
 		}
-		for (uint32_t i : path) {
-			lda_stream_chunk c = pc[i];
-			if (c.kind == LDA_CHUNK_WARM) {
-				c.kind = LDA_CHUNK_EXACT;
-				c.start_bit = pr[i].start_bit;
-			}
-			acc.push_back(c);
-			accr.push_back(pr[i]);
-		}
 	}
-	lap(10);
 	const uint32_t na = (uint32_t)acc.size();
 	S[6] = na;
 	std::vector<uint64_t> offs(na + 1);
@@ -502,11 +554,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		/* (the accepted chain may hold more chunks than were planned) */
 		const size_t res2_at = align_up((size_t)na * sizeof(lda_stream_chunk) + 64, 64);
 		const size_t off2_at = res2_at + align_up((size_t)na * sizeof(lda_stream_res) + 64, 64);
-		sch = (uint8_t *)d->schunks.reserve(off2_at + ((size_t)na + 2) * 8 + 64);
+		uint8_t *sch = (uint8_t *)d->schunks.reserve(off2_at + ((size_t)na + 2) * 8 + 64);
 		if (!sch)
 			return false;
-		d_chunks = (lda_stream_chunk *)sch;
-		d_res = (lda_stream_res *)(sch + res2_at);
+		lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
+		lda_stream_res *d_res = (lda_stream_res *)(sch + res2_at);
 		uint64_t *d_off = (uint64_t *)(sch + off2_at);
 		if (!pin_phase((size_t)na * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res) + 8) + 512))
 			return false;
@@ -516,7 +568,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
 			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
 					   lda_stream_chunk_lds(), s_comp, nk, d_chunks + lo,
-					   d_res + lo, d_raw, raw_n, d_sym, d_tok);
+					   d_res + lo, d_raw, dev_n, d_sym, d_tok);
 		}
 		{
 			/* the window chain as a two-level scan over groups of chunks:

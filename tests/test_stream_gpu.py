@@ -197,3 +197,49 @@ def test_switch_off(dec, comp, monkeypatch):
     binding.reload_env()
     assert dec.decompress_ex("gzip", z, len(data)) == (0, len(z), len(data), data)
     assert binding.stream_stats()["parallel"] == 0
+
+
+def test_input_windows(dec, comp, oracle, monkeypatch):
+    """The input is taken in windows (4 MiB, then 4x as much each time): a
+    stream longer than the first window carries its state - inside a block or
+    at a block boundary - into the next one; a stream that ends inside the
+    first window leaves the rest of the buffer alone.  Small windows here, so
+    that a few MiB cross many of them."""
+    data = _data("mix", 3 << 20, 0x53000)
+    for win in ("32768", "65536", "262144"):
+        monkeypatch.setenv("LDA_STREAM_WINDOW", win)
+        monkeypatch.setenv("LDA_STREAM_PAR_MIN", "0")
+        binding.reload_env()
+        for fmt, lvl in (("gzip", 6), ("deflate", 1), ("zlib", 12), ("deflate", 0)):
+            z = comp(fmt, lvl, data)
+            r = dec.decompress_ex(fmt, z, len(data))
+            st = binding.stream_stats()
+            assert r == (0, len(z), len(data), data), (win, fmt, lvl, r[:3], st)
+            assert st["parallel"] == 1, (win, fmt, lvl, st)
+        # static-only stream: no candidates anywhere, window after window
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+        txt = data[:500000]
+        z = co.compress(txt) + co.flush()
+        assert dec.decompress_ex("deflate", z, len(txt)) == (0, len(z), len(txt), txt)
+        # truncated: the final block is never seen -> the oracle's verdict
+        z = comp("gzip", 6, data)
+        for cut in (len(z) // 2, len(z) - 9):
+            got = dec.decompress_ex("gzip", z[:cut], len(data))
+            assert got[0] == oracle.decompress_ex("gzip", z[:cut], len(data))[0]
+
+
+def test_members_one_after_the_other(dec, comp):
+    """programs/gzip.c:236-299: the caller hands the rest of the file to every
+    call; a member that ends inside the first window must not make the library
+    copy and search everything behind it (here: 40 members of 1 MiB each, every
+    call sees what is left of the 13 MB file)."""
+    members = [datagen.text_chunk(1 << 20, 0x54000 + i) for i in range(40)]
+    z = b"".join(comp("gzip", 6, m) for m in members)
+    t0 = time.perf_counter()
+    r = dec.gzip_decompress_members(z, 40 << 20)
+    dt = time.perf_counter() - t0
+    assert r[0] == 0 and r[1] == len(z) and r[3] == 40
+    assert r[4] == b"".join(members)
+    print(f"40 gzip members of 1 MiB, member after member: {dt * 1e3:.1f} ms "
+          f"({(40 << 20) / dt / 1e9:.2f} GB/s)")
+    assert dt < 2.0
