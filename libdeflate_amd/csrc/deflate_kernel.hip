@@ -832,6 +832,7 @@ template <int N> struct huff_scratch {
 	u32 cnt[40];	/* leaves per depth (code lengths) */
 	u32 start[16];	/* first index in sorted[] for each length */
 	u32 nc[16];	/* next canonical codeword per length */
+	u16 S[2 * N];	/* merge rounds: the items of a round in merged order */
 };
 
 template <int N> static __device__ void
@@ -885,14 +886,107 @@ make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
 			H->cntI[lane] = 0;
 		wave_sync();
 		if (N == 288) PROF_MARK(13);
-		if (lane == 0) {
-			/* two-queue merge: leaves A[] (ascending), nodes NW[] in
-			 * creation order (ascending too); heads cached in registers
-			 * (a variant that also prefetched the following entries had
-			 * more instructions on this single-lane path and was slower) */
-			u32 leaf = 0, node = 0;
-			u32 wl = H->A[0], wn = 0xFFFFFFFFu;
-			for (u32 k = 0; k + 1 < m; k++) {
+		/* The two-queue merge (leaves A[] ascending, nodes NW[] in creation
+		 * order, ascending too) in ROUNDS by the whole wave.  The next node
+		 * to be created weighs T = the sum of the two smallest items; every
+		 * node created from now on weighs at least T, and every node that
+		 * exists weighs at most T (the sums never decrease), so all items of
+		 * at most T - the leaves up to T and all queued nodes - are consumed
+		 * before any new node is, in merged order, two by two: that is one
+		 * round.  An odd item out waits for the next round (where it is one of
+		 * the two smallest).  The serial loop below does the same merges one
+		 * at a time: 375 cycles each on one lane, 45 K cycles for a block's
+		 * litlen tree; a round is ~250 wave instructions and a block takes
+		 * 9-15 of them.  Weights that grow like Fibonacci numbers give one
+		 * merge per round: after MERGE_ROUNDS rounds the serial loop takes
+		 * over from where the rounds are. */
+		u32 leaf = 0, node = 0, made = 0;	/* consumed leaves / nodes, created nodes */
+#ifndef MERGE_ROUNDS
+#define MERGE_ROUNDS 40u
+#endif
+		if (m >= 24) {
+			const u32 INF = 0x7FFFFFFFu;
+			for (u32 round = 0; round < MERGE_ROUNDS && made + 1 < m; round++) {
+				const u32 wl0 = leaf < m ? H->A[leaf] : INF;
+				const u32 wl1 = leaf + 1 < m ? H->A[leaf + 1] : INF;
+				const u32 wn0 = node < made ? H->NW[node] : INF;
+				const u32 wn1 = node + 1 < made ? H->NW[node + 1] : INF;
+				u32 T = wl0 + wl1;	/* (INF + INF does not wrap) */
+				T = wl0 + wn0 < T ? wl0 + wn0 : T;
+				T = wn0 + wn1 < T ? wn0 + wn1 : T;
+				/* leaves of at most T: a prefix of what is left */
+				u32 cl = 0;
+				for (u32 b0 = leaf; b0 < m; b0 += 64) {
+					const u32 i = b0 + lane;
+					const u32 c = (u32)__builtin_popcountll(__ballot(i < m && H->A[i] <= T));
+					cl += c;
+					if (c < 64)
+						break;
+				}
+				u32 cn = made - node;
+				if ((cl + cn) & 1) {
+					/* the last item of the merged order stays (a node
+					 * follows a leaf of the same weight) */
+					if (cn && (cl == 0 || H->NW[node + cn - 1] >= H->A[leaf + cl - 1]))
+						cn--;
+					else
+						cl--;
+				}
+				const u32 tot = cl + cn;
+				for (u32 k = lane; k < tot; k += 64)
+					H->S[k] = 0xFFFF;
+				wave_sync();
+				/* a leaf's place: its index + the nodes that weigh less (the
+				 * first 64 queued nodes sit in a register, one per lane, and
+				 * are read lane by lane: no LDS round trip per node) */
+				const u32 wnode = lane < cn ? H->NW[node + lane] : 0;
+				const u32 cn64 = cn < 64 ? cn : 64;
+				for (u32 i0 = 0; i0 < cl; i0 += 64) {
+					const u32 i = i0 + lane;
+					const u32 wv = i < cl ? H->A[leaf + i] : 0;
+					u32 r = i;
+					for (u32 j = 0; j < cn64; j++)
+						r += bcast_lane(wnode, j) < wv;
+					for (u32 j = 64; j < cn; j++)
+						r += H->NW[node + j] < wv;
+					if (i < cl)
+						H->S[r] = (u16)i;
+				}
+				wave_sync();
+				/* the nodes take the places left, in order */
+				u32 nfree = 0;
+				for (u32 k0 = 0; k0 < tot; k0 += 64) {
+					const u32 k = k0 + lane;
+					const bool fr = k < tot && H->S[k] == 0xFFFF;
+					const u64 mk = __ballot(fr);
+					if (fr)
+						H->S[k] = (u16)(0x8000u | (nfree + rank_below(mk)));
+					nfree += (u32)__builtin_popcountll(mk);
+				}
+				wave_sync();
+				for (u32 q = lane; q < tot / 2; q += 64) {
+					const u32 a = H->S[2 * q], b = H->S[2 * q + 1];
+					const u32 wa = a & 0x8000 ? H->NW[node + (a & 0x7FFF)] : H->A[leaf + a];
+					const u32 wb = b & 0x8000 ? H->NW[node + (b & 0x7FFF)] : H->A[leaf + b];
+					if (a & 0x8000)
+						H->P[node + (a & 0x7FFF)] = made + q;
+					if (b & 0x8000)
+						H->P[node + (b & 0x7FFF)] = made + q;
+					H->NW[made + q] = wa + wb;
+				}
+				wave_sync();
+				leaf += cl;
+				node += cn;
+				made += tot / 2;
+			}
+		}
+		if (lane == 0 && made + 1 < m) {
+			/* one merge at a time; heads cached in registers (a variant that
+			 * also prefetched the following entries had more instructions on
+			 * this single-lane path and was slower) */
+			u32 wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
+			u32 wn = node < made ? H->NW[node] : 0xFFFFFFFFu;
+			for (u32 k = made; k + 1 < m; k++) {
 				u32 w;
 				if (leaf < m && wl <= wn) {
 					w = wl;

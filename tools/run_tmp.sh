@@ -1,8 +1,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-python -m pytest tests/test_stream_gpu.py -x -q -s 2>&1 | tail -12 > gpurun_out/r04_w1.log
-python tools/bench_stream.py 1 16 64 2>&1 | grep -v amdgpu >> gpurun_out/r04_w1.log
-timeout 300 python tools/fuzz_stream.py $(seq 500 512) 2>&1 | tail -2 >> gpurun_out/r04_w1.log
-LDA_STREAM_WINDOW=65536 timeout 300 python tools/fuzz_stream.py $(seq 600 612) 2>&1 | tail -2 >> gpurun_out/r04_w1.log
-cat gpurun_out/r04_w1.log
+python tools/digest_deflate.py --quick > gpurun_out/dig_new2.txt 2>&1
+diff <(grep -v big gpurun_out/dig_new.txt) <(grep -v big gpurun_out/dig_new2.txt) > gpurun_out/r04_huff2.log && echo "digests identical to the first parallel build (except big)" >> gpurun_out/r04_huff2.log
+python tools/microbench.py deflate --chunks 4096 --level 6 2>&1 | grep "deflate\[" >> gpurun_out/r04_huff2.log
+python tools/microbench.py deflate --size 4096 --chunks 262144 --level 9 --fmt zlib 2>&1 | grep "deflate\[" >> gpurun_out/r04_huff2.log
+LIBDEFLATE_AMD_LIB=$R/libdeflate_amd/libdeflate_amd_prof.so python tools/microbench.py deflate --chunks 4096 --level 6 2>&1 | grep -E "two trees|mc:|deflate\[" | tail -6 >> gpurun_out/r04_huff2.log
+cat gpurun_out/r04_huff2.log
