@@ -653,6 +653,7 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	u64 start_exact = cd->start_bit;
 	u32 final_blk = 0, status = LDA_STREAM_OK, bad = 0, at_boundary = 0;
 	bool in_block = false, first = cd->kind == LDA_CHUNK_HEADER;	/* its own header is not a stop */
+	bool after_stored = false;	/* the block before pos was a stored one */
 	u64 ring_lo = out;
 
 	if (kind != LDA_CHUNK_HEADER) {
@@ -683,10 +684,25 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	while (status == LDA_STREAM_OK) {
 		if (!in_block) {
 			if (pos >= limit && !first) {
-				at_boundary = 1;
-				break;
+				/* A run of stored blocks is walked to its end whatever the
+				 * limit says (for 256 Mbit at most): nothing in it can be a
+				 * chunk start - the finder does not look for stored blocks,
+				 * and what it finds INSIDE one (incompressible bytes: a
+				 * header-like pattern every few KiB) is false - so a chunk that
+				 * stopped in the middle of the run would only hand over to a
+				 * repair chunk per block. */
+				bool on = false;
+				if (after_stored && pos - limit < (1ull << 28) && (pos >> 3) + 1 < in_n) {
+					const u32 w = inp[pos >> 3] | ((u32)inp[(pos >> 3) + 1] << 8);
+					on = ((w >> ((u32)pos & 7)) & 6) == 0;	/* BTYPE 00 */
+				}
+				if (!on) {
+					at_boundary = 1;
+					break;
+				}
 			}
 			first = false;
+			after_stored = false;
 			u64 p2;
 			hdr = pos;
 			const u32 r = chunk_header(inp, in_n, S, stage, lane, pos, &final_blk, &p2);
@@ -715,6 +731,7 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 				out += len;
 				ring_lo = out;
 				pos = 8 * (bp + 4 + len);
+				after_stored = true;
 				if (final_blk) {
 					status = LDA_STREAM_FINAL;
 					break;
@@ -932,6 +949,12 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 	const u32 npre = 4 + ((h >> 13) & 15);
 	u64 f = (x0 >> 17) | (x1 << 47);
 	f &= (1ull << (3 * npre)) - 1;
+	/* the compressors send no trailing zero lengths (HCLEN, HLIT and HDIST are
+	 * the smallest that do: lib/deflate_compress.c:1575-1586, :1618-1624;
+	 * zlib's max_code); a header that does is, among incompressible bytes,
+	 * nearly always a false one */
+	if (npre > 4 && ((f >> (3 * (npre - 1))) & 7) == 0)
+		return;
 	/* The precode's decode table, from registers only (field i of f is the
 	 * length of symbol c_pre_perm[i]; the first stage has checked that the
 	 * code is complete): lengths counted in 5-bit fields, first codewords per
@@ -967,7 +990,7 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 	u64 bp = p + 17 + 3 * npre;	/* next bit to read */
 	u64 buf = 0;
 	u32 cnt = 0;
-	u32 i = 0, prev = 0, kl = 0, ko = 0, n_o = 0, eob_len = 0;
+	u32 i = 0, prev = 0, kl = 0, ko = 0, n_o = 0, eob_len = 0, last_lit = 0, last_off = 0;
 	const u32 total = nlit + noff;
 	bool ok = true;
 	/* the lane's next 72 bytes of input sit in its LDS row (nine loads in
@@ -1029,6 +1052,10 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 			n_o += rep - n1;
 			if (i <= 256 && 256 < i + n1)
 				eob_len = val;
+			if (i + n1 == nlit && n1)
+				last_lit = val;
+			if (i + rep == total && rep > n1)
+				last_off = val;
 			/* an over-subscribed code cannot recover: most false survivors
 			 * of the first stage end here within a dozen lengths */
 			if (kl > 32768 || ko > 32768) {
@@ -1043,6 +1070,8 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
 		return;
 	if (kl != 32768 || eob_len == 0)
 		return;
+	if ((nlit > 257 && last_lit == 0) || (noff > 1 && last_off == 0))
+		return;		/* trailing zero lengths: see above */
 	if (!(ko == 32768 || (ko == 16384 && n_o == 1) || ko == 0))
 		return;
 	const u32 at = atomicAdd(ncand, 1u);

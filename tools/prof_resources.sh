@@ -3,7 +3,7 @@
 # occupancy) -> stdout; no GPU needed.  profiles/rNN_kernel_resources.txt is
 # this script's output for the round's final build.
 cd "$(dirname "$0")/../libdeflate_amd/csrc"
-for f in deflate_kernel deflate_small inflate_kernel checksum_kernels compact_kernels; do
+for f in deflate_kernel deflate_small inflate_kernel inflate_stream checksum_kernels compact_kernels; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden \
       -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c $f.hip -o /dev/null 2>&1 |
     grep -E "Function Name|VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|SGPRs:" |
