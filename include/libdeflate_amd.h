@@ -355,7 +355,8 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
  * repairs); [2] bit offsets that passed the first filter of the block finder;
  * [3] block starts found; [4] chunks planned; [5] repairs; [6] chunks decoded;
  * [7] bytes produced; [8..13] host-side microseconds of: copy in, block finder,
- * count pass + chain, decode + window + resolve, checksum, copy out.
+ * count pass + chain, queueing the decode / window / resolve / checksum kernels,
+ * footer check, output copy (which waits for those kernels); [14] input windows.
  */
 #define LIBDEFLATE_AMD_STREAM_STATS 16
 LIBDEFLATEAPI void

@@ -108,6 +108,7 @@ struct PinnedBuf {
  */
 struct StreamPair {
 	hipStream_t copy = nullptr, comp = nullptr;
+	hipEvent_t mark = nullptr;	/* a point on `comp` that `copy` may wait for */
 	bool ensure();
 	void release();
 };
@@ -140,6 +141,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 /* checksum of A || B from the checksums of A and B and the length of B
  * (host_compress.hip) */
 uint32_t crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+/* the same with x^(8 len_b) mod P computed once for many pieces of one length */
+uint32_t crc32_shift(uint64_t len);
+uint32_t crc32_concat_shift(uint32_t crc_a, uint32_t crc_b, uint32_t shift_b);
 uint32_t adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b);
 
 } /* namespace lda */

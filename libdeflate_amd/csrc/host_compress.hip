@@ -398,16 +398,27 @@ static uint32_t crc_mulmod(uint32_t a, uint32_t b)
 	return p;
 }
 
-uint32_t lda::crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+/* x^(8 len) mod P: what appending len bytes multiplies a CRC by */
+uint32_t lda::crc32_shift(uint64_t len)
 {
 	uint32_t xp = 0x80000000u;	/* 1 */
 	uint32_t base = 0x00800000u;	/* x^8 */
-	for (uint64_t k = len_b; k; k >>= 1) {
+	for (uint64_t k = len; k; k >>= 1) {
 		if (k & 1)
 			xp = crc_mulmod(xp, base);
 		base = crc_mulmod(base, base);
 	}
-	return crc_mulmod(crc_a, xp) ^ crc_b;
+	return xp;
+}
+
+uint32_t lda::crc32_concat_shift(uint32_t crc_a, uint32_t crc_b, uint32_t shift_b)
+{
+	return crc_mulmod(crc_a, shift_b) ^ crc_b;
+}
+
+uint32_t lda::crc32_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+{
+	return crc32_concat_shift(crc_a, crc_b, crc32_shift(len_b));
 }
 
 uint32_t lda::adler32_concat(uint32_t ad_a, uint32_t ad_b, uint64_t len_b)
@@ -603,8 +614,11 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	if (format == LIBDEFLATE_AMD_GZIP) {
 		/* lib/gzip_compress.c:44-79 */
 		uint32_t crc = 0;
+		const uint32_t shS = crc32_shift(S);	/* every piece but the last is S bytes */
 		for (size_t i = 0; i < nseg; i++)
-			crc = i ? crc32_concat(crc, h_sums[i], pc_n[i]) : h_sums[0];
+			crc = !i ? h_sums[0] :
+			      pc_n[i] == S ? crc32_concat_shift(crc, h_sums[i], shS) :
+					     crc32_concat(crc, h_sums[i], pc_n[i]);
 		const uint8_t xfl = c->level < 2 ? 4 : c->level >= 8 ? 2 : 0;
 		const uint8_t h[10] = { 0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 0xFF };
 		memcpy(out, h, 10);

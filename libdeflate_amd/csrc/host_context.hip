@@ -149,10 +149,11 @@ void PinnedBuf::release()
 
 bool StreamPair::ensure()
 {
-	if (copy && comp)
+	if (copy && comp && mark)
 		return true;
 	if ((!copy && hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) ||
-	    (!comp && hipStreamCreateWithFlags(&comp, hipStreamNonBlocking) != hipSuccess)) {
+	    (!comp && hipStreamCreateWithFlags(&comp, hipStreamNonBlocking) != hipSuccess) ||
+	    (!mark && hipEventCreateWithFlags(&mark, hipEventDisableTiming) != hipSuccess)) {
 		set_error("hipStreamCreate: %s", hipGetErrorString(hipGetLastError()));
 		return false;
 	}
@@ -165,7 +166,10 @@ void StreamPair::release()
 		(void)hipStreamDestroy(copy);
 	if (comp)
 		(void)hipStreamDestroy(comp);
+	if (mark)
+		(void)hipEventDestroy(mark);
 	copy = comp = nullptr;
+	mark = nullptr;
 }
 
 size_t slice_by_bytes(size_t n, const size_t *nbytes, size_t max_slices,

@@ -114,6 +114,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->stage.release();
 	d->tokens.release();
 	d->sin.release();
+	d->squeue.release();
 	d->schunks.release();
 	d->srepair.release();
 	d->swin.release();

@@ -193,19 +193,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	const size_t W0 = env.stream_window ? env.stream_window :
 			  std::min<size_t>(std::max<size_t>(out_avail / 2, (size_t)4 << 20), (size_t)16 << 20);
 	const size_t in_at = 64;
-	/* [input][finder queue][candidates][counters]: sized for the whole input
-	 * (grow-only; a window never needs more than that) */
-	const uint64_t all_bits = raw_bits;
-	const uint32_t qcap = (uint32_t)std::min<uint64_t>(all_bits / 128 + 4096, 1u << 28);
-	const uint32_t ccap = (uint32_t)std::min<uint64_t>(all_bits / 512 + 4096, 1u << 26);
-	const size_t q_at = align_up(in_at + in_nbytes + 64, 64);
-	const size_t c_at = q_at + (size_t)qcap * 8, cnt_at = c_at + (size_t)ccap * 8;
-	uint8_t *sin = (uint8_t *)d->sin.reserve(cnt_at + 64);
-	if (!sin)
-		return false;
-	uint8_t *d_raw = sin + in_at + hdr;
-	uint64_t *d_queue = (uint64_t *)(sin + q_at), *d_cand = (uint64_t *)(sin + c_at);
-	uint32_t *d_cnt = (uint32_t *)(sin + cnt_at);	/* [0] queue, [1] candidates, [2] error flag */
+	/* device memory follows the windows, not the caller's buffer: the input
+	 * copy grows with them (a regrown buffer is filled again from the start:
+	 * a quarter more bytes copied at worst), the finder's queues are sized by
+	 * the window searched */
+	uint8_t *sin = nullptr, *d_raw = nullptr;
+	uint64_t *d_queue = nullptr, *d_cand = nullptr;
+	uint32_t *d_cnt = nullptr;	/* [0] queue, [1] candidates, [2] error flag */
+	uint32_t qcap = 0, ccap = 0;
 
 	std::vector<lda_stream_chunk> acc;	/* accepted chunks, exact starts */
 	std::vector<lda_stream_res> accr;
@@ -218,6 +213,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	for (size_t W = W0; !final_seen; W = W < ((size_t)1 << 40) ? W * 4 : W) {
 		/* ---- this window's input ---- */
 		const size_t upto = std::min<size_t>(in_nbytes, std::max(copied, hdr) + W);
+		if (!sin || in_at + upto + 64 > d->sin.cap) {
+			sin = (uint8_t *)d->sin.reserve(in_at + std::min<size_t>(in_nbytes, 2 * upto) + 64);
+			if (!sin)
+				return false;
+			d_raw = sin + in_at + hdr;
+			copied = 0;
+		}
 		if (upto > copied) {
 			if (span_in(&d->pinned, sin, in_at + copied, in + copied, upto - copied, s_copy) !=
 			    LIBDEFLATE_AMD_OK)
@@ -236,10 +238,24 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			continue;
 		lap(8);
 		/* ---- block starts in [carry, R1) ---- */
-		ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
 		std::vector<uint64_t> cands;
 		const uint64_t fb0 = carry.start_bit & ~(uint64_t)7;
 		const uint64_t nbits = R1 > 80 ? R1 - 80 : 0;	/* a header needs its bits */
+		{
+			/* about one offset in 500 passes the first filter on compressed
+			 * data and a real block is rarely under a few hundred bits; a
+			 * queue that overflows only loses entry points */
+			const uint64_t span = nbits > fb0 ? nbits - fb0 : 0;
+			qcap = (uint32_t)std::min<uint64_t>(span / 128 + 4096, 1u << 28);
+			ccap = (uint32_t)std::min<uint64_t>(span / 512 + 4096, 1u << 26);
+			uint8_t *sq = (uint8_t *)d->squeue.reserve(((size_t)qcap + ccap) * 8 + 128);
+			if (!sq)
+				return false;
+			d_queue = (uint64_t *)sq;
+			d_cand = d_queue + qcap;
+			d_cnt = (uint32_t *)(d_cand + ccap);
+		}
+		ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
 		if (nbits > fb0) {
 			for (uint64_t b0 = fb0; b0 < nbits; b0 += 1ull << 31) {
 				const uint64_t nb = std::min<uint64_t>(nbits - b0, 1ull << 31);
@@ -540,13 +556,21 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		return false;
 	}
 
-	/* ---- decode -> window -> resolve ---- */
-	uint8_t *d_out = NULL;
+	/* ---- decode -> window -> resolve -> checksum, one round trip ----
+	 * Everything is queued on the compute stream; what comes back (the decode
+	 * pass's per-chunk results, the error flag, the pieces' checksums) is
+	 * looked at after ONE synchronisation, and the output is on its way to the
+	 * caller meanwhile: the copy stream waits for the resolve pass, not for the
+	 * host.  (Output is undefined on failure, libdeflate.h:216-217; when the
+	 * sequential kernel has to decide it writes the buffer again.) */
+	const size_t consumed = (size_t)((end_bit + 7) / 8);
+	int32_t result = LIBDEFLATE_SUCCESS;
+	uint32_t sum = format == LIBDEFLATE_AMD_GZIP ? 0u : 1u;
 	if (total) {
 		S[1] = WHY_DEVICE;
 		const size_t BATCH = 2048;	/* decode waves per launch (their token scratch) */
 		uint16_t *d_sym = (uint16_t *)d->ssym.reserve((size_t)total * 2 + 64);
-		d_out = (uint8_t *)d->sout.reserve((size_t)total + 64);
+		uint8_t *d_out = (uint8_t *)d->sout.reserve((size_t)total + 64);
 		uint32_t *d_tok = (uint32_t *)d->tokens.reserve(
 			std::min<size_t>(na, BATCH) * lda_stream_tokcap() * 4 + 64);
 		if (!d_sym || !d_out || !d_tok)
@@ -560,10 +584,26 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		lda_stream_chunk *d_chunks = (lda_stream_chunk *)sch;
 		lda_stream_res *d_res = (lda_stream_res *)(sch + res2_at);
 		uint64_t *d_off = (uint64_t *)(sch + off2_at);
-		if (!pin_phase((size_t)na * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res) + 8) + 512))
+		/* pieces of the output for the checksum kernels */
+		const uint64_t piece = std::max<uint64_t>(65536, align_up(total / 4096, 4096));
+		const size_t npc = ftr ? (size_t)((total + piece - 1) / piece) : 0;
+		std::vector<uint64_t> po(2 * npc);
+		for (size_t i = 0; i < npc; i++) {
+			po[i] = i * piece;
+			po[npc + i] = std::min<uint64_t>(piece, total - i * piece);
+		}
+		uint8_t *scr = npc ? (uint8_t *)d->scratch.reserve(npc * 20 + 64) : nullptr;
+		if (npc && !scr)
+			return false;
+		uint64_t *d_po = (uint64_t *)scr;
+		uint32_t *d_sums = (uint32_t *)(scr + npc * 16);
+		if (!pin_phase((size_t)na * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res) + 8) +
+			       npc * 20 + 1024))
 			return false;
 		ST_TRY(up(d_chunks, acc.data(), (size_t)na * sizeof(lda_stream_chunk)));
 		ST_TRY(up(d_off, offs.data(), ((size_t)na + 1) * 8));
+		if (npc)
+			ST_TRY(up(d_po, po.data(), npc * 16));
 		for (size_t lo = 0; lo < na; lo += BATCH) {
 			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
 			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
@@ -609,10 +649,27 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			}
 		}
 		ST_TRY(hipGetLastError());
+		ST_TRY(hipEventRecord(d->streams.mark, s_comp));	/* the bytes are final */
+		if (npc) {
+			const int rc = format == LIBDEFLATE_AMD_GZIP ?
+				libdeflate_amd_crc32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp) :
+				libdeflate_amd_adler32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp);
+			if (rc != LIBDEFLATE_AMD_OK)
+				return false;
+		}
 		std::vector<lda_stream_res> dr(na);
+		std::vector<uint32_t> sums(npc);
 		uint32_t err = 0;
 		ST_TRY(back(dr.data(), d_res, (size_t)na * sizeof(lda_stream_res)));
 		ST_TRY(back(&err, d_cnt + 2, 4));
+		if (npc)
+			ST_TRY(back(sums.data(), d_sums, npc * 4));
+		lap(11);
+		/* the output, beside the checksum kernels and the read-backs */
+		ST_TRY(hipStreamWaitEvent(s_copy, d->streams.mark, 0));
+		if (span_out(&d->pinned, d_out, 0, out, (size_t)total, s_copy) != LIBDEFLATE_AMD_OK)
+			return false;
+		lap(13);
 		ST_TRY(pin_sync());
 		bool same = err == 0;
 		for (uint32_t i = 0; i < na && same; i++)
@@ -622,45 +679,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			S[1] = WHY_DECODE;
 			return false;
 		}
+		const uint32_t shp = format == LIBDEFLATE_AMD_GZIP ? crc32_shift(piece) : 0;
+		for (size_t i = 0; i < npc; i++)
+			sum = i == 0 ? sums[0] :
+			      format != LIBDEFLATE_AMD_GZIP ? adler32_concat(sum, sums[i], po[npc + i]) :
+			      po[npc + i] == piece ? crc32_concat_shift(sum, sums[i], shp) :
+						     crc32_concat(sum, sums[i], po[npc + i]);
 	}
-
-	lap(11);
-	/* ---- footer: checksum of the output in pieces, combined on the host ---- */
-	const size_t consumed = (size_t)((end_bit + 7) / 8);
-	int32_t result = LIBDEFLATE_SUCCESS;
 	if (ftr) {
-		uint32_t sum = format == LIBDEFLATE_AMD_GZIP ? 0u : 1u;
-		if (total) {
-			S[1] = WHY_DEVICE;
-			const uint64_t piece = std::max<uint64_t>(65536, align_up(total / 4096, 4096));
-			const size_t npc = (size_t)((total + piece - 1) / piece);
-			std::vector<uint64_t> po(2 * npc);
-			for (size_t i = 0; i < npc; i++) {
-				po[i] = i * piece;
-				po[npc + i] = std::min<uint64_t>(piece, total - i * piece);
-			}
-			uint8_t *scr = (uint8_t *)d->scratch.reserve(npc * 20 + 64);
-			if (!scr)
-				return false;
-			uint64_t *d_po = (uint64_t *)scr;
-			uint32_t *d_sums = (uint32_t *)(scr + npc * 16);
-			std::vector<uint32_t> sums(npc);
-			if (!pin_phase(npc * 20 + 256))
-				return false;
-			ST_TRY(up(d_po, po.data(), npc * 16));
-			const int rc = format == LIBDEFLATE_AMD_GZIP ?
-				libdeflate_amd_crc32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp) :
-				libdeflate_amd_adler32_batch(npc, d_out, d_po, d_po + npc, NULL, d_sums, s_comp);
-			if (rc != LIBDEFLATE_AMD_OK)
-				return false;
-			ST_TRY(back(sums.data(), d_sums, npc * 4));
-			ST_TRY(pin_sync());
-			for (size_t i = 0; i < npc; i++)
-				sum = i == 0 ? sums[0] :
-				      format == LIBDEFLATE_AMD_GZIP ?
-					      crc32_concat(sum, sums[i], po[npc + i]) :
-					      adler32_concat(sum, sums[i], po[npc + i]);
-		}
 		const uint8_t *f = in + hdr + consumed;
 		if (format == LIBDEFLATE_AMD_GZIP) {
 			const uint32_t want = f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) |
@@ -677,11 +703,6 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		}
 	}
 	lap(12);
-	if (result == LIBDEFLATE_SUCCESS && total) {
-		if (span_out(&d->pinned, d_out, 0, out, (size_t)total, s_copy) != LIBDEFLATE_AMD_OK)
-			return false;
-	}
-	lap(13);
 	*res = result;
 	if (result == LIBDEFLATE_SUCCESS) {
 		*ain = hdr + consumed + ftr;
