@@ -5,7 +5,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -218,8 +223,78 @@ void PinnedPair::release()
  * The host side of the host-pointer batches is memcpy between the caller's
  * (pageable) buffers and the pinned staging: one thread moves ~12 GB/s, PCIe
  * 55.  Large slices are packed / unpacked by a few threads side by side
- * (LDA_HOST_THREADS, default 4; 1 = the calling thread alone).
+ * (LDA_HOST_THREADS, default 4; 1 = the calling thread alone): workers of a
+ * small pool that is started on first use and shared by all objects (a thread
+ * per slice and call cost 20-30 us each to create - as much as the copy of a
+ * 4 MiB slice takes).  The workers are detached and never joined: they sleep
+ * on a condition variable between calls; a forked child starts its own.
  */
+namespace {
+
+struct HostPool {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<std::function<void()>> q;
+	unsigned nthreads = 0;
+
+	void run()
+	{
+		for (;;) {
+			std::function<void()> f;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return !q.empty(); });
+				f = std::move(q.front());
+				q.pop_front();
+			}
+			f();
+		}
+	}
+	/* workers that exist after trying for `want` (a thread that cannot be
+	 * created - EAGAIN under a thread or cgroup limit - is simply not there) */
+	unsigned ensure(unsigned want)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		while (nthreads < want) {
+			try {
+				std::thread(&HostPool::run, this).detach();
+			} catch (...) {
+				break;
+			}
+			nthreads++;
+		}
+		return nthreads;
+	}
+	void submit(std::function<void()> f)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			q.push_back(std::move(f));
+		}
+		cv.notify_one();
+	}
+};
+
+HostPool *g_pool;
+std::once_flag g_pool_once;
+
+HostPool *host_pool()
+{
+	std::call_once(g_pool_once, [] {
+		g_pool = new HostPool;	/* never freed: the workers outlive static destruction */
+		(void)pthread_atfork(nullptr, nullptr, [] { g_pool = new HostPool; });
+	});
+	return g_pool;
+}
+
+struct Join {
+	std::mutex m;
+	std::condition_variable cv;
+	size_t left = 0;
+};
+
+} /* namespace */
+
 template <typename F> static void for_chunks_parallel(size_t lo, size_t hi, uint64_t bytes, F fn)
 {
 	size_t nt = (size_t)env_cfg().host_threads;
@@ -228,32 +303,56 @@ template <typename F> static void for_chunks_parallel(size_t lo, size_t hi, uint
 			fn(k);
 		return;
 	}
-	std::thread th[16];
+	HostPool *pool = nullptr;
+	try {
+		pool = host_pool();
+		if (pool->ensure((unsigned)nt - 1) == 0)
+			pool = nullptr;
+	} catch (...) {		/* nothing may unwind through the extern "C" entry points */
+		pool = nullptr;
+	}
+	if (!pool) {
+		for (size_t k = lo; k < hi; k++)
+			fn(k);
+		return;
+	}
 	const size_t per = (hi - lo + nt - 1) / nt;
-	size_t started = 0, own_hi = lo + per < hi ? lo + per : hi;
+	const size_t own_hi = lo + per < hi ? lo + per : hi;
+	auto join = std::make_shared<Join>();
+	size_t queued = 0;
 	for (size_t t = 1; t < nt; t++) {
 		const size_t a = lo + t * per, b = a + per < hi ? a + per : hi;
 		if (a >= hi)
 			break;
-		/* a thread that cannot be created (EAGAIN under a thread or cgroup
-		 * limit) must not unwind through the extern "C" entry points: the
-		 * calling thread takes the rest */
+		{
+			std::lock_guard<std::mutex> lk(join->m);
+			join->left++;
+		}
 		try {
-			th[started] = std::thread([=]() {
+			pool->submit([=]() {
 				for (size_t k = a; k < b; k++)
 					fn(k);
+				std::lock_guard<std::mutex> lk(join->m);
+				if (--join->left == 0)
+					join->cv.notify_one();
 			});
-			started++;
+			queued++;
 		} catch (...) {
-			for (size_t k = a; k < hi; k++)
+			{
+				std::lock_guard<std::mutex> lk(join->m);
+				join->left--;
+			}
+			for (size_t k = a; k < hi; k++)	/* the calling thread takes the rest */
 				fn(k);
 			break;
 		}
 	}
 	for (size_t k = lo; k < own_hi; k++)
 		fn(k);
-	for (size_t t = 0; t < started; t++)
-		th[t].join();
+	if (queued) {
+		std::unique_lock<std::mutex> lk(join->m);
+		join->cv.wait(lk, [&] { return join->left == 0; });
+	}
 }
 
 int copy_in_packed(PinnedPair *pp, uint8_t *d_base, size_t n,
