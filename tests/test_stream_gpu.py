@@ -243,3 +243,25 @@ def test_members_one_after_the_other(dec, comp):
     print(f"40 gzip members of 1 MiB, member after member: {dt * 1e3:.1f} ms "
           f"({(40 << 20) / dt / 1e9:.2f} GB/s)")
     assert dt < 2.0
+
+
+def test_block_finder_against_the_block_map(dec, comp, oracle):
+    """The finder (every bit offset tried as a dynamic block header) against
+    the stream's real block structure (oracle_deflate_block_map): it finds
+    the dynamic blocks - all but, at most, one in fifty - and on compressed
+    text nothing else; among incompressible bytes (stored blocks) it may take
+    a few header-like patterns for block starts, which the chain rejects."""
+    for kind, level, max_false in (("text", 6, 2), ("text", 1, 2), ("mix", 6, 400)):
+        data = _data(kind, 4 << 20, 0x55000 + level)
+        z = comp("deflate", level, data)
+        blocks, r = oracle.block_map(z, len(data))
+        assert r == 0
+        dyn = sum(1 for b in blocks if b[2] == 2)
+        got = dec.decompress_ex("deflate", z, len(data))
+        st = binding.stream_stats()
+        assert got == (0, len(z), len(data), data)
+        assert st["parallel"] == 1 and st["windows"] == 1, st
+        print(f"{kind} L{level}: {len(blocks)} blocks, {dyn} dynamic; finder: "
+              f"{st['blocks_found']} (first filter {st['filter_a']}), repairs {st['repairs']}")
+        assert st["blocks_found"] >= dyn - max(1, dyn // 50), (dyn, st)
+        assert st["blocks_found"] <= dyn + max_false, (dyn, st)
