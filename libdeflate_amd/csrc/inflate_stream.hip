@@ -1124,21 +1124,27 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 	}
 	__syncthreads();
 	u32 bad = 0;
-	u16 nx[32];
-	/* (32 symbols per thread at most; the loops run in blocks of 8 and skip
-	 * the blocks a short tail does not reach: the branch is uniform) */
-#define TAIL_BLOCKS(n_, body)                                                  \
+	/* 32 symbols per thread at most, held two to a register (symbols 2 tid +
+	 * 2048 k and the one after it); the loops run in blocks of 4 registers and
+	 * skip the blocks a short tail does not reach (the branch is uniform) */
+	u32 nx[16];
+#define TAIL_BLOCKS(n_, ...)                                                   \
 	_Pragma("unroll") for (u32 kb = 0; kb < 4; kb++)                       \
 		if (kb * 8192u < (n_)) {                                       \
-			_Pragma("unroll") for (u32 k = 8 * kb; k < 8 * kb + 8; k++) { body } \
+			_Pragma("unroll") for (u32 k = 4 * kb; k < 4 * kb + 4; k++) { __VA_ARGS__ } \
 		}
 	auto load_tail = [&](u32 c) {
 		const u64 s = out_off[c], e = out_off[c + 1];
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
 		const u32 n = (u32)(e - t0);
 		TAIL_BLOCKS(n, {
-			const u32 i = tid + 1024 * k;
-			nx[k] = i < n ? sym[t0 + i] : 0;
+			const u32 i = 2 * tid + 2048 * k;
+			u32 v2 = 0;
+			if (i + 1 < n)
+				__builtin_memcpy(&v2, sym + t0 + i, 4);
+			else if (i < n)
+				v2 = sym[t0 + i];
+			nx[k] = v2;
 		})
 	};
 	load_tail(c0);
@@ -1146,7 +1152,7 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 		const u64 s = out_off[c], e = out_off[c + 1];
 		const u64 t0 = e - s > 32768 ? e - 32768 : s;
 		const u32 n = (u32)(e - t0);
-		u16 v[32];
+		u32 v[16];
 		TAIL_BLOCKS(n, { v[k] = nx[k]; })
 		if (c + 1 < c1)
 			load_tail(c + 1);
@@ -1154,24 +1160,40 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 		 * below `lowest` lie before the stream's first byte */
 		const u32 lowest = s < 32768 ? 32768 - (u32)s : 0;
 		TAIL_BLOCKS(n, {
-			const u32 i = tid + 1024 * k;
-			if (i < n && (v[k] & 0x8000)) {
-				const u32 w = v[k] & 0x7FFF;
+			const u32 i = 2 * tid + 2048 * k;
+			u32 a = v[k] & 0xFFFF, b = v[k] >> 16;
+			if (i < n && (a & 0x8000)) {
+				const u32 w = a & 0x7FFF;
 				if (phase != 0 && w < lowest) {
 					bad = 1;
-					v[k] = 0;
+					a = 0;
 				} else {
-					v[k] = W[((u32)s + w) & 32767];
+					a = W[((u32)s + w) & 32767];
 				}
 			}
+			if (i + 1 < n && (b & 0x8000)) {
+				const u32 w = b & 0x7FFF;
+				if (phase != 0 && w < lowest) {
+					bad = 1;
+					b = 0;
+				} else {
+					b = W[((u32)s + w) & 32767];
+				}
+			}
+			v[k] = a | (b << 16);
 		})
 		__syncthreads();
 		TAIL_BLOCKS(n, {
-			const u32 i = tid + 1024 * k;
+			const u32 i = 2 * tid + 2048 * k;
 			if (i < n) {
-				W[((u32)t0 + i) & 32767] = v[k];
+				W[((u32)t0 + i) & 32767] = (u16)v[k];
 				if (phase != 0)
 					out[t0 + i] = (u8)v[k];
+			}
+			if (i + 1 < n) {
+				W[((u32)t0 + i + 1) & 32767] = (u16)(v[k] >> 16);
+				if (phase != 0)
+					out[t0 + i + 1] = (u8)(v[k] >> 16);
 			}
 		})
 		__syncthreads();
