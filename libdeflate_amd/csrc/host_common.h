@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <atomic>
+#include <exception>
 #include <mutex>
 
 #include "../../include/libdeflate_amd.h"
@@ -137,6 +138,26 @@ int span_out(PinnedPair *pp, const uint8_t *d_base, uint64_t d_off, uint8_t *dst
 	     hipStream_t st);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/*
+ * Nothing may unwind through an extern "C" entry point: the reference is C and
+ * its callers have no handlers, an exception that reaches them ends the
+ * process.  The entry points whose bodies use the standard library's
+ * containers or threads run them through this: a failed host allocation
+ * becomes the call's failure value, with the reason in
+ * libdeflate_amd_last_error().
+ */
+template <typename R, typename F> static inline R no_unwind(const char *what, R failed, F body)
+{
+	try {
+		return body();
+	} catch (const std::exception &e) {
+		set_error("%s: %s", what, e.what());
+	} catch (...) {
+		set_error("%s: exception", what);
+	}
+	return failed;
+}
 
 /* checksum of A || B from the checksums of A and B and the length of B
  * (host_compress.hip) */

@@ -227,8 +227,24 @@ libdeflate_amd_compress_batch_bounded(struct libdeflate_compressor *c, int forma
 				   d_out_nbytes, stream, NULL, max_in_nbytes);
 }
 
+static int compress_batch_host_body(struct libdeflate_compressor *c, int format,
+				   size_t n, const void *const *in,
+				   const size_t *in_nbytes, void *const *out,
+				   const size_t *out_avail, size_t *out_nbytes);
+
 extern "C" LIBDEFLATEAPI int
 libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
+				   size_t n, const void *const *in,
+				   const size_t *in_nbytes, void *const *out,
+				   const size_t *out_avail, size_t *out_nbytes)
+{
+	return no_unwind("compress_batch_host", (int)LIBDEFLATE_AMD_OOM, [&]() {
+		return compress_batch_host_body(c, format, n, in, in_nbytes, out, out_avail,
+						out_nbytes);
+	});
+}
+
+static int compress_batch_host_body(struct libdeflate_compressor *c, int format,
 				   size_t n, const void *const *in,
 				   const size_t *in_nbytes, void *const *out,
 				   const size_t *out_avail, size_t *out_nbytes)
@@ -651,8 +667,10 @@ static size_t compress_one(struct libdeflate_compressor *c, int format,
 	 * chunk with 32 bits, the segments are 64 KiB each) */
 	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 &&
 	    (!env_cfg().no_segments || in_nbytes >= 0xFFFF0000u))
-		return compress_large(c, format, (const uint8_t *)in, in_nbytes,
-				      (uint8_t *)out, out_avail);
+		return no_unwind("libdeflate_*_compress", (size_t)0, [&]() {
+			return compress_large(c, format, (const uint8_t *)in, in_nbytes,
+					      (uint8_t *)out, out_avail);
+		});
 	const void *ins[1] = { in };
 	void *outs[1] = { out };
 	size_t got = 0;

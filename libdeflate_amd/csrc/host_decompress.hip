@@ -249,8 +249,28 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 	return LIBDEFLATE_AMD_OK;
 }
 
+static int decompress_batch_host_body(struct libdeflate_decompressor *d,
+				     int format, size_t n,
+				     const void *const *in,
+				     const size_t *in_nbytes, void *const *out,
+				     const size_t *out_avail, int32_t *results,
+				     size_t *actual_in, size_t *actual_out);
+
 extern "C" LIBDEFLATEAPI int
 libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
+				     int format, size_t n,
+				     const void *const *in,
+				     const size_t *in_nbytes, void *const *out,
+				     const size_t *out_avail, int32_t *results,
+				     size_t *actual_in, size_t *actual_out)
+{
+	return no_unwind("decompress_batch_host", (int)LIBDEFLATE_AMD_OOM, [&]() {
+		return decompress_batch_host_body(d, format, n, in, in_nbytes, out, out_avail,
+						  results, actual_in, actual_out);
+	});
+}
+
+static int decompress_batch_host_body(struct libdeflate_decompressor *d,
 				     int format, size_t n,
 				     const void *const *in,
 				     const size_t *in_nbytes, void *const *out,
@@ -390,9 +410,11 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 	/* a large stream: many waves (host_stream.hip); it answers only for what
 	 * it decoded cleanly, everything else goes on to the sequential kernel */
 	if (d && in && out &&
-	    decompress_stream_parallel(d, format, (const uint8_t *)in, in_nbytes,
-				       (uint8_t *)out, out_avail, actual_out_ret == NULL,
-				       &res, &ain, &aout)) {
+	    no_unwind("libdeflate_*_decompress (many waves)", false, [&]() {
+		    return decompress_stream_parallel(d, format, (const uint8_t *)in, in_nbytes,
+						      (uint8_t *)out, out_avail,
+						      actual_out_ret == NULL, &res, &ain, &aout);
+	    })) {
 		if (res == LIBDEFLATE_SUCCESS) {
 			if (actual_in_ret)
 				*actual_in_ret = ain;
@@ -461,6 +483,14 @@ DEFINE_DECOMPRESS(gzip, LIBDEFLATE_AMD_GZIP)
  * or what follows the indexed part of a file) is decoded member after member:
  * a member's end is only known once it has been decoded.
  */
+static enum libdeflate_result
+decompress_members_body(struct libdeflate_decompressor *d,
+			const void *in_, size_t in_nbytes,
+			void *out_, size_t out_avail,
+			size_t *actual_in_ret,
+			size_t *actual_out_ret,
+			size_t *members_ret);
+
 extern "C" LIBDEFLATEAPI enum libdeflate_result
 libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 				       const void *in_, size_t in_nbytes,
@@ -468,6 +498,21 @@ libdeflate_amd_gzip_decompress_members(struct libdeflate_decompressor *d,
 				       size_t *actual_in_ret,
 				       size_t *actual_out_ret,
 				       size_t *members_ret)
+{
+	/* (a library-side failure is BAD_DATA, see decompress_one()) */
+	return no_unwind("libdeflate_amd_gzip_decompress_members", LIBDEFLATE_BAD_DATA, [&]() {
+		return decompress_members_body(d, in_, in_nbytes, out_, out_avail, actual_in_ret,
+					       actual_out_ret, members_ret);
+	});
+}
+
+static enum libdeflate_result
+decompress_members_body(struct libdeflate_decompressor *d,
+			const void *in_, size_t in_nbytes,
+			void *out_, size_t out_avail,
+			size_t *actual_in_ret,
+			size_t *actual_out_ret,
+			size_t *members_ret)
 {
 	const uint8_t *in = (const uint8_t *)in_;
 	uint8_t *out = (uint8_t *)out_;
