@@ -1165,6 +1165,14 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 							break;
 					}
 				}
+#if defined(LDA_PROFILE) && defined(LDA_PROFILE_COUNTS)
+				/* the wait for the far sources on its own (the profile build
+				 * only: it also waits for the token rows requested ahead) */
+				PROF_SEC(3);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				PROF_SEC(4);
+				PROF_SEC_ADD(7, 1);
+#endif
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane, tw = own[k];

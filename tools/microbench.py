@@ -128,7 +128,7 @@ def bench_inflate(a, fmt="gzip", level=6):
     U = a.chunks * a.size
     C = sum(sizes)
     read_profile("libdeflate_amd_profile_read_inflate",
-                 ["hdr", "tables", "tokens", "-", "dec seg(lane0)", "flush seg(lane0)", "rounds(lane0)", "iterations(wave)", "reg-matches", "pipelined", "slow-matches", "slow-bytes", "#par STOP", "#par rounds", "#par EOB rounds", "-", "par: sync", "#sync iterations", "copy: tokens+marks", "copy: roots", "copy: doubling", "copy: fill", "#copy groups", "#sync passes"])
+                 ["hdr", "tables", "tokens", "-", "dec seg(lane0)", "flush seg(lane0)", "rounds(lane0)", "iterations(wave)", "reg-matches", "pipelined", "slow-matches", "slow-bytes", "#par STOP", "#par rounds", "#par EOB rounds", "-", "par: sync", "#sync iterations", "copy: group setup", "copy: slots", "copy: wait for far sources", "copy: flush", "#copy groups", "#slot batches"])
     print(f"inflate[{fmt} L{level}]: {U/t/1e9:.2f} GB/s uncompressed, algorithmic {(U+C)/t/1e9:.2f} GB/s, "
           f"{t*1e3:.2f} ms, ratio {C/U:.3f}, ok {ok}/{a.chunks}")
 
