@@ -22,28 +22,33 @@
  *            inflate_kernel.hip rest on), so a chunk that knows its block's
  *            header parses 1 KiB of warm-up in front of its nominal start,
  *            and the first token boundary at or after that start is its start.
- *   count    lda_stream_chunk_kernel<COUNT>: a wave per chunk parses its
- *            chunk up to the first token (or block) boundary at or after the
- *            next chunk's nominal start and reports where it started, where
- *            it ended, under which block header, and how many bytes it makes.
+ *   count    lda_stream_count_kernel: a wave per chunk parses its chunk up to
+ *            the first token (or block) boundary at or after the next chunk's
+ *            nominal start (runs of stored blocks are walked through) and
+ *            reports where it started, where it ended, under which block
+ *            header, and how many bytes it makes.
  *   chain    (host) chunk 0 starts at the stream's first bit and is exact.
  *            A chunk is accepted iff its start - position, governing header,
  *            boundary kind - is exactly the end of an accepted chunk, so by
  *            induction every accepted chunk is the reference's parse.  Where
  *            the chain breaks (a block the finder does not look for - stored,
  *            static -, a false candidate, a warm-up that did not fall in
- *            step) a repair chunk is counted from the exact end state; too
- *            many repairs, any error, or an output that does not fit send the
- *            whole stream to the sequential kernel, which owns the result
- *            codes.
- *   decode   lda_stream_chunk_kernel<MARK>: the same parse again (tokens are
+ *            step) a repair chunk is counted from the exact end state - for
+ *            every open end at once, one launch per round; too many repairs,
+ *            any error, or an output that does not fit send the whole stream
+ *            to the sequential kernel, which owns the result codes.  The input
+ *            goes through find .. chain in WINDOWS of growing size, so a
+ *            stream that ends early never has the rest of the buffer touched.
+ *   decode   lda_stream_decode_kernel: the same parse again (tokens are
  *            cheaper to decode twice than to keep), now executed: 16-bit
  *            symbols, a byte or - for a match source in front of the chunk's
  *            first byte - a MARKER 0x8000 | index into the 32 KiB in front of
  *            the chunk.
- *   window   lda_stream_window_kernel: one workgroup walks the chunks in
- *            order with the window in LDS and settles the last 32 KiB of
- *            every chunk (32 Ki symbols per step, the only serial part).
+ *   window   lda_stream_window_kernel (+ lda_stream_window_link_kernel): the
+ *            last 32 KiB of every chunk settled against the 32 KiB in front
+ *            of it - a chain through all chunks, run as a two-level scan over
+ *            groups of chunks with the window as a ring in LDS (see "markers
+ *            -> bytes" below).
  *   resolve  lda_stream_resolve_kernel: every other symbol, all in parallel.
  *
  * Not a restatement of anything in the reference; the validity rules of the
