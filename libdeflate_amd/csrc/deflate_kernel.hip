@@ -61,7 +61,7 @@
  * ratio-vs-reference are what the tests check.
  *
  * deflate_small.hip compiles this file a second time (LDA_SMALL: 256 threads,
- * one tile of state) for batches of buffers of at most 4096 bytes.
+ * a 4 KiB ring, tiles of 2048) for batches of buffers of at most 4096 bytes.
  */
 #include <stddef.h>
 #include "device_common.h"
@@ -145,7 +145,7 @@
 #define WQ_SEG (WQ_CAP / NWAVES)
 #ifndef RA_PAIR
 /* round A measures its two candidates side by side (match_length2()).  Not
- * in the small-buffer kernel: three workgroups share a CU there and hide each
+ * in the small-buffer kernel: several workgroups share a CU there and hide each
  * other's LDS round trips already; the longer code measured 12 % slower. */
 #ifdef LDA_SMALL
 #define RA_PAIR 0
@@ -222,8 +222,8 @@ struct deflate_lds {
 typedef AS3 struct deflate_lds lds_t;
 
 #ifdef LDA_SMALL
-static_assert(sizeof(struct deflate_lds) <= 163840 / 3, "three workgroups per CU");
-static_assert(RING >= TILE && NXT_ELEMS * 2 >= 3600, "one tile per buffer; block-end tables fit nxtB");
+static_assert(sizeof(struct deflate_lds) <= 163840 / SMALL_WGS, "SMALL_WGS workgroups per CU");
+static_assert(RING >= TILE && NXT_ELEMS * 2 >= 3600, "the whole buffer is resident; block-end tables fit nxtB");
 #else
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 static_assert(NXT_ELEMS == TILE + 8, "levels 10-12 keep one u16 per position in nxtA");
@@ -1810,10 +1810,12 @@ parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u6
 				}
 			}
 		}
-		/* where the path of the lane before me leaves its positions */
+		/* where the path of the lane before me leaves its positions (the
+		 * lanes past the last position have nothing to walk: the path's
+		 * exit is read from the last lane that has) */
 		s32 pe = (s32)__builtin_amdgcn_update_dpp((u32)ex, (u32)ex, 0x138, 0xF, 0xF, false);
 		const s32 e = lane == 0 ? entry : pe;
-		const bool redo = e != ein;
+		const bool redo = e != ein && seg_lo < limit;
 		if (!__ballot(redo) || --max_pass == 0)
 			break;
 		nm = 0;
@@ -1831,7 +1833,7 @@ parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u6
 	if (lane < TILE / 64)
 		pmp[lane] = mask;
 	*mask_out = mask;
-	return (s32)__builtin_amdgcn_readlane((int)ex, 63);
+	return (s32)bcast_lane((u32)ex, limit > 0 ? (u32)(limit - 1) >> 6 : 0);
 }
 
 /* the carried-in idx 2, 3 (the last two positions of the tile before, which
@@ -1899,10 +1901,12 @@ parse_and_base(lds_t *L, u32 *__restrict__ tokg, u32 t, s32 limit, u32 mode,
 	const s32 px = parse_tile((const AS3 u32 *)L->M, (const AS3 u64 *)L->lit1,
 				  (const AS3 u64 *)L->lit2, (AS3 u64 *)L->pm, lane,
 				  (s32)e - 4, limit, &mask);
-	const u64 two = mask & L->lit2[lane];
+	/* (a tile shorter than 64 groups: the lanes past it hold an empty mask) */
+	const u64 two = lane < TILE / 64 ? mask & L->lit2[lane] : 0;
 	const u32 cnt = (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(two);
 	const u32 incl = wave_scan_incl(cnt);
-	L->gbase[lane] = seq0 + npre + incl - cnt;
+	if (lane < TILE / 64)
+		L->gbase[lane] = seq0 + npre + incl - cnt;
 	if (lane == 63) {
 		L->vars[V_NSEQ] = seq0 + npre + incl;
 		/* where the path leaves the tile */
@@ -2537,7 +2541,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		if (n64 > 0xFFFFFF00u)	/* positions are 32-bit here */
 			overflow = true;
 #ifdef LDA_SMALL
-		if (n64 > TILE)		/* the caller's size bound was wrong */
+		if (n64 > RING)		/* the caller's size bound was wrong */
 			overflow = true;
 #endif
 		const u32 n = (u32)n64;
@@ -3582,10 +3586,9 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	out_nbytes, sums, seq_scratch, seg_info, next_chunk
 
 #ifdef LDA_SMALL
-/* buffers of at most TILE bytes, 256 threads, three workgroups per CU:
- * deflate_small.hip */
-/* (three workgroups per CU = three waves per SIMD: at most 168 VGPRs) */
-extern "C" __global__ void __launch_bounds__(NT, 3)
+/* buffers of at most RING bytes, 256 threads, SMALL_WGS workgroups per CU
+ * (= waves per SIMD: four leave 128 VGPRs each): deflate_small.hip */
+extern "C" __global__ void __launch_bounds__(NT, SMALL_WGS)
 lda_deflate_small_kernel(DEFLATE_KERNEL_PARAMS)
 {
 	extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
@@ -3599,7 +3602,12 @@ extern "C" size_t lda_deflate_small_lds_bytes(void)
 
 extern "C" size_t lda_deflate_small_max(void)
 {
-	return TILE;
+	return RING;
+}
+
+extern "C" size_t lda_deflate_small_wgs(void)
+{
+	return SMALL_WGS;
 }
 
 LDA_PROF_DEFINE_READER(libdeflate_amd_profile_read_deflate_small)

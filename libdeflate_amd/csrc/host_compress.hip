@@ -144,12 +144,12 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
 	/* buffers of at most 4 KiB (filesystem blocks): the 256-thread kernel,
-	 * three workgroups per CU (deflate_small.hip); levels 10-12 keep the
+	 * several workgroups per CU (deflate_small.hip); levels 10-12 keep the
 	 * big one (their parse wants its LDS) */
 	const bool small = max_in_nbytes <= lda_deflate_small_max() &&
 			   c->level <= 9 && !d_seg_info && !env_cfg().no_small;
 	/* scratch: [token lists: u64 x words x grid][chunk counter][sums u32 x n] */
-	size_t grid_max = (size_t)ctx->num_cus * (small ? 3 : 1);
+	size_t grid_max = (size_t)ctx->num_cus * (small ? lda_deflate_small_wgs() : 1);
 	size_t grid = n < grid_max ? n : grid_max;
 	size_t seq_bytes = grid * lda_deflate_seq_words() * 8;
 	uint8_t *scr = (uint8_t *)c->scratch.reserve(seq_bytes + 16 + n * 4);
@@ -315,7 +315,7 @@ static int compress_batch_host_body(struct libdeflate_compressor *c, int format,
 			max_nk = bounds[k + 1] - bounds[k] > max_nk ? bounds[k + 1] - bounds[k] : max_nk;
 		const bool small = max_in <= lda_deflate_small_max() && c->level <= 9 &&
 				   !env_cfg().no_small;
-		const size_t grid_max = (size_t)device_ctx()->num_cus * (small ? 3 : 1);
+		const size_t grid_max = (size_t)device_ctx()->num_cus * (small ? lda_deflate_small_wgs() : 1);
 		const size_t grid = max_nk < grid_max ? max_nk : grid_max;
 		if (!c->scratch.reserve(grid * lda_deflate_seq_words() * 8 + 16 + max_nk * 4))
 			return LIBDEFLATE_AMD_OOM;

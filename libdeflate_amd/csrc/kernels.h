@@ -80,6 +80,7 @@ lda_deflate_small_kernel(uint64_t n_chunks, int format, int level,
 			 uint32_t *next_chunk);
 extern "C" size_t lda_deflate_small_lds_bytes(void);
 extern "C" size_t lda_deflate_small_max(void);
+extern "C" size_t lda_deflate_small_wgs(void);	/* workgroups per CU it is built for */
 extern "C" size_t lda_deflate_tile(void);	/* positions per tile (dictionary granularity) */
 extern "C" size_t lda_deflate_lds_bytes(void);
 extern "C" size_t lda_deflate_seq_words(void);	/* u64 words of HBM scratch per workgroup (token list, saved histograms) */
