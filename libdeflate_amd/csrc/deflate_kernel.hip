@@ -224,6 +224,7 @@ typedef AS3 struct deflate_lds lds_t;
 #ifdef LDA_SMALL
 static_assert(sizeof(struct deflate_lds) <= 163840 / SMALL_WGS, "SMALL_WGS workgroups per CU");
 static_assert(RING >= TILE && NXT_ELEMS * 2 >= 3600, "the whole buffer is resident; block-end tables fit nxtB");
+static_assert(TILE == 2048 || TILE == 4096, "tiles of 1024 find fewer matches (measured: 0.57 instead of 0.40 of the input): not supported");
 #else
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 static_assert(NXT_ELEMS == TILE + 8, "levels 10-12 keep one u16 per position in nxtA");

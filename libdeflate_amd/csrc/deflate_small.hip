@@ -28,7 +28,10 @@
 #endif
 #define TILE SMALL_TILE
 #define RING 4096u
-#define HASH_BITS 11
+#ifndef SMALL_HASH_BITS
+#define SMALL_HASH_BITS 11
+#endif
+#define HASH_BITS SMALL_HASH_BITS
 #define HASH3_BITS SMALL_HASH3_BITS
 #define WQ_CAP 1024u
 #include "deflate_kernel.hip"
