@@ -500,6 +500,35 @@ def test_small_buffer_kernel(level, oracle):
     c.close()
 
 
+def test_small_buffer_of_two_kinds(oracle):
+    """The small-buffer kernel takes a 4 KiB buffer as two tiles of 2048
+    positions (deflate_small.hip): a buffer whose halves are of different
+    content may end its first block between them (the split rule of
+    lib/deflate_compress.c:2092-2218 once per tile), the round trip holds for
+    every pair of kinds and every cut position around the tile boundary, and
+    the batch is within 3 % of the reference's size at the same level."""
+    from libdeflate_amd import api
+    from tests import oracle_util
+    ref = oracle_util.load_ref()
+    bufs = []
+    for i, (ka, kb) in enumerate(((0, 7), (7, 0), (0, 5), (5, 6), (6, 0), (2, 7), (0, 0), (7, 7))):
+        for cut in (1, 1000, 2046, 2047, 2048, 2049, 2050, 2306, 3000, 4095):
+            bufs.append(datagen.chunk(ka, cut, 0x0E110090 + i, datagen.MIX4K) +
+                        datagen.chunk(kb, 4096 - cut, 0x0E1100A0 + i, datagen.MIX4K))
+    for level in (1, 6, 9):
+        c = api.Compressor(level)
+        comps = c.compress_batch_host("zlib", bufs)
+        for d, z in zip(bufs, comps):
+            _check_roundtrip(oracle, "zlib", d, z, ("two kinds", level))
+            assert len(z) <= c.bound("zlib", len(d))
+        if ref is not None:
+            ours = sum(map(len, comps))
+            theirs = sum(len(ref.compress("zlib", level, d)) for d in bufs)
+            print(f"4 KiB buffers of two kinds, level {level}: {ours} bytes, reference {theirs}")
+            assert ours <= 1.03 * theirs, (level, ours, theirs)
+        c.close()
+
+
 def test_first_call_small_batch_then_large():
     """A process whose FIRST compress call is a batch of small buffers (the
     256-thread kernel) must still be able to launch the 1024-thread kernels
