@@ -224,7 +224,6 @@ typedef AS3 struct deflate_lds lds_t;
 #ifdef LDA_SMALL
 static_assert(sizeof(struct deflate_lds) <= 163840 / SMALL_WGS, "SMALL_WGS workgroups per CU");
 static_assert(RING >= TILE && NXT_ELEMS * 2 >= 3600, "the whole buffer is resident; block-end tables fit nxtB");
-static_assert(TILE == 2048 || TILE == 4096, "tiles of 1024 find fewer matches (measured: 0.57 instead of 0.40 of the input): not supported");
 #else
 static_assert(sizeof(struct deflate_lds) <= 163840, "LDS of one CU");
 static_assert(NXT_ELEMS == TILE + 8, "levels 10-12 keep one u16 per position in nxtA");
@@ -835,6 +834,13 @@ template <int N> struct huff_scratch {
 	u32 nc[16];	/* next canonical codeword per length */
 	u16 S[2 * N];	/* merge rounds: the items of a round in merged order */
 };
+
+/* a block end builds its codes in M[] (keys and sorted symbols in the first
+ * 2 KiB, the litlen tree's scratch behind them): tiles of 1024 positions do
+ * not leave room for it (such a build measured 7 % faster per batch with five
+ * workgroups per CU - and wrote garbage codes over the histogram) */
+static_assert(sizeof(((struct deflate_lds *)0)->M) >= 2048 + sizeof(huff_scratch<288>),
+	      "M[] holds the block-end scratch");
 
 template <int N> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
