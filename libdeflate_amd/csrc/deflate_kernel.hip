@@ -2644,6 +2644,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		 * (deflate_compress_fastest(), lib/deflate_compress.c:2451-2523, ends
 		 * blocks by length only) */
 		const bool use3 = level >= 2;
+		/* split statistics are kept where a block can end before the buffer
+		 * does: not at level 1 (blocks end by length only), not in a buffer
+		 * shorter than the minimum block length of two blocks' first
+		 * (split_stats(): no cut below 5000 bytes; every 4 KiB buffer) */
+		const bool splits = use3 && n - dict_len >= 5000;
 		bool mx_pending = false;	/* the next tile's search results wait in MX */
 		u32 ml_cur = 3, ml_nxt = 3;	/* minimum match length of tile cur / nxt */
 		u32 carryv = 0;			/* M[TILE + tid] of the tile before (tid < 4) */
@@ -2993,7 +2998,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						/* block split observations of tile cur, by the last wave
 						 * once every group is emitted (wave 0 is still walking
 						 * the next tile's first parse) */
-						if (wave == NWAVES - 1 && use3) {
+						if (wave == NWAVES - 1 && splits && !last_tile) {
 							wait_lds_eq(L, V_EMDONE, TILE / 64);
 							split_stats(L, bcast_first(L->vars[V_WALKPOS_LO]), block_start, false, lane);
 						}
@@ -3033,7 +3038,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					carryv = L->M[TILE + tid];
 				/* block split observations (see "block end?" below), by the
 				 * last wave while the others wait at the barrier */
-				if (!use3) {
+				if (!splits) {
 					if (tid == 0)
 						L->vars[V_SPLIT] = 0;
 				} else if (wave == NWAVES - 1 && optm) {
