@@ -136,6 +136,19 @@
 #ifndef P1_PASSES
 #define P1_PASSES 0xFFFFFFFFu	/* passes of the first (worklist) parse */
 #endif
+#ifndef RB_DEFER
+/* the last generation of round B runs inside phase X, beside the next tile's
+ * shallow search (see rb_last_gen() and the schedule); not in the small-buffer
+ * kernel: its four waves have no eight to spare */
+#ifdef LDA_SMALL
+#define RB_DEFER 0
+#else
+#define RB_DEFER 1
+#endif
+#endif
+#ifndef RB_TAIL_WAVES
+#define RB_TAIL_WAVES 8u	/* waves 1..8 take a deferred generation: at most 512 items */
+#endif
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
 #endif
@@ -234,7 +247,7 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
 	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_UNUSED0,
-	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE
+	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE, V_TAILDONE, V_CTR4, V_ST2DONE
 };
 
 /* depth classes of the progressive search (done[]): what a position has been
@@ -1752,6 +1765,38 @@ stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, 
 	}
 }
 
+/* the steps of the FINAL parse of the current tile by claimed groups (V_CTR4,
+ * counted in V_ST2DONE): what stage_steps() does, for the waves that ran a
+ * deferred generation of round B inside phase X (M[] is complete when they
+ * all are through) */
+static __device__ __forceinline__ void
+stage_steps_cur_claimed(lds_t *L, s32 limit, u32 mode, u32 nice, u32 lane)
+{
+	bool had = false;
+
+#pragma unroll 1
+	for (;;) {
+		u32 g = 0;
+		if (lane == 0) {
+			if (had)
+				atomicAdd((u32 *)&L->vars[V_ST2DONE], 1u);
+			g = atomicAdd((u32 *)&L->vars[V_CTR4], 1u);
+		}
+		g = bcast_first(g);
+		if (g >= TILE / 64)
+			break;
+		had = true;
+		const u32 q = 64 * g + lane, idx = q + 4;
+		u32 st = 1;
+		if ((s32)q < limit)
+			st = token_step(L->M[idx], L->M[idx + 1], L->M[idx + 2], mode, nice);
+		/* (every lane stores the same words: no second lane-0 section) */
+		L->lit1[g] = __ballot(st == 1);
+		L->lit2[g] = __ballot(st == 2);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	}
+}
+
 /* wait until an LDS word written by other waves reaches a value */
 static __device__ __forceinline__ void wait_lds_eq(lds_t *L, u32 idx, u32 val)
 {
@@ -2262,11 +2307,9 @@ search_items(lds_t *L, AS3 u32 *Mo, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 d
 #else
 #define PROF_GEN(g) do { } while (0)
 #endif
-static __device__ __forceinline__ void
-search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
-	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid)
+/* the search depth round B works with: see the comment inside */
+static __device__ __forceinline__ u32 rb_trim_depth(u32 depth)
 {
-	const u32 lane = tid & 63, wave = tid >> 6;
 	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;	/* walk passes per generation */
 	const u32 quantum = 8 * npass;
 #if GEN_TRIM
@@ -2282,13 +2325,132 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 	if (depth >= 16 && (depth & 7) <= depth / 8)
 		depth &= ~7u;
 #endif
+	return depth;
+}
+
+/* generation `gen`: chain steps already walked, walk passes, steps of this one */
+static __device__ __forceinline__ void
+rb_gen_params(u32 depth, u32 gen, u32 *before, u32 *npass_g)
+{
+	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;
+	const u32 quantum = 8 * npass;
+	/* the survivors of a generation are the deep chains: later
+	 * generations walk longer before they repack (GEN_GROW) */
+	*npass_g = GEN_GROW ? npass * (gen + 1) : npass;
+	*before = GEN_GROW ? quantum * (gen * (gen + 1) / 2) : quantum * gen;
+}
+
+/*
+ * One batch of a generation: lane's item `e` (see search_queue() for the
+ * layout; `have` = the lane has one).  `depth` is the trimmed one.  Returns
+ * whether the item goes on to the next generation, *next = its entry there.
+ */
+static __device__ __forceinline__ bool
+rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
+	 u32 e, bool have, u32 gen, u32 lane, u32 *next)
+{
 	const u32 half = depth >> S3_HALF_SHIFT ? depth >> S3_HALF_SHIFT : 1;
+	u32 before, npass_g;
+	rb_gen_params(depth, gen, &before, &npass_g);
+	const u32 qg = 8 * npass_g;
+	const u32 i = e & 0xFFF, p = t + i;
+	const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
+	u32 dep = before < cdepth ? cdepth - before : 0;
+	dep = dep < qg ? dep : qg;
+	const u32 cur = ld32(L->in, p);
+	const u64 nxt8 = ld64(L->in, p + 4);
+	const u32 maxlen = n - p < 258 ? n - p : 258;
+	const u32 dmaxp = p - lo_pos;
+	const u32 nic = nice < maxlen ? nice : maxlen;
+	const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
+	u32 best = l0 >= 4 ? l0 : 3, bestd = l0 >= 4 ? m >> 16 : 0;
+	const u32 best0 = best;
+	u32 boff = best - 3;
+	u32 curb = ld32(L->in, p + boff);
+	u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
+	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
+	bool act = have && p + 4 <= n && best < nic && dep;
+	bool ended = false;
+	for (u32 ps = 0; ps < npass_g; ps++) {
+		u32 cnt = 0;
+#if RB_HITS <= 2
+		u32 qh = 0;
+#else
+		u64 qh = 0;
+#endif
+#pragma unroll
+		for (int s = 0; s < 8; s++) {
+			u32 d = (p - c16) & 0xFFFF;
+			bool chain = dep && d > dprev && d <= dmaxp;
+			bool stall = ended || cnt >= RB_HITS;
+			bool ok = act && !stall && chain;
+			u32 cp = p - d;
+			u32 w = ld32(L->in, cp + boff);
+			u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
+			bool hit = ok && w == curb;
+			c16 = ok ? c16n : c16;
+			dprev = ok ? d : dprev;
+			dep -= ok ? 1 : 0;
+			ended = ended || (act && !stall && !chain);
+			qh = hit ? ((qh << 16) | d) : qh;
+			cnt += hit ? 1 : 0;
+			PROF_COUNT(20, __builtin_popcountll(__ballot(ok)));
+			PROF_COUNT(17, __builtin_popcountll(__ballot(hit)));
+		}
+		PROF_COUNT(13, __builtin_popcountll(__ballot(have)));
+		/* evaluate: every lane pops its oldest (closest) hit.  (Dealing
+		 * the wave's hits out to all lanes through LDS - they are a
+		 * third of a hit per lane - measured slower: the five
+		 * cross-lane fetches per round cost more than the rounds
+		 * saved.) */
+		while (__ballot(cnt > 0)) {
+			PROF_COUNT(21, 1);
+			const bool ev = cnt > 0;
+			const u32 d = (u32)(qh >> (16 * ((cnt - 1) & (RB_HITS - 1)))) & 0xFFFF;
+			cnt -= ev ? 1 : 0;
+			const u32 len = match_length(L, ev, p, p - d, cur, nxt8,
+						     maxlen, lane);
+			if (ev && len > best) {
+				best = len;
+				bestd = d;
+			}
+		}
+		if (best >= nic)
+			act = false;
+		if (npass_g > 1) {
+			if (!__ballot(act && !ended && dep))
+				break;
+			boff = best - 3;
+			curb = ld32(L->in, p + boff);
+		}
+	}
+	if (best > best0)
+		L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
+	*next = (e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);
+	return act && !ended && before + qg < cdepth;
+}
+
+/*
+ * `defer`: a generation that no item can outlive (the search depth ends with
+ * it) and that fits RB_TAIL_WAVES batches is NOT run here: its list stays in
+ * *tail_list (*tail_n items, generation *tail_gen) and the caller runs it
+ * inside phase X (rb_batch() by the waves that loaded the items).  Never the
+ * first generation: that one is the bulk of the work and fills every wave.
+ */
+static __device__ __forceinline__ void
+search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
+	     u32 nice, AS3 u32 *WA, AS3 u32 *WB, u32 wc, u32 tid,
+	     bool defer, u32 *tail_n, u32 *tail_gen, AS3 u32 **tail_list)
+{
+	const u32 lane = tid & 63, wave = tid >> 6;
+	depth = rb_trim_depth(depth);
 	const u64 lt = (1ull << lane) - 1;
 	u32 ncur = wc;
 #ifdef LDA_PROFILE
 	unsigned long long pg_ = __builtin_readcyclecounter();
 #endif
 
+	*tail_n = 0;
 	PROF_COUNT(15, wc);
 	PROF_COUNT(18, 1);
 	for (u32 gen = 0;; gen++) {
@@ -2297,98 +2459,30 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 		PROF_COUNT(19, ncur);
 		AS3 u32 *cur_l = gen & 1 ? WB : WA, *nxt_l = gen & 1 ? WA : WB;
 		AS3 u32 *ctr = &L->qn[gen % 3];
-		/* the survivors of a generation are the deep chains: later
-		 * generations walk longer before they repack (GEN_GROW) */
-		const u32 npass_g = GEN_GROW ? npass * (gen + 1) : npass;
-		const u32 qg = 8 * npass_g;
-		const u32 before = GEN_GROW ? quantum * (gen * (gen + 1) / 2) : quantum * gen;
+		u32 before, npass_g;
+		rb_gen_params(depth, gen, &before, &npass_g);
+		if (RB_DEFER && defer && gen && before + 8 * npass_g >= depth &&
+		    ncur <= 64 * RB_TAIL_WAVES) {
+			*tail_n = ncur;
+			*tail_gen = gen;
+			*tail_list = cur_l;
+			return;
+		}
 		if (tid == 0)
 			L->qn[(gen + 1) % 3] = 0;
 		for (u32 base = 64 * wave; base < ncur; base += 64 * NWAVES) {
 			const bool have = base + lane < ncur;
 			const u32 e = have ? cur_l[base + lane] : 0;
-			const u32 i = e & 0xFFF, p = t + i;
-			const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
-			u32 dep = before < cdepth ? cdepth - before : 0;
-			dep = dep < qg ? dep : qg;
-			const u32 cur = ld32(L->in, p);
-			const u64 nxt8 = ld64(L->in, p + 4);
-			const u32 maxlen = n - p < 258 ? n - p : 258;
-			const u32 dmaxp = p - lo_pos;
-			const u32 nic = nice < maxlen ? nice : maxlen;
-			const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
-			u32 best = l0 >= 4 ? l0 : 3, bestd = l0 >= 4 ? m >> 16 : 0;
-			const u32 best0 = best;
-			u32 boff = best - 3;
-			u32 curb = ld32(L->in, p + boff);
-			u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
-			u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
-			bool act = have && p + 4 <= n && best < nic && dep;
-			bool ended = false;
-			for (u32 ps = 0; ps < npass_g; ps++) {
-				u32 cnt = 0;
-#if RB_HITS <= 2
-				u32 qh = 0;
-#else
-				u64 qh = 0;
-#endif
-#pragma unroll
-				for (int s = 0; s < 8; s++) {
-					u32 d = (p - c16) & 0xFFFF;
-					bool chain = dep && d > dprev && d <= dmaxp;
-					bool stall = ended || cnt >= RB_HITS;
-					bool ok = act && !stall && chain;
-					u32 cp = p - d;
-					u32 w = ld32(L->in, cp + boff);
-					u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
-					bool hit = ok && w == curb;
-					c16 = ok ? c16n : c16;
-					dprev = ok ? d : dprev;
-					dep -= ok ? 1 : 0;
-					ended = ended || (act && !stall && !chain);
-					qh = hit ? ((qh << 16) | d) : qh;
-					cnt += hit ? 1 : 0;
-					PROF_COUNT(20, __builtin_popcountll(__ballot(ok)));
-					PROF_COUNT(17, __builtin_popcountll(__ballot(hit)));
-				}
-				PROF_COUNT(13, __builtin_popcountll(__ballot(have)));
-				/* evaluate: every lane pops its oldest (closest) hit.  (Dealing
-				 * the wave's hits out to all lanes through LDS - they are a
-				 * third of a hit per lane - measured slower: the five
-				 * cross-lane fetches per round cost more than the rounds
-				 * saved.) */
-				while (__ballot(cnt > 0)) {
-					PROF_COUNT(21, 1);
-					const bool ev = cnt > 0;
-					const u32 d = (u32)(qh >> (16 * ((cnt - 1) & (RB_HITS - 1)))) & 0xFFFF;
-					cnt -= ev ? 1 : 0;
-					const u32 len = match_length(L, ev, p, p - d, cur, nxt8,
-								     maxlen, lane);
-					if (ev && len > best) {
-						best = len;
-						bestd = d;
-					}
-				}
-				if (best >= nic)
-					act = false;
-				if (npass_g > 1) {
-					if (!__ballot(act && !ended && dep))
-						break;
-					boff = best - 3;
-					curb = ld32(L->in, p + boff);
-				}
-			}
-			if (best > best0)
-				L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
-			const bool surv = act && !ended && before + qg < cdepth;
+			u32 nx;
+			const bool surv = rb_batch(L, t, n, lo_pos, min_len, depth, nice, e, have,
+						   gen, lane, &nx);
 			const u64 b = __ballot(surv);
 			u32 at = 0;
 			if (lane == 0 && b)
 				at = atomicAdd((u32 *)ctr, (u32)__builtin_popcountll(b));
 			at = bcast_first(at);
 			if (surv)
-				nxt_l[at + __builtin_popcountll(b & lt)] =
-					(e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);
+				nxt_l[at + __builtin_popcountll(b & lt)] = nx;
 		}
 		__syncthreads();
 		PROF_GEN(gen);
@@ -2650,6 +2744,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		 * (split_stats(): no cut below 5000 bytes; every 4 KiB buffer) */
 		const bool splits = use3 && n - dict_len >= 5000;
 		bool mx_pending = false;	/* the next tile's search results wait in MX */
+		u32 tail_n = 0, tail_gen = 0, tail_e = 0;	/* round B's deferred last generation */
 		u32 ml_cur = 3, ml_nxt = 3;	/* minimum match length of tile cur / nxt */
 		u32 carryv = 0;			/* M[TILE + tid] of the tile before (tid < 4) */
 
@@ -2743,6 +2838,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				uint4 s0_v = make_uint4(0, 0, 0, 0);
 				if (s0_pre)
 					s0_v = *(const uint4 *)(inp + s0_p);
+				tail_n = 0;
 				if (cur_real && !optm) {
 					/* ---- S3 round B: the positions the first parse visited
 					 * (pmA: it ran beside phase X of the iteration before) are
@@ -2751,13 +2847,26 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice,
 									      wq_limit, tid);
 						PROF_MARK(39);
-						if (wc)
+						if (wc) {
+							AS3 u32 *tl = (AS3 u32 *)L->nxtB;
 							search_queue(L, t, n, lo_cur, ml_cur, depth, nice,
-								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid);
+								     (AS3 u32 *)L->nxtB, (AS3 u32 *)L->nxtA, wc, tid,
+								     nxt_real, &tail_n, &tail_gen, &tl);
+							/* a deferred last generation: its items leave the
+							 * list (the next tile's search results take the
+							 * list's LDS in phase X) for a register of the
+							 * waves that will walk them */
+							if (tail_n && wave >= 1 && wave <= RB_TAIL_WAVES) {
+								const u32 k = 64 * (wave - 1) + lane;
+								tail_e = k < tail_n ? tl[k] : 0;
+							}
+						}
 						PROF_MARK(3);
 					}
-					/* steps of the final parse (it runs in phase X) */
-					stage_steps(L, limit, mode, nice, tid);
+					/* steps of the final parse (it runs in phase X; behind a
+					 * deferred generation they are computed there as well) */
+					if (!tail_n)
+						stage_steps(L, limit, mode, nice, tid);
 					__syncthreads();
 				}
 				if (cur_real && optm) {
@@ -2867,13 +2976,20 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_CTR3] = 0;
 						L->vars[V_STDONE] = 0;
 						L->vars[V_EMDONE] = 0;
+						L->vars[V_TAILDONE] = 0;
+						L->vars[V_CTR4] = 0;
+						L->vars[V_ST2DONE] = 0;
 					}
 					/* what the first parse of tile nxt reads around its search
 					 * results: the entries its predecessor's walk deferred, and
 					 * no matches past the end */
 					if (tid < 4 && nxt_real) {
 						AS3 u32 *const Mo = cur_real ? MX : (AS3 u32 *)L->M;
-						Mo[tid] = cur_real ? L->M[TILE + tid] : 0;
+						/* (behind a deferred generation of round B the
+						 * entries may still change: wave 0 copies them after
+						 * its final parse) */
+						if (!tail_n)
+							Mo[tid] = cur_real ? L->M[TILE + tid] : 0;
 						Mo[TILE + 4 + tid] = 0;
 					}
 					/* (the minimum match length of tile nxt was estimated a
@@ -2940,13 +3056,43 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						 * step(p) is a pure function of M[p..p+2]; the chosen
 						 * tokens are the positions reachable from the entry
 						 * point by p -> p + step(p); idx = p + 4 */
+						if (tail_n)	/* its steps follow round B's last generation */
+							wait_lds_eq(L, V_ST2DONE, TILE / 64);
 						__builtin_amdgcn_s_setprio(3);
 						parse_and_base(L, tokg, t, limit, mode, nice, lane);
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						if (lane == 0)
 							*(volatile AS3 u32 *)&L->vars[V_PFLAG] = it;
 						__builtin_amdgcn_s_setprio(0);
+						/* (the entries the next tile's first parse takes over
+						 * from this one may have changed until now) */
+						if (tail_n && nxt_real && lane < 4)
+							Mo[lane] = L->M[TILE + lane];
 						PROF_W(26);
+					} else if (RB_DEFER && tail_n && wave <= RB_TAIL_WAVES) {
+						/* ---- round B's last generation, deferred (waves 1 ..
+						 * RB_TAIL_WAVES; wave 0 stays free to start the final
+						 * parse the moment its steps are there: with a batch of
+						 * its own it measured 0.6 % slower): beside the shallow
+						 * search of tile nxt.  Phase X has staged the input of
+						 * the tile after nxt and inserts it meanwhile, over the
+						 * oldest tile of the window round B had: these items
+						 * search with the window of tile nxt ---- */
+						__builtin_amdgcn_s_setprio(2);
+						if (64 * (wave - 1) < tail_n) {
+							u32 nx;
+							(void)rb_batch(L, t, n, lo_nxt, ml_cur, rb_trim_depth(depth), nice,
+								       tail_e, tail_e != 0, tail_gen, lane, &nx);
+						}
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0)
+							atomicAdd((u32 *)&L->vars[V_TAILDONE], 1u);
+						/* (all of them share the steps: a tail of one batch
+						 * would leave one wave with the whole tile's - measured
+						 * 6 % slower than no deferral at all) */
+						wait_lds_eq(L, V_TAILDONE, RB_TAIL_WAVES);
+						stage_steps_cur_claimed(L, limit, mode, nice, lane);
+						__builtin_amdgcn_s_setprio(0);
 					}
 					/* ---- S3 round A: tile nxt ---- */
 					if (nxt_real) {
