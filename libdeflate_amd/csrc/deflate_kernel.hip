@@ -38,8 +38,9 @@
  *       only the positions that parse visited are searched to the full depth
  *       (depth / nice length per level as lib/deflate_compress.c:3927-3979),
  *       in packed generations of growing quanta of chain steps
- *       (build_worklist, search_queue).  Levels 10-12 search every position
- *       (search_items);
+ *       (build_worklist, search_queue); the last generation - few items, long
+ *       chains - runs inside phase X beside the next tile's round A
+ *       (rb_batch).  Levels 10-12 search every position (search_items);
  *   S4  the greedy / lazy / lazy2 choice is a pure function of the
  *       per-position results (rules of deflate_compress.c:2573-2575,
  *       2712-2755): steps position-parallel (stage_steps), the path by one
@@ -2760,11 +2761,15 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 		 * issue slots meanwhile; the step bitmaps and the FIRST parse of
 		 * tile nxt follow inside the same phase as soon as its groups are
 		 * searched, and the split statistics of cur as soon as its tokens
-		 * are out.  The search results of tile nxt land in MX (the LDS of
+		 * are out; the last generation of tile cur's deep search, when it
+		 * was deferred (search_queue()), runs at the head of the phase on
+		 * waves 1 .. RB_TAIL_WAVES, which then compute the final parse's
+		 * steps - wave 0 waits for those instead of starting at once.  The
+		 * search results of tile nxt land in MX (the LDS of
 		 * the round-B lists and the bit staging area, both idle in that
 		 * phase) and move to M[] at the top of the next iteration.  The
 		 * hand-overs inside the phase are LDS words polled with s_sleep
-		 * (V_PFLAG, rdy[], V_STDONE, V_EMDONE): every wait is for work that
+		 * (V_PFLAG, rdy[], V_STDONE, V_EMDONE, V_TAILDONE, V_ST2DONE): every wait is for work that
 		 * some wave is already doing or will do without waiting itself.
 		 * Iteration 0 has no cur: it inserts tile 0 and runs phase X for
 		 * tile 0 alone; dictionary tiles (segment mode) are only inserted.
