@@ -150,6 +150,8 @@
 #ifndef RB_TAIL_WAVES
 #define RB_TAIL_WAVES 8u	/* waves 1..8 take a deferred generation: at most 512 items */
 #endif
+static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
+	      "wave 0 parses, the last two waves insert: the tail waves lie between them");
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
 #endif
@@ -248,8 +250,10 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 enum {
 	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
 	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_UNUSED0,
-	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE, V_TAILDONE, V_CTR4, V_ST2DONE
+	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE, V_TAILDONE, V_CTR4, V_ST2DONE,
+	V_COUNT
 };
+static_assert(V_COUNT <= sizeof(((struct deflate_lds *)0)->vars) / sizeof(u32), "vars[] holds them all");
 
 /* depth classes of the progressive search (done[]): what a position has been
  * searched with so far */
@@ -2861,6 +2865,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 							 * list (the next tile's search results take the
 							 * list's LDS in phase X) for a register of the
 							 * waves that will walk them */
+							/* (0 = no item: an entry carries its depth class,
+							 * DC_HALF or DC_FULL, in bits 12-13) */
 							if (tail_n && wave >= 1 && wave <= RB_TAIL_WAVES) {
 								const u32 k = 64 * (wave - 1) + lane;
 								tail_e = k < tail_n ? tl[k] : 0;
