@@ -624,3 +624,24 @@ def test_output_is_deterministic(level):
     c1.close()
     c2.close()
     assert a == b == c
+
+
+def test_streams_are_the_recorded_ones():
+    """The bytes this library produces are not pinned by the reference
+    (libdeflate.h:76-83), but they are a pure function of the input and the
+    build: `tools/digest_deflate.py --quick` (a fixed seeded input set at levels
+    1, 6, 9, 12 through both compress kernels and the segmented path, every
+    stream decoded by zlib) must print the digests recorded in
+    tests/golden/digest_quick.txt for this build.  A change of a kernel's
+    schedule keeps them; a change of policy regenerates the file (and says in
+    DESIGN.md what it did to the sizes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "digest_deflate.py"), "--quick"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    got = [l for l in r.stdout.splitlines() if l.startswith("L")]
+    want = open(os.path.join(root, "tests", "golden", "digest_quick.txt")).read().splitlines()
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert got == want, "\n".join(l for l in got if l not in want)
