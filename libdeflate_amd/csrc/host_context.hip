@@ -227,7 +227,8 @@ void PinnedPair::release()
  * small pool that is started on first use and shared by all objects (a thread
  * per slice and call cost 20-30 us each to create - as much as the copy of a
  * 4 MiB slice takes).  The workers are detached and never joined: they sleep
- * on a condition variable between calls; a forked child starts its own.
+ * on a condition variable between calls; a forked child starts its own (see
+ * host_pool()).
  */
 namespace {
 
@@ -275,16 +276,37 @@ struct HostPool {
 	}
 };
 
-HostPool *g_pool;
+/* The pool is never freed: its workers outlive static destruction, and the
+ * library is linked -z nodelete (Makefile), so a dlclose() by a plugin host
+ * cannot unmap the text they sleep in.  A forked child has none of the
+ * parent's threads: its fork handler only drops the pointer (nothing that
+ * allocates or locks may run there - the child of a multi-threaded process
+ * is restricted to async-signal-safe calls), and the child's first use builds
+ * a pool of its own. */
+std::atomic<HostPool *> g_pool{nullptr};
+std::mutex g_pool_mu;
 std::once_flag g_pool_once;
 
 HostPool *host_pool()
 {
+	HostPool *p = g_pool.load(std::memory_order_acquire);
+	if (p)
+		return p;
 	std::call_once(g_pool_once, [] {
-		g_pool = new HostPool;	/* never freed: the workers outlive static destruction */
-		(void)pthread_atfork(nullptr, nullptr, [] { g_pool = new HostPool; });
+		(void)pthread_atfork(nullptr, nullptr,
+				     [] {
+					     g_pool.store(nullptr, std::memory_order_relaxed);
+					     /* (a parent thread may have held it at the fork) */
+					     new (&g_pool_mu) std::mutex;
+				     });
 	});
-	return g_pool;
+	std::lock_guard<std::mutex> lk(g_pool_mu);
+	p = g_pool.load(std::memory_order_acquire);
+	if (!p) {
+		p = new HostPool;
+		g_pool.store(p, std::memory_order_release);
+	}
+	return p;
 }
 
 struct Join {

@@ -230,7 +230,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		/* raw bytes the kernels may read; chunks of a partial window end a few
 		 * KiB in front of that (a round stages up to 3 KiB ahead, a header 704
 		 * bytes) */
-		const uint64_t win_n = whole ? raw_n : copied - hdr;
+		/* (never the footer: a partial window that ends inside it would let a
+		 * run of stored blocks be walked past the end of the raw stream, which
+		 * the reference - it hands the decoder in_nbytes - hdr - ftr bytes -
+		 * rejects) */
+		const uint64_t win_n = whole ? raw_n : std::min<uint64_t>(copied - hdr, raw_n);
 		dev_n = win_n;
 		const uint64_t R1 = whole ? raw_bits : 8 * (win_n > 8192 ? win_n - 8192 : 0);
 		S[14]++;
@@ -547,6 +551,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	}
 	offs[na] = total;
 	const uint64_t end_bit = accr[na - 1].end_bit;
+	if (end_bit > raw_bits) {
+		/* a chain that closes beyond the raw stream (inside the footer): the
+		 * sequential kernel decides what the reference would say, and the
+		 * footer is never read at f = in + hdr + consumed past the buffer */
+		S[1] = WHY_NOFINAL;
+		return false;
+	}
 	if (total > out_avail) {
 		S[1] = WHY_SPACE;
 		return false;
@@ -644,8 +655,12 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			if (longest > 32768) {
 				const unsigned gx = (unsigned)std::min<uint64_t>(
 					(longest - 32768 + 2047) / 2048, 64);
-				hipLaunchKernelGGL(lda_stream_resolve_kernel, dim3(gx, na), dim3(256),
-						   0, s_comp, na, d_off, d_sym, d_out, d_cnt + 2);
+				/* (grid.y <= 65535: a window of small blocks can have more
+				 * chunks than that) */
+				for (uint32_t c0 = 0; c0 < na; c0 += 32768)
+					hipLaunchKernelGGL(lda_stream_resolve_kernel,
+							   dim3(gx, std::min<uint32_t>(32768, na - c0)), dim3(256),
+							   0, s_comp, na, c0, d_off, d_sym, d_out, d_cnt + 2);
 			}
 		}
 		ST_TRY(hipGetLastError());

@@ -1405,7 +1405,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 						nlit = 288;
 						noff = 32;
 						state = ST_TABLES;
-						static_loaded = true;	/* taken back if the build fails */
+						static_loaded = true;	/* taken back if the build fails (ST_TABLES) */
 					}
 				} else {
 					/* dynamic header: decompress_template.h:85-245 (its
@@ -1519,6 +1519,9 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					} else {
 						result = LDA_BAD_DATA;
 						state = ST_DONE;
+						/* (the tables are no code's now; the stream ends
+						 * here, but the flag must not outlive them) */
+						static_loaded = false;
 					}
 				}
 			}

@@ -1262,11 +1262,12 @@ lda_stream_window_link_kernel(u32 groups, const u16 *__restrict__ gwin,
 
 /* everything in front of a chunk's tail, 8 symbols per thread */
 extern "C" __global__ void __launch_bounds__(256)
-lda_stream_resolve_kernel(u32 nchunks, const u64 *__restrict__ out_off,
+lda_stream_resolve_kernel(u32 nchunks, u32 chunk0, const u64 *__restrict__ out_off,
 			  const u16 *__restrict__ sym, u8 *__restrict__ out,
 			  u32 *__restrict__ err)
 {
-	const u32 c = blockIdx.y;
+	/* (grid.y is limited to 65535: the host launches batches of chunks) */
+	const u32 c = chunk0 + blockIdx.y;
 	if (c >= nchunks)
 		return;
 	const u64 s = out_off[c], e = out_off[c + 1];

@@ -64,8 +64,8 @@ lda_stream_window_kernel(uint32_t nchunks, uint32_t per_group, uint32_t phase,
 extern "C" __global__ void
 lda_stream_window_link_kernel(uint32_t groups, const uint16_t *gwin, uint8_t *fwin);
 extern "C" __global__ void
-lda_stream_resolve_kernel(uint32_t nchunks, const uint64_t *out_off, const uint16_t *sym,
-			  uint8_t *out, uint32_t *err);
+lda_stream_resolve_kernel(uint32_t nchunks, uint32_t chunk0, const uint64_t *out_off,
+			  const uint16_t *sym, uint8_t *out, uint32_t *err);
 extern "C" size_t lda_stream_chunk_lds(void);
 extern "C" size_t lda_stream_find_b_lds(void);
 extern "C" size_t lda_stream_tokcap(void);	/* u32 words of token scratch per decode wave */

@@ -342,6 +342,42 @@ def stored_then_match_streams():
     return out
 
 
+def static_dynamic_static_streams():
+    """[static][empty stored][dynamic (zlib)][empty stored][static, final]: the
+    decoder keeps the static tables across the static blocks that follow one
+    another (decompress_template.h:303-311) - and must build them again after
+    a dynamic block has used the tables' memory.  The last block copies from
+    both earlier ones.  -> list of (stream, expected)."""
+    import zlib
+    out = []
+    for head, mid, (mlen, mdist), tail in [
+            (b"static one. ", b"the quick brown fox jumps over the lazy dog. " * 40, (9, 5), b" end"),
+            (b"A" * 70, bytes(range(256)) * 3 + b"abcabcabc" * 50, (200, 300), b""),
+            (b"", b"0123456789" * 200, (12, 1999), b"zz" * 40)]:
+        w = BitWriter()
+        w.put(0, 1); w.put(1, 2)                 # static block, not final
+        for b in head:
+            _static_lit(w, b)
+        _static_lit(w, 256)
+        w.put(0, 1); w.put(0, 2)                 # empty stored block: byte boundary
+        if w.n:
+            w.put(0, 8 - w.n)
+        w.put(0, 16); w.put(0xFFFF, 16)
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        for b in co.compress(mid) + co.flush(zlib.Z_FULL_FLUSH):
+            w.put(b, 8)                          # dynamic block(s) + empty stored
+        w.put(1, 1); w.put(1, 2)                 # final static block
+        sofar = bytearray(head + mid)
+        _static_match(w, mlen, mdist)
+        for _ in range(mlen):
+            sofar.append(sofar[-mdist])
+        for b in tail:
+            _static_lit(w, b)
+        _static_lit(w, 256)
+        out.append((w.finish(), bytes(sofar) + tail))
+    return out
+
+
 def gzip_optional_field_streams():
     """VALID gzip members that carry FEXTRA / FNAME / FCOMMENT / FHCRC in every
     combination (lib/gzip_decompress.c:69-100 skips them) -> (stream, data)."""

@@ -375,6 +375,23 @@ def test_stored_block_then_short_match(dec, oracle, monkeypatch):
             assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
 
 
+def test_static_tables_after_a_dynamic_block(dec, oracle, monkeypatch):
+    """static -> stored -> dynamic -> stored -> static: the static tables are
+    kept across static blocks and rebuilt after a dynamic block took their
+    memory (`static_loaded`), in both mappings."""
+    cases = []
+    for i, (s, want) in enumerate(streams.static_dynamic_static_streams()):
+        cases.append(("deflate", s, len(want), True, f"sds{i}"))
+        cases.append(("deflate", s, len(want), False, f"sds{i}/exact"))
+        cases.append(("deflate", s[:-3], len(want), True, f"sds{i}/cut"))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()
+        _run_cases(dec, oracle, cases)
+        for i, (s, want) in enumerate(streams.static_dynamic_static_streams()):
+            assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
+
+
 def test_parallel_round_corner_streams(dec, oracle, monkeypatch):
     """Streams aimed at the wave-per-stream rounds (more tokens in a piece
     than a lane records, copies inside a 64-byte slot, sources older than the

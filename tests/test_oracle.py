@@ -200,6 +200,11 @@ def test_stored_then_match_and_gzip_fields(oracle, ref):
         assert zlib.decompress(s, -15) == want
         for chk in (oracle, ref):
             assert chk.decompress_ex("deflate", s, len(want)) == (0, len(s), len(want), want)
+    for s, want in streams.static_dynamic_static_streams():
+        assert zlib.decompress(s, -15) == want
+        for chk in (oracle, ref):
+            assert chk.decompress_ex("deflate", s, len(want)) == (0, len(s), len(want), want)
+            assert chk.decompress_ex("deflate", s[:-3], len(want))[0] != 0
     for s, want in streams.gzip_optional_field_streams():
         assert zlib.decompress(s, 31) == want
         for chk in (oracle, ref):

@@ -228,6 +228,40 @@ def test_input_windows(dec, comp, oracle, monkeypatch):
             assert got[0] == oracle.decompress_ex("gzip", z[:cut], len(data))[0]
 
 
+def test_stored_run_into_the_footer(dec, oracle, monkeypatch):
+    """A partial input window that ends INSIDE the gzip footer, and a final
+    stored block whose LEN reaches into that footer: the reference hands its
+    decoder in_nbytes - header - footer bytes and says BAD_DATA; the many-wave
+    path must not count the block as the stream's end (nor read the footer
+    behind the caller's buffer) - the oracle's code either way.  The honest
+    stream of the same shape decodes."""
+    import struct
+    monkeypatch.setenv("LDA_STREAM_WINDOW", "32768")
+    monkeypatch.setenv("LDA_STREAM_PAR_MIN", "0")
+    binding.reload_env()
+    rng = np.random.default_rng(0xF007)
+    for t in range(1, 8):
+        for over in (0, 1, t, 8):
+            raw_len = 32768 - t         # the window ends t bytes into the footer
+            payload, raw = bytearray(), bytearray()
+            while raw_len - len(raw) > 5 + 1000:
+                blk = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
+                raw += b"\x00" + struct.pack("<HH", 1000, 1000 ^ 0xFFFF) + blk
+                payload += blk
+            k = raw_len - len(raw) - 5
+            blk = rng.integers(0, 256, k, dtype=np.uint8).tobytes()
+            raw += b"\x01" + struct.pack("<HH", k + over, (k + over) ^ 0xFFFF) + blk
+            payload += blk
+            assert len(raw) == raw_len
+            z = (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + bytes(raw) +
+                 struct.pack("<II", zlib.crc32(bytes(payload)), len(payload)))
+            got = dec.decompress_ex("gzip", z, len(payload) + 64)
+            exp = oracle.decompress_ex("gzip", z, len(payload) + 64)
+            assert got[0] == exp[0], (t, over, got[:3], exp[:3], binding.stream_stats())
+            if over == 0:
+                assert exp[0] == 0 and got[1:] == (len(z), len(payload), bytes(payload))
+
+
 def test_members_one_after_the_other(dec, comp):
     """programs/gzip.c:236-299: the caller hands the rest of the file to every
     call; a member that ends inside the first window must not make the library
