@@ -213,6 +213,26 @@ LIBDEFLATEAPI void
 libdeflate_amd_reload_env(void);
 
 /*
+ * Devices.  An object (compressor / decompressor) belongs to the HIP device
+ * that was current when it was allocated; every call that takes the object
+ * runs there, whatever device the calling thread has current, and puts the
+ * caller's device back (libdeflate.h has no notion of a device).  The
+ * device-pointer batch calls expect their buffers and their stream on the
+ * object's device.
+ *
+ * The host-pointer batch calls (libdeflate_amd_*_batch_host) can use every GPU
+ * of the node from ONE object: with LDA_DEVICES=all (or =N) in the environment
+ * a batch is cut into contiguous shards of about equal byte counts, shard k
+ * runs on visible device (own + k) through an object and a host thread of its
+ * own, and every result lands where the caller asked for it - host order, no
+ * gather.  Unset (the default) or one visible GPU: one shard, the
+ * single-device path.  Returns the shards the calling thread's last
+ * host-pointer batch was spread over.
+ */
+LIBDEFLATEAPI size_t
+libdeflate_amd_last_fanout(void);
+
+/*
  * Chunk i of a batch occupies bytes [offsets[i], offsets[i] + nbytes[i]) of a
  * base buffer.  `d_` pointers are device pointers.  Offsets/sizes are u64 so
  * the same descriptors serve 4 KiB filesystem blocks and multi-GiB buffers.

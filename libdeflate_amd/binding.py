@@ -46,7 +46,7 @@ BATCH_SYMBOLS = [
     "libdeflate_amd_decompress_batch_host",
     "libdeflate_amd_compact_offsets_len", "libdeflate_amd_compact_batch",
     "libdeflate_amd_gzip_decompress_members",
-    "libdeflate_amd_stream_stats",
+    "libdeflate_amd_stream_stats", "libdeflate_amd_last_fanout",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load():
         P, P, P, P)
     sig("libdeflate_amd_gzip_decompress_members", c_int, P, P, SZ, P, SZ, psz, psz, psz)
     sig("libdeflate_amd_stream_stats", None, POINTER(c_uint64))
+    sig("libdeflate_amd_last_fanout", c_size_t)
     sig("libdeflate_amd_compact_offsets_len", SZ, SZ)
     sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib
@@ -126,6 +127,11 @@ def reload_env():
     """Have the library read its LDA_* tuning switches again (it reads them
     once, at load)."""
     load().libdeflate_amd_reload_env()
+
+
+def last_fanout():
+    """shards (devices) the calling thread's last host-pointer batch used"""
+    return int(load().libdeflate_amd_last_fanout())
 
 
 def stream_stats():

@@ -45,6 +45,26 @@ struct DeviceCtx {
 /* context of the calling thread's current device; nullptr (+error) if none */
 DeviceCtx *device_ctx();
 
+/*
+ * An object belongs to the device that was current when it was allocated (its
+ * scratch, staging and streams live there).  Every entry point that takes an
+ * object makes that device current for its duration and puts the caller's
+ * back: a caller that drives several GPUs from one thread - or calls with
+ * another device current - launches where the object's memory is, not where
+ * the thread happens to point (libdeflate.h has no notion of a device: the
+ * drop-in must not grow one).  ok() == false: the device could not be made
+ * current (the reason is in libdeflate_amd_last_error()).
+ */
+struct DeviceGuard {
+	int prev = -1;
+	bool switched = false, good = true;
+	explicit DeviceGuard(int device);
+	~DeviceGuard();
+	bool ok() const { return good; }
+	DeviceGuard(const DeviceGuard &) = delete;
+	DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 /* the environment switches (tuning aids), read ONCE per
  * process at the first use - not per call */
 struct EnvCfg {
@@ -59,6 +79,8 @@ struct EnvCfg {
 	size_t stream_par_min = 16384;	/* LDA_STREAM_PAR_MIN: smallest stream (bytes in) for the many-wave path */
 	size_t stream_window = 0;	/* LDA_STREAM_WINDOW: first input window of that path (0 = 4 MiB) */
 	size_t stream_chunk = 0;	/* LDA_STREAM_CHUNK: input bytes per chunk of that path (0 = by size) */
+	int devices = 1;		/* LDA_DEVICES: GPUs a host-pointer batch is spread over (N, or "all" = -1) */
+	bool fanout_oversub = false;	/* LDA_FANOUT_OVERSUB: more shards than visible devices (a test aid: several shards share a GPU) */
 };
 const EnvCfg &env_cfg();
 

@@ -72,7 +72,12 @@ libdeflate_alloc_compressor_ex(int level, const struct libdeflate_options *optio
 		return NULL;
 	struct libdeflate_compressor *c = new (mem) libdeflate_compressor();
 	c->free_func = f;
+	c->malloc_func = m;
 	c->level = level;
+	c->device = 0;
+	(void)hipGetDevice(&c->device);	/* (device_ctx() above has seen it work) */
+	for (int k = 0; k < LDA_MAX_SHARDS; k++)
+		c->shard[k] = NULL;
 	return c;
 }
 
@@ -87,6 +92,9 @@ libdeflate_free_compressor(struct libdeflate_compressor *c)
 {
 	if (!c)
 		return;
+	for (int k = 0; k < LDA_MAX_SHARDS; k++)
+		libdeflate_free_compressor(c->shard[k]);
+	DeviceGuard on(c->device);
 	c->scratch.release();
 	c->stage.release();
 	c->pinned.release();
@@ -130,6 +138,13 @@ compress_batch_impl(struct libdeflate_compressor *c, int format, size_t n,
 		    uint64_t *d_out_nbytes, void *stream,
 		    const uint32_t *d_seg_info, size_t max_in_nbytes = SIZE_MAX)
 {
+	if (!c) {
+		set_error("compress_batch: bad argument");
+		return LIBDEFLATE_AMD_BAD_ARG;
+	}
+	DeviceGuard on(c->device);
+	if (!on.ok())
+		return LIBDEFLATE_AMD_NO_DEVICE;
 	DeviceCtx *ctx = device_ctx();
 	hipStream_t st = (hipStream_t)stream;
 
@@ -239,8 +254,41 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 				   const size_t *out_avail, size_t *out_nbytes)
 {
 	return no_unwind("compress_batch_host", (int)LIBDEFLATE_AMD_OOM, [&]() {
-		return compress_batch_host_body(c, format, n, in, in_nbytes, out, out_avail,
-						out_nbytes);
+		if (!c || !in_nbytes || n == 0)
+			return compress_batch_host_body(c, format, n, in, in_nbytes, out, out_avail,
+							out_nbytes);
+		/* several GPUs (LDA_DEVICES, host_fanout.hip): contiguous shards,
+		 * an object and a host thread per device, results in place */
+		size_t bounds[LDA_MAX_SHARDS + 1];
+		int devs[LDA_MAX_SHARDS];
+		const size_t shards = fanout_plan(c->device, n, in_nbytes, bounds, devs);
+		fanout_note(shards);
+		if (shards < 2)
+			return compress_batch_host_body(c, format, n, in, in_nbytes, out, out_avail,
+							out_nbytes);
+		if (!in || !out || !out_avail || !out_nbytes) {
+			set_error("compress_batch_host: NULL argument");
+			return (int)LIBDEFLATE_AMD_BAD_ARG;
+		}
+		for (size_t k = 1; k < shards; k++) {
+			if (c->shard[k])
+				continue;
+			DeviceGuard on(devs[k]);
+			struct libdeflate_options o = {};
+			o.sizeof_options = sizeof(o);
+			o.malloc_func = c->malloc_func;
+			o.free_func = c->free_func;
+			if (on.ok())
+				c->shard[k] = libdeflate_alloc_compressor_ex(c->level, &o);
+			if (!c->shard[k])
+				return (int)LIBDEFLATE_AMD_NO_DEVICE;
+		}
+		return fanout_run(shards, [&](size_t k) {
+			const size_t lo = bounds[k], cnt = bounds[k + 1] - lo;
+			return compress_batch_host_body(k ? c->shard[k] : c, format, cnt, in + lo,
+							in_nbytes + lo, out + lo, out_avail + lo,
+							out_nbytes + lo);
+		});
 	});
 }
 
@@ -249,14 +297,15 @@ static int compress_batch_host_body(struct libdeflate_compressor *c, int format,
 				   const size_t *in_nbytes, void *const *out,
 				   const size_t *out_avail, size_t *out_nbytes)
 {
-	if (!device_ctx())
-		return LIBDEFLATE_AMD_NO_DEVICE;
 	if (n == 0)
-		return LIBDEFLATE_AMD_OK;
+		return device_ctx() ? LIBDEFLATE_AMD_OK : LIBDEFLATE_AMD_NO_DEVICE;
 	if (!c || !in || !in_nbytes || !out || !out_avail || !out_nbytes) {
 		set_error("compress_batch_host: NULL argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
+	DeviceGuard on(c->device);
+	if (!on.ok() || !device_ctx())
+		return LIBDEFLATE_AMD_NO_DEVICE;
 	/* The batch goes through in SLICES (up to 8, >= 64 MiB of input each - a
 	 * slice has to fill the GPU several times over, or its kernel's tail
 	 * costs more than the overlap gives: 8 MiB slices measured slower than
@@ -663,6 +712,13 @@ static size_t compress_one(struct libdeflate_compressor *c, int format,
 			   const void *in, size_t in_nbytes, void *out,
 			   size_t out_avail)
 {
+	if (!c)
+		return 0;
+	DeviceGuard on(c->device);
+	if (!on.ok()) {
+		complain("libdeflate_*_compress", LIBDEFLATE_AMD_NO_DEVICE);
+		return 0;
+	}
 	/* (inputs of 4 GiB and more always take this path: the kernels index a
 	 * chunk with 32 bits, the segments are 64 KiB each) */
 	if (in_nbytes >= LDA_LARGE_MIN && c->level > 0 &&

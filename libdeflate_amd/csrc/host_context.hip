@@ -80,6 +80,16 @@ static EnvCfg read_env()
 	}
 	if (const char *e = getenv("LDA_STREAM_CHUNK"))
 		c.stream_chunk = (size_t)strtoull(e, nullptr, 0);
+	if (const char *e = getenv("LDA_DEVICES")) {
+		if (!strcmp(e, "all")) {
+			c.devices = -1;
+		} else {
+			int v = atoi(e);
+			if (v >= 1 && v <= 16)
+				c.devices = v;
+		}
+	}
+	c.fanout_oversub = getenv("LDA_FANOUT_OVERSUB") != nullptr;
 	return c;
 }
 
@@ -579,6 +589,27 @@ static void gen_crc_tables(uint32_t *tab /*17*256*/, uint32_t *xpow /*1024*/)
 		for (int k = 0; k < 8; k++)
 			x = (x >> 1) ^ (poly & (0u - (x & 1u)));
 	}
+}
+
+DeviceGuard::DeviceGuard(int device)
+{
+	hipError_t e = hipGetDevice(&prev);
+
+	if (e == hipSuccess && prev == device)
+		return;
+	e = hipSetDevice(device);
+	if (e != hipSuccess) {
+		set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+		good = false;
+		return;
+	}
+	switched = true;
+}
+
+DeviceGuard::~DeviceGuard()
+{
+	if (switched && prev >= 0)
+		(void)hipSetDevice(prev);
 }
 
 DeviceCtx *device_ctx()

@@ -96,6 +96,11 @@ libdeflate_alloc_decompressor_ex(const struct libdeflate_options *options)
 	struct libdeflate_decompressor *d =
 		new (mem) libdeflate_decompressor();
 	d->free_func = f;
+	d->malloc_func = m;
+	d->device = 0;
+	(void)hipGetDevice(&d->device);	/* (device_ctx() above has seen it work) */
+	for (int k = 0; k < LDA_MAX_SHARDS; k++)
+		d->shard[k] = NULL;
 	return d;
 }
 
@@ -110,6 +115,9 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 {
 	if (!d)
 		return;
+	for (int k = 0; k < LDA_MAX_SHARDS; k++)
+		libdeflate_free_decompressor(d->shard[k]);
+	DeviceGuard on(d->device);
 	d->scratch.release();
 	d->stage.release();
 	d->tokens.release();
@@ -140,6 +148,13 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 				uint64_t *d_actual_in, uint64_t *d_actual_out,
 				void *stream)
 {
+	if (!d) {
+		set_error("decompress_batch: bad argument");
+		return LIBDEFLATE_AMD_BAD_ARG;
+	}
+	DeviceGuard on(d->device);
+	if (!on.ok())
+		return LIBDEFLATE_AMD_NO_DEVICE;
 	DeviceCtx *c = device_ctx();
 	hipStream_t st = (hipStream_t)stream;
 
@@ -265,8 +280,43 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 				     size_t *actual_in, size_t *actual_out)
 {
 	return no_unwind("decompress_batch_host", (int)LIBDEFLATE_AMD_OOM, [&]() {
-		return decompress_batch_host_body(d, format, n, in, in_nbytes, out, out_avail,
-						  results, actual_in, actual_out);
+		if (!d || !out_avail || n == 0)
+			return decompress_batch_host_body(d, format, n, in, in_nbytes, out, out_avail,
+							  results, actual_in, actual_out);
+		/* several GPUs (LDA_DEVICES, host_fanout.hip): shards of about equal
+		 * OUTPUT (what a stream costs to decode), an object and a host thread
+		 * per device, results in place */
+		size_t bounds[LDA_MAX_SHARDS + 1];
+		int devs[LDA_MAX_SHARDS];
+		const size_t shards = fanout_plan(d->device, n, out_avail, bounds, devs);
+		fanout_note(shards);
+		if (shards < 2)
+			return decompress_batch_host_body(d, format, n, in, in_nbytes, out, out_avail,
+							  results, actual_in, actual_out);
+		if (!in || !in_nbytes || !out || !results) {
+			set_error("decompress_batch_host: NULL argument");
+			return (int)LIBDEFLATE_AMD_BAD_ARG;
+		}
+		for (size_t k = 1; k < shards; k++) {
+			if (d->shard[k])
+				continue;
+			DeviceGuard on(devs[k]);
+			struct libdeflate_options o = {};
+			o.sizeof_options = sizeof(o);
+			o.malloc_func = d->malloc_func;
+			o.free_func = d->free_func;
+			if (on.ok())
+				d->shard[k] = libdeflate_alloc_decompressor_ex(&o);
+			if (!d->shard[k])
+				return (int)LIBDEFLATE_AMD_NO_DEVICE;
+		}
+		return fanout_run(shards, [&](size_t k) {
+			const size_t lo = bounds[k], cnt = bounds[k + 1] - lo;
+			return decompress_batch_host_body(k ? d->shard[k] : d, format, cnt, in + lo,
+							  in_nbytes + lo, out + lo, out_avail + lo,
+							  results + lo, actual_in ? actual_in + lo : NULL,
+							  actual_out ? actual_out + lo : NULL);
+		});
 	});
 }
 
@@ -277,14 +327,15 @@ static int decompress_batch_host_body(struct libdeflate_decompressor *d,
 				     const size_t *out_avail, int32_t *results,
 				     size_t *actual_in, size_t *actual_out)
 {
-	if (!device_ctx())
-		return LIBDEFLATE_AMD_NO_DEVICE;
 	if (n == 0)
-		return LIBDEFLATE_AMD_OK;
+		return device_ctx() ? LIBDEFLATE_AMD_OK : LIBDEFLATE_AMD_NO_DEVICE;
 	if (!d || !in || !in_nbytes || !out || !out_avail || !results) {
 		set_error("decompress_batch_host: NULL argument");
 		return LIBDEFLATE_AMD_BAD_ARG;
 	}
+	DeviceGuard on(d->device);
+	if (!on.ok() || !device_ctx())
+		return LIBDEFLATE_AMD_NO_DEVICE;
 	/* In slices like libdeflate_amd_compress_batch_host(): the kernels of
 	 * slice k (compute stream) run while the host packs and sends slice k + 1
 	 * and unpacks slice k - 1 (copy stream).  Slices of at least 256 MiB of
@@ -407,6 +458,14 @@ decompress_one(struct libdeflate_decompressor *d, int format, const void *in,
 	void *outs[1] = { out };
 	int32_t res = LIBDEFLATE_BAD_DATA;
 	size_t ain = 0, aout = 0;
+	if (!d)
+		return LIBDEFLATE_BAD_DATA;
+	/* (a single stream never fans out: it is one device's work) */
+	DeviceGuard on(d->device);
+	if (!on.ok()) {
+		complain("libdeflate_*_decompress", LIBDEFLATE_AMD_NO_DEVICE);
+		return LIBDEFLATE_BAD_DATA;	/* see below: a library-side failure */
+	}
 	/* a large stream: many waves (host_stream.hip); it answers only for what
 	 * it decoded cleanly, everything else goes on to the sequential kernel */
 	if (d && in && out &&

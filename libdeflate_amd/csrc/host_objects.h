@@ -10,6 +10,7 @@
 #define LDA_HOST_OBJECTS_H
 
 #include "host_common.h"
+#include <functional>
 
 namespace lda {
 
@@ -29,8 +30,15 @@ struct DevBuf {
 
 } /* namespace lda */
 
+#define LDA_MAX_SHARDS 16	/* devices one host-pointer batch is spread over */
+
 struct libdeflate_decompressor {
 	lda::free_func_t free_func;
+	lda::malloc_func_t malloc_func;
+	int device;		/* the device the object lives on (current at allocation) */
+	/* host-pointer batches over several GPUs (LDA_DEVICES): one more object
+	 * per further device, built on first use, freed with this one */
+	struct libdeflate_decompressor *shard[LDA_MAX_SHARDS];
 	lda::DevBuf scratch;	/* per-chunk u32 sums + u64 actual_in/out */
 	lda::DevBuf stage;	/* host-pointer entry points */
 	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
@@ -44,6 +52,9 @@ struct libdeflate_decompressor {
 
 struct libdeflate_compressor {
 	lda::free_func_t free_func;
+	lda::malloc_func_t malloc_func;
+	int device;		/* the device the object lives on (current at allocation) */
+	struct libdeflate_compressor *shard[LDA_MAX_SHARDS];	/* see libdeflate_decompressor */
 	int level;
 	lda::DevBuf scratch;	/* parse/encode workspace + per-chunk sums */
 	lda::DevBuf stage;
@@ -53,6 +64,15 @@ struct libdeflate_compressor {
 };
 
 namespace lda {
+/* host_fanout.hip: the devices a host-pointer batch of n chunks is spread over
+ * (1 = the object's own device only), and the plan: shard k takes the chunks
+ * [bounds[k], bounds[k+1]) on device devs[k] */
+size_t fanout_plan(int own_device, size_t n, const size_t *nbytes, size_t *bounds, int *devs);
+void fanout_note(size_t shards);	/* what libdeflate_amd_last_fanout() reports */
+/* run fn(k) for k = 1 .. shards-1 on threads of their own and fn(0) on the
+ * calling one; returns the first non-OK status */
+int fanout_run(size_t shards, const std::function<int(size_t)> &fn);
+
 /* host_stream.hip: true = answered (result, sizes, output); false = the
  * caller takes the sequential path */
 bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,

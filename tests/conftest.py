@@ -32,7 +32,8 @@ def ref():
 
 _LDA_SWITCHES = ("LDA_INFLATE_PAR", "LDA_INFLATE_LPW", "LDA_INFLATE_WAVES_PER_CU",
                  "LDA_NO_SMALL", "LDA_NO_SEGMENTS", "LDA_HOST_THREADS",
-                 "LDA_NO_STREAM_PAR", "LDA_STREAM_PAR_MIN")
+                 "LDA_NO_STREAM_PAR", "LDA_STREAM_PAR_MIN", "LDA_STREAM_WINDOW",
+                 "LDA_STREAM_CHUNK", "LDA_DEVICES", "LDA_FANOUT_OVERSUB")
 
 
 @pytest.fixture(autouse=True)

@@ -59,6 +59,28 @@ def test_bench_two_ranks_one_device():
     assert "end_to_end" in line                     # rank 0 only
 
 
+def test_bench_eight_ranks_one_device():
+    """the world size of a full node: eight ranks share cuda:0 (small batches,
+    so that it stays under a minute); n_gpus 8, eight partitions that add up,
+    eight verdict vectors at rank 0"""
+    streams, blocks, chunks = 1024, 16384, 64
+    line = _run(["--gpus", "8", "--backend", "gloo", "--one-device", "--configs", "all",
+                 "--streams", str(streams), "--blocks", str(blocks),
+                 "--chunks", str(chunks), "--steps", "2", "--warmup", "1", "--no-cpu"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["verdicts"] == {"chunks": 8 * chunks, "failed": 0}
+    cfg = line["configs"]
+    assert cfg["configs[1]"]["chunks_total"] == 8 * chunks
+    assert cfg["configs[1]"]["verdicts"] == {"chunks": 8 * chunks, "failed": 0}
+    c3 = cfg["configs[3]"]
+    assert c3["n_gpus"] == 8 and c3["streams_total"] == streams
+    assert c3["verdicts"] == {"chunks": streams, "failed": 0}
+    assert c3["verified"].startswith(f"all {streams * 65536} output bytes equal")
+    c4 = cfg["configs[4]"]
+    assert c4["n_gpus"] == 8 and c4["chunks_total"] == blocks
+    assert c4["verdicts"] == {"chunks": blocks, "failed": 0}
+
+
 def test_bench_single_rank_line_shape():
     line = _run(["--configs", "headline", "--chunks", "256", "--steps", "2",
                  "--warmup", "1", "--no-cpu"])

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2, gloo backend.  Checks the contiguous
+"""The N>1 path on CPU: world_size 2 and 8, gloo backend.  Checks the contiguous
 partition, the verdict gather and the padded payload gather that bench.py
 --gpus N runs over RCCL.  (Compute stays on the GPU; here the per-rank
 "results" are synthesized so the exchange logic is what is under test.)"""
@@ -66,6 +66,26 @@ def test_gather_world2_gloo():
         p.start()
     for p in procs:
         p.join(120)
+        assert p.exitcode == 0
+    tot, bad, ok = q.get(timeout=10)
+    assert (tot, bad, ok) == (1001, 1, True)
+
+
+def test_gather_world8_gloo():
+    """the same exchange at the world size of a full node (8 ranks): the
+    contiguous partitions add up, eight verdict vectors and eight payload
+    segments arrive at rank 0 in rank order"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
         assert p.exitcode == 0
     tot, bad, ok = q.get(timeout=10)
     assert (tot, bad, ok) == (1001, 1, True)
