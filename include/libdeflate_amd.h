@@ -233,6 +233,20 @@ LIBDEFLATEAPI size_t
 libdeflate_amd_last_fanout(void);
 
 /*
+ * The kernels rely on two hardware behaviours beyond what the ISA manual
+ * states (lane order of conflicting LDS atomics; a wave's global store being
+ * visible to its own next load).  Both are checked on every device before its
+ * first use (~1 ms, once per device and process; LDA_NO_SELFCHECK skips it):
+ * a device that deviates is refused - the allocators return NULL and
+ * libdeflate_amd_last_error() says why.  This runs the check again on the
+ * current device: out[0..4] = LDS-atomic lanes checked, of them out of order,
+ * same-instruction conflicts among them, loads checked, of them stale.
+ * Returns LIBDEFLATE_AMD_OK when the device passes.
+ */
+LIBDEFLATEAPI int
+libdeflate_amd_selfcheck(uint64_t *out /* [5], may be NULL */);
+
+/*
  * Chunk i of a batch occupies bytes [offsets[i], offsets[i] + nbytes[i]) of a
  * base buffer.  `d_` pointers are device pointers.  Offsets/sizes are u64 so
  * the same descriptors serve 4 KiB filesystem blocks and multi-GiB buffers.

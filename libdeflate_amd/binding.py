@@ -47,6 +47,7 @@ BATCH_SYMBOLS = [
     "libdeflate_amd_compact_offsets_len", "libdeflate_amd_compact_batch",
     "libdeflate_amd_gzip_decompress_members",
     "libdeflate_amd_stream_stats", "libdeflate_amd_last_fanout",
+    "libdeflate_amd_selfcheck",
 ]
 
 _lib = None
@@ -117,6 +118,7 @@ def load():
     sig("libdeflate_amd_gzip_decompress_members", c_int, P, P, SZ, P, SZ, psz, psz, psz)
     sig("libdeflate_amd_stream_stats", None, POINTER(c_uint64))
     sig("libdeflate_amd_last_fanout", c_size_t)
+    sig("libdeflate_amd_selfcheck", c_int, POINTER(c_uint64))
     sig("libdeflate_amd_compact_offsets_len", SZ, SZ)
     sig("libdeflate_amd_compact_batch", c_int, SZ, P, P, P, P, P, P)
     _lib = lib
@@ -132,6 +134,14 @@ def reload_env():
 def last_fanout():
     """shards (devices) the calling thread's last host-pointer batch used"""
     return int(load().libdeflate_amd_last_fanout())
+
+
+def selfcheck():
+    """the per-device hardware self-check again -> (status, dict of counters)"""
+    out = (c_uint64 * 5)()
+    rc = load().libdeflate_amd_selfcheck(out)
+    keys = ("lds_lanes", "lds_out_of_order", "lds_conflicts", "loads", "stale_loads")
+    return rc, dict(zip(keys, (int(x) for x in out)))
 
 
 def stream_stats():

@@ -44,6 +44,10 @@ struct DeviceCtx {
 
 /* context of the calling thread's current device; nullptr (+error) if none */
 DeviceCtx *device_ctx();
+/* the hardware self-check on the current device (selfcheck_kernels.hip):
+ * out[0..4] = lanes, order mismatches, conflicts seen, loads, stale loads;
+ * true = the device behaves as the kernels need */
+bool device_selfcheck(int num_cus, uint64_t out[5]);
 
 /*
  * An object belongs to the device that was current when it was allocated (its
@@ -80,6 +84,7 @@ struct EnvCfg {
 	size_t stream_window = 0;	/* LDA_STREAM_WINDOW: first input window of that path (0 = 4 MiB) */
 	size_t stream_chunk = 0;	/* LDA_STREAM_CHUNK: input bytes per chunk of that path (0 = by size) */
 	int devices = 1;		/* LDA_DEVICES: GPUs a host-pointer batch is spread over (N, or "all" = -1) */
+	bool no_selfcheck = false;	/* LDA_NO_SELFCHECK: skip the per-device hardware self-check */
 	bool fanout_oversub = false;	/* LDA_FANOUT_OVERSUB: more shards than visible devices (a test aid: several shards share a GPU) */
 };
 const EnvCfg &env_cfg();

@@ -90,6 +90,7 @@ static EnvCfg read_env()
 		}
 	}
 	c.fanout_oversub = getenv("LDA_FANOUT_OVERSUB") != nullptr;
+	c.no_selfcheck = getenv("LDA_NO_SELFCHECK") != nullptr;
 	return c;
 }
 
@@ -591,6 +592,46 @@ static void gen_crc_tables(uint32_t *tab /*17*256*/, uint32_t *xpow /*1024*/)
 	}
 }
 
+bool device_selfcheck(int num_cus, uint64_t out[5])
+{
+	const unsigned blocks = (unsigned)(num_cus > 0 ? num_cus : 256);
+	const unsigned waves = 16 * blocks;
+	const size_t region = lda_selfcheck_region_bytes();
+	uint8_t *buf = nullptr;
+	uint64_t *d_cnt = nullptr;
+
+	memset(out, 0, 5 * sizeof(uint64_t));
+	LDA_HIP_TRY(hipMalloc((void **)&buf, (size_t)waves * region + 64), false);
+	d_cnt = (uint64_t *)(buf + (size_t)waves * region);
+	hipError_t e = hipMemset(buf, 0, (size_t)waves * region + 64);
+	if (e == hipSuccess) {
+		/* one workgroup of 16 waves per CU hammering one LDS; 16 waves per
+		 * CU storing and loading their own regions */
+		hipLaunchKernelGGL(lda_selfcheck_lds_order_kernel, dim3(blocks), dim3(1024), 0, 0,
+				   d_cnt);
+		hipLaunchKernelGGL(lda_selfcheck_visibility_kernel, dim3(waves), dim3(64), 0, 0,
+				   buf, d_cnt);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess)
+		e = hipMemcpy(out, d_cnt, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	(void)hipFree(buf);
+	if (e != hipSuccess) {
+		set_error("hardware self-check: %s", hipGetErrorString(e));
+		return false;
+	}
+	if (out[0] == 0 || out[3] == 0 || out[1] || out[4]) {
+		set_error("hardware self-check failed: %llu of %llu LDS-atomic lanes out of lane "
+			  "order, %llu of %llu loads did not see the wave's own store - this "
+			  "device does not behave as the kernels need (deflate_kernel.hip "
+			  "insert_tile(), inflate_kernel.hip par_round())",
+			  (unsigned long long)out[1], (unsigned long long)out[0],
+			  (unsigned long long)out[4], (unsigned long long)out[3]);
+		return false;
+	}
+	return true;
+}
+
 DeviceGuard::DeviceGuard(int device)
 {
 	hipError_t e = hipGetDevice(&prev);
@@ -648,6 +689,16 @@ DeviceCtx *device_ctx()
 		set_error("hipMemcpy(CRC tables): %s", hipGetErrorString(ce));
 		return nullptr;
 	}
+	/* the hardware behaves as the kernels need?  (once per device; a device
+	 * that does not is refused: the allocators return NULL with the reason
+	 * in libdeflate_amd_last_error()) */
+	if (!env_cfg().no_selfcheck) {
+		uint64_t sc[5];
+		if (!device_selfcheck(prop.multiProcessorCount, sc)) {
+			(void)hipFree(d_tab);
+			return nullptr;
+		}
+	}
 	c->d_crc_tables = d_tab;
 	c->d_crc_xpow8 = d_tab + LDA_CRC_TABLE_WORDS;
 	c->num_cus = prop.multiProcessorCount;
@@ -676,6 +727,18 @@ void *stage_reserve(DeviceCtx *ctx, size_t nbytes)
 }
 
 } /* namespace lda */
+
+/* runs the hardware self-check again on the calling thread's current device */
+extern "C" LIBDEFLATEAPI int libdeflate_amd_selfcheck(uint64_t *out /* [5] */)
+{
+	lda::DeviceCtx *c = lda::device_ctx();
+	uint64_t tmp[5];
+
+	if (!c)
+		return LIBDEFLATE_AMD_NO_DEVICE;
+	const bool ok = lda::device_selfcheck(c->num_cus, out ? out : tmp);
+	return ok ? LIBDEFLATE_AMD_OK : LIBDEFLATE_AMD_NO_DEVICE;
+}
 
 extern "C" LIBDEFLATEAPI int libdeflate_amd_device_ready(void)
 {

@@ -100,6 +100,15 @@ lda_compact_copy_kernel(uint64_t n, const uint8_t *in_base,
 			uint8_t *out_base, uint64_t *offsets,
 			const uint64_t *block_sums);
 
+/* selfcheck_kernels.hip: the hardware behaviours the kernels rely on, checked
+ * per device (counters: [0] lanes, [1] order mismatches, [2] same-instruction
+ * conflicts seen, [3] loads, [4] stale loads) */
+extern "C" __global__ void
+lda_selfcheck_lds_order_kernel(uint64_t *counters);
+extern "C" __global__ void
+lda_selfcheck_visibility_kernel(uint8_t *buf, uint64_t *counters);
+extern "C" size_t lda_selfcheck_region_bytes(void);
+
 /* CRC constant tables, generated on the host at first use (host_context.hip) */
 #define LDA_CRC_TABLE_WORDS (17 * 256)
 #define LDA_CRC_XPOW_WORDS 1024

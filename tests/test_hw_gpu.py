@@ -37,3 +37,27 @@ def test_global_store_is_visible_to_a_following_load_of_the_wave():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["store_then_load_visible"] is True and out["stale"] == 0
     assert out["loads"] > 1_000_000_000
+
+
+def test_library_selfcheck_runs_and_passes():
+    """the short forms of the two probes run inside the library before a
+    device's first use (csrc/selfcheck_kernels.hip, device_ctx()): a device
+    that deviates is refused there, not only when this suite is run.  Here:
+    the check ran (the allocator below succeeded with it on), runs again on
+    request, saw same-instruction conflicts at all (it tests what it claims
+    to) and found nothing out of order / stale."""
+    import os
+    import time
+    from libdeflate_amd import api, binding
+    assert "LDA_NO_SELFCHECK" not in os.environ
+    c = api.Compressor(6)           # device_ctx(): the self-check ran and passed
+    t0 = time.perf_counter()
+    rc, cnt = binding.selfcheck()
+    dt = time.perf_counter() - t0
+    print("selfcheck:", cnt, f"{dt * 1e3:.2f} ms")
+    assert rc == 0
+    assert cnt["lds_lanes"] >= 16 * 16 * 64 and cnt["lds_conflicts"] > cnt["lds_lanes"] // 8
+    assert cnt["lds_out_of_order"] == 0
+    assert cnt["loads"] >= 1 << 20 and cnt["stale_loads"] == 0
+    assert dt < 0.05
+    c.close()
