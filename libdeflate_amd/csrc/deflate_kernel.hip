@@ -842,10 +842,15 @@ opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo_, s32 hi_, s32 e_, u32 lan
  *   - fewer than two used symbols -> two 1-bit codewords
  *     (lib/deflate_compress.c:1369-1378).
  */
-template <int N> struct huff_scratch {
-	u32 A[N];	/* leaf weights, later hop pointers */
-	u32 NW[N];	/* internal node weights, later depths */
-	u32 P[N];	/* parent of each internal node */
+/* W: the type of a weight.  A block of the small-buffer kernel has at most
+ * 4097 tokens: its weights (and everything else these arrays hold: node
+ * indices, depths) fit 16 bits, and the scratch of the litlen tree fits the
+ * 4 KiB of the bit staging area, idle while the codes are built - M[] of a
+ * tile of 1024 positions has no room for it */
+template <int N, typename W = u32> struct huff_scratch {
+	W A[N];	/* leaf weights, later hop pointers */
+	W NW[N];	/* internal node weights, later depths */
+	W P[N];	/* parent of each internal node */
 	u32 cntI[40];	/* internal nodes per depth */
 	u32 cnt[40];	/* leaves per depth (code lengths) */
 	u32 start[16];	/* first index in sorted[] for each length */
@@ -853,16 +858,26 @@ template <int N> struct huff_scratch {
 	u16 S[2 * N];	/* merge rounds: the items of a round in merged order */
 };
 
-/* a block end builds its codes in M[] (keys and sorted symbols in the first
- * 2 KiB, the litlen tree's scratch behind them): tiles of 1024 positions do
- * not leave room for it (such a build measured 7 % faster per batch with five
- * workgroups per CU - and wrote garbage codes over the histogram) */
-static_assert(sizeof(((struct deflate_lds *)0)->M) >= 2048 + sizeof(huff_scratch<288>),
+/* a block end builds its codes in M[]: keys and sorted symbols in the first
+ * 2 KiB, the litlen tree's scratch behind them - or, where M[] is a tile of
+ * 1024 positions (small-buffer kernel), in the bit staging area with 16-bit
+ * entries (a build that kept it in M[] wrote over the histogram) */
+#ifdef LDA_SMALL
+typedef huff_scratch<288, u16> huff_litlen_t;
+#define HUFF_LITLEN(L) ((huff_litlen_t *)(L)->nxtA)
+static_assert(sizeof(((struct deflate_lds *)0)->nxtA) >= sizeof(huff_litlen_t) &&
+	      sizeof(((struct deflate_lds *)0)->M) >= 2048 && RING + 1 < 65536,
+	      "the staging area holds the litlen tree's scratch, M[] the keys");
+#else
+typedef huff_scratch<288, u32> huff_litlen_t;
+#define HUFF_LITLEN(L) ((huff_litlen_t *)((L)->M + 512))
+static_assert(sizeof(((struct deflate_lds *)0)->M) >= 2048 + sizeof(huff_litlen_t),
 	      "M[] holds the block-end scratch");
+#endif
 
-template <int N> static __device__ void
+template <int N, typename W> static __device__ void
 make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
-	  u16 *sorted, huff_scratch<N> *H, u32 used, bool presorted, u32 lane)
+	  u16 *sorted, huff_scratch<N, W> *H, u32 used, bool presorted, u32 lane)
 {
 	PROF_DECL;
 	PROF_START();
@@ -3301,7 +3316,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					/* the two trees are built side by side on two waves */
 					if (wave == 0)
 						make_code(L->freq, 288, 15, L->lens, L->codes,
-							  L->sorted, (huff_scratch<288> *)(L->M + 512),
+							  L->sorted, HUFF_LITLEN(L),
 							  usedv[0], true, lane);
 					else if (wave == 1)
 						make_code(L->freq + 288, 32, 15, L->lens + 288,

@@ -53,6 +53,9 @@
 #include "kernels.h"
 
 #ifndef PAR_PRIO
+#ifndef FAR_SC1
+#define FAR_SC1 0	/* far match sources through the L2 (measured: see DESIGN 3.2) */
+#endif
 #define PAR_PRIO 1	/* wave-per-stream: issue priority by the share of the input still ahead */
 #endif
 #define LIT_TB 9
@@ -1134,8 +1137,17 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 						 * s_waitcnt vmcnt(0) here would also wait for the
 						 * token rows requested ahead and cost 5 % on 65 536
 						 * streams) */
+#if FAR_SC1
+						/* (device scope: served by the L2, which this
+						 * wave's earlier store has reached in order) */
+						if (far)
+							vfar[k] = __hip_atomic_load(
+								(const u8 *)&gfar[bi + 32768u - dist],
+								__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
 						if (far)
 							vfar[k] = gfar[bi + 32768u - dist];
+#endif
 					}
 				}
 				/* copies inside a slot: where each lane's byte finally comes
