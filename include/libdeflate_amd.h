@@ -390,7 +390,8 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
  * [3] block starts found; [4] chunks planned; [5] repairs; [6] chunks decoded;
  * [7] bytes produced; [8..13] host-side microseconds of: copy in, block finder,
  * count pass + chain, queueing the decode / window / resolve / checksum kernels,
- * footer check, output copy (which waits for those kernels); [14] input windows.
+ * footer check, output copy (which waits for those kernels); [14] input windows;
+ * [15] chunks the host made itself from runs of stored blocks (no count pass).
  */
 #define LIBDEFLATE_AMD_STREAM_STATS 16
 LIBDEFLATEAPI void

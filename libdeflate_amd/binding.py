@@ -151,7 +151,7 @@ def stream_stats():
     load().libdeflate_amd_stream_stats(out)
     keys = ("parallel", "why_not", "filter_a", "blocks_found", "chunks_planned",
             "repairs", "chunks_decoded", "bytes", "us_in", "us_find", "us_count",
-            "us_decode", "us_sum", "us_out", "windows")
+            "us_decode", "us_sum", "us_out", "windows", "host_chunks")
     return dict(zip(keys, [int(v) for v in out]))
 
 

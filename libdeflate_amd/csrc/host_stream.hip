@@ -176,6 +176,73 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		return e;
 	};
 
+	/* the host has the stream too: bits of it, for what it can decide itself */
+	const uint8_t *raw = in + hdr;
+	auto peek = [&](uint64_t bit, unsigned n) -> uint32_t {	/* n <= 24; zeros past the end */
+		uint32_t v = 0;
+		const uint64_t b0 = bit >> 3;
+		for (unsigned k = 0; k < 4; k++)
+			if (b0 + k < raw_n)
+				v |= (uint32_t)raw[b0 + k] << (8 * k);
+		return (v >> (bit & 7)) & ((1u << n) - 1);
+	};
+	/*
+	 * A RUN OF STORED BLOCKS from the block boundary `p` on, walked by the
+	 * host (5 header bytes per block of up to 65535: lib/decompress_template.h:
+	 * 247-285): the finder does not look for stored blocks, and a chunk that
+	 * walked such a run alone copied it alone - a level-0 file at one wave's
+	 * speed.  Every stored block (several small ones together, up to `group`
+	 * bits of input) becomes a chunk of its own whose result is known without
+	 * a count pass; the decode pass copies them side by side.  Stops in front
+	 * of the first block that is not stored, is not wholly inside the first
+	 * `dev_bytes` of the stream (what the kernels can read), or is invalid
+	 * (the kernels - and after them the sequential path - say what the
+	 * reference says about that one).  Returns the bit it stopped at.
+	 */
+	auto walk_stored = [&](uint64_t p, uint64_t dev_bytes, uint64_t group,
+			       std::vector<lda_stream_chunk> &oc, std::vector<lda_stream_res> &orr,
+			       bool *fin_ret) -> uint64_t {
+		*fin_ret = false;
+		for (;;) {
+			lda_stream_chunk c = {};
+			lda_stream_res r = {};
+			c.kind = LDA_CHUNK_HEADER;
+			c.hdr_bit = c.start_bit = c.target_bit = p;
+			r.start_bit = p;
+			uint64_t q = p;
+			bool fin = false;
+			while (q + 3 <= raw_bits && !fin && q - p < group) {
+				const uint32_t h = peek(q, 3);
+				if ((h >> 1) != 0)
+					break;
+				const uint64_t bp = (q + 3 + 7) >> 3;
+				if (bp + 4 > raw_n)
+					break;
+				const uint32_t len = raw[bp] | ((uint32_t)raw[bp + 1] << 8);
+				const uint32_t nlen = raw[bp + 2] | ((uint32_t)raw[bp + 3] << 8);
+				if (len != (nlen ^ 0xFFFFu) || bp + 4 + len > raw_n || bp + 4 + len > dev_bytes)
+					break;
+				r.nout += len;
+				q = 8 * (bp + 4 + len);
+				fin = h & 1;
+			}
+			if (q == p)
+				return p;
+			c.limit_bit = q;
+			r.end_bit = r.end_hdr_bit = q;
+			r.status = fin ? LDA_STREAM_FINAL : LDA_STREAM_OK;
+			r.flags = LDA_RES_BOUNDARY;
+			oc.push_back(c);
+			orr.push_back(r);
+			S[15]++;
+			p = q;
+			if (fin) {
+				*fin_ret = true;
+				return p;
+			}
+		}
+	};
+
 	/*
 	 * The input is taken in WINDOWS (4 to 16 MiB of it, then four times as much
 	 * each time, up to all of it): copied to the device, searched for block starts,
@@ -207,6 +274,10 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	/* where the next window's first chunk starts */
 	lda_stream_chunk carry = {};
 	carry.kind = LDA_CHUNK_HEADER;
+	/* the state carried in lies inside a static block (carry.hdr_bit ==
+	 * LDA_HDR_STATIC): is that block the stream's last?  (the chunks planned
+	 * under the static codes cannot know, see stream_kernels.h) */
+	bool carry_gf = false;
 	size_t copied = 0;	/* bytes of the caller's buffer on the device */
 	uint64_t dev_n = 0;	/* raw bytes the kernels may read (the last window's) */
 	bool final_seen = false;
@@ -238,6 +309,21 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		dev_n = win_n;
 		const uint64_t R1 = whole ? raw_bits : 8 * (win_n > 8192 ? win_n - 8192 : 0);
 		S[14]++;
+		/* stored blocks at the carried-in boundary: the host's */
+		if (carry.kind == LDA_CHUNK_HEADER) {
+			const uint64_t group = 8 * (uint64_t)(env.stream_chunk ? env.stream_chunk : 16384);
+			bool fin = false;
+			const uint64_t q = walk_stored(carry.start_bit, win_n, group, acc, accr, &fin);
+			if (fin) {
+				final_seen = true;
+				break;
+			}
+			if (q != carry.start_bit) {
+				carry = lda_stream_chunk();
+				carry.kind = LDA_CHUNK_HEADER;
+				carry.hdr_bit = carry.start_bit = carry.target_bit = q;
+			}
+		}
 		if (R1 <= carry.start_bit + 4096 && !whole)
 			continue;
 		lap(8);
@@ -308,12 +394,16 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		std::vector<planned> plan;
 		/* a block (or, for the carried-in state, what is left of one): its
 		 * first chunk, then inner chunks up to `next` */
-		auto add_block = [&](const lda_stream_chunk &first, uint64_t next, bool dynamic) {
+		/* (`inner`: the block's tables are known without looking - from its
+		 * header at first.hdr_bit, or the static codes', `under` =
+		 * LDA_HDR_STATIC) */
+		auto add_block = [&](const lda_stream_chunk &first, uint64_t next, bool inner,
+				     uint64_t under) {
 			planned p = {};
 			p.c = first;
 			p.at = first.start_bit;
 			plan.push_back(p);
-			if (!dynamic)
+			if (!inner)
 				return;
 			const uint64_t start = first.start_bit;
 			const uint64_t safe = first.kind == LDA_CHUNK_HEADER ? start + HDRSAFE : start;
@@ -325,7 +415,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					continue;
 				planned q = {};
 				q.c.kind = LDA_CHUNK_WARM;
-				q.c.hdr_bit = first.hdr_bit;
+				q.c.hdr_bit = under;
 				q.c.start_bit = ws;
 				q.c.target_bit = P;
 				q.at = P;
@@ -348,7 +438,15 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					cs.push_back(c);
 			}
 			uint64_t last_at = carry.start_bit;
-			add_block(carry, cs.empty() ? R1 : cs[0], carry_dynamic);
+			/* a STATIC block at the carried-in state (the host sees the
+			 * header, or the state says so): chunks under the static
+			 * codes up to the next candidate.  They stop at the block's
+			 * end; what follows there is found by the chain (repairs). */
+			const bool carry_static =
+				carry.kind == LDA_CHUNK_HEADER ? !carry_dynamic && (peek(carry.start_bit, 3) >> 1) == 1 :
+								 carry.hdr_bit == LDA_HDR_STATIC;
+			add_block(carry, cs.empty() ? R1 : cs[0], carry_dynamic || carry_static,
+				  carry_static ? LDA_HDR_STATIC : carry.hdr_bit);
 			for (size_t i = 0; i < cs.size(); i++) {
 				const uint64_t next = i + 1 < cs.size() ? cs[i + 1] : R1;
 				if (cs[i] - last_at < T / 8 && next - cs[i] < T / 2)
@@ -356,7 +454,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				lda_stream_chunk b = {};
 				b.kind = LDA_CHUNK_HEADER;
 				b.hdr_bit = b.start_bit = b.target_bit = cs[i];
-				add_block(b, next, true);
+				add_block(b, next, true, b.hdr_bit);
 				last_at = cs[i];
 			}
 		}
@@ -415,12 +513,24 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			for (uint32_t i = 0; i < np; i++)
 				ats[i] = plan[i].at;
 			std::vector<uint32_t> path;
+			/* how many repairs in a row led to an entry (0: planned): a
+			 * repair behind a repair reaches twice as far as the one before
+			 * it - a block whose parse never falls in step (codewords of one
+			 * length) is walked in a few long strides, not chunk by chunk */
+			std::vector<uint8_t> depth(np, 0);
 			uint32_t repairs = 0, first_open = 0;
 			const uint32_t max_repairs = 64 + 2 * np;
+			const uint64_t sgroup = 8 * (uint64_t)(env.stream_chunk ? env.stream_chunk : 16384);
 			bool closed = false;	/* the walk ended: final block, or the window's end */
+			bool gf_end = false;	/* the walk's end lies in the stream's final (static) block */
+			/* chunks planned under the static codes: not a header, not a real block */
+			auto under_static = [&](uint32_t i) {
+				return pc[i].kind != LDA_CHUNK_HEADER && pc[i].hdr_bit == LDA_HDR_STATIC;
+			};
 			for (int round = 0; round < 16 && !closed; round++) {
 				path.clear();
 				uint32_t cur = 0;
+				bool gf = carry_gf;
 				for (;;) {
 					if (pr[cur].status == LDA_STREAM_ERR) {
 						if (whole) {
@@ -435,6 +545,22 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 						closed = final_seen = true;
 						break;
 					}
+					/* is the block the walk stands in the stream's last?  A
+					 * chunk that read the header says so itself; one under
+					 * the static codes inherits it - and when it stopped at
+					 * its block's end, that was the end of the stream */
+					const bool bnd_end = pr[cur].flags & LDA_RES_BOUNDARY;
+					if (!under_static(cur))
+						gf = pr[cur].flags & LDA_RES_GOV_FINAL;
+					else if (bnd_end && gf) {
+						/* (its status stays OK: that is what the decode
+						 * pass will report for it too) */
+						closed = final_seen = true;
+						break;
+					}
+					if (bnd_end)
+						gf = false;
+					gf_end = gf;
 					if (pr[cur].end_bit >= R1 || path.size() > pc.size()) {
 						if (whole) {
 							S[1] = WHY_NOFINAL;	/* ran out of input without a final block */
@@ -444,6 +570,23 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 						break;
 					}
 					auto it = by_start.find(end_key(cur));
+					if (it == by_start.end() && bnd_end) {
+						/* a run of stored blocks behind this boundary: the
+						 * host's (no count pass, no round trip) */
+						std::vector<lda_stream_chunk> oc;
+						std::vector<lda_stream_res> orr;
+						bool fin = false;
+						const uint64_t stop = std::min<uint64_t>(win_n, (R1 + 7) / 8 + 65536 + 16);
+						(void)walk_stored(pr[cur].end_bit, stop, sgroup, oc, orr, &fin);
+						for (size_t k = 0; k < oc.size(); k++) {
+							pc.push_back(oc[k]);
+							pr.push_back(orr[k]);
+							depth.push_back(0);
+							by_start.emplace(start_key((uint32_t)pc.size() - 1),
+									 (uint32_t)pc.size() - 1);
+						}
+						it = by_start.find(end_key(cur));
+					}
 					if (it == by_start.end())
 						break;
 					cur = it->second;
@@ -462,6 +605,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				/* repairs for every open end (entries added in earlier rounds
 				 * were looked at then: start at first_open) */
 				std::vector<lda_stream_chunk> rc;
+				std::vector<uint8_t> rdepth;
 				const uint32_t npool = (uint32_t)pc.size();
 				std::map<key_t, int> asked;
 				for (uint32_t i = first_open; i < npool; i++) {
@@ -476,9 +620,15 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					c.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
 					c.hdr_bit = bnd ? pr[i].end_bit : pr[i].end_hdr_bit;
 					c.start_bit = c.target_bit = pr[i].end_bit;
-					auto nx = std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit);
-					c.limit_bit = nx == ats.end() ? R1 : *nx;
+					/* up to the next planned start - or, behind a repair,
+					 * twice as many planned starts further than that one */
+					const uint32_t dp = std::min<uint32_t>((uint32_t)depth[i] + 1, 12);
+					size_t nx = (size_t)(std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit) -
+							     ats.begin());
+					nx += ((size_t)1 << (dp - 1)) - 1;
+					c.limit_bit = nx >= ats.size() ? R1 : ats[nx];
 					rc.push_back(c);
+					rdepth.push_back((uint8_t)dp);
 				}
 				/* the open end of the walk is always among them (round 0 looks at
 				 * all entries; later rounds at the new ones, and the walk can only
@@ -508,6 +658,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				for (uint32_t i = 0; i < nr; i++) {
 					pc.push_back(rc[i]);
 					pr.push_back(rr[i]);
+					depth.push_back(rdepth[i]);
 					by_start.emplace(start_key(npool + i), npool + i);
 				}
 			}
@@ -532,6 +683,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				carry.kind = bnd ? LDA_CHUNK_HEADER : LDA_CHUNK_EXACT;
 				carry.hdr_bit = bnd ? e.end_bit : e.end_hdr_bit;
 				carry.start_bit = carry.target_bit = e.end_bit;
+				carry_gf = !bnd && gf_end;
 			}
 		}
 		lap(10);
@@ -579,6 +731,16 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	uint32_t sum = format == LIBDEFLATE_AMD_GZIP ? 0u : 1u;
 	if (total) {
 		S[1] = WHY_DEVICE;
+		if (!d_cnt) {
+			/* (no window went through the block finder: every block was
+			 * the host's) */
+			uint8_t *sq = (uint8_t *)d->squeue.reserve(128);
+			if (!sq)
+				return false;
+			d_cnt = (uint32_t *)sq;
+		}
+		/* [2]: the error flag of the window / resolve kernels */
+		ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
 		const size_t BATCH = 2048;	/* decode waves per launch (their token scratch) */
 		uint16_t *d_sym = (uint16_t *)d->ssym.reserve((size_t)total * 2 + 64);
 		uint8_t *d_out = (uint8_t *)d->sout.reserve((size_t)total + 64);

@@ -424,16 +424,25 @@ stage_input(lu8 *stage, const u8 *inp, u64 in_n, u64 byte0, u32 nbytes, u32 lane
 #define HDR_STAGE 704u	/* 17 + 57 + 316 x 14 bits at most, + slack */
 static __device__ u32
 chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
-	     u32 *final_ret, u64 *pos_ret)
+	     u32 *final_ret, u64 *pos_ret, bool *static_ret)
 {
-	stage_input(stage, inp, in_n, pos >> 3, HDR_STAGE, lane);
-	u32 r = 2, fin = 0, nlit = 0, noff = 0, used = 0;
+	/* pos == LDA_HDR_STATIC: no header to read, the static codes' tables */
+	const bool forced = pos == LDA_HDR_STATIC;
+	if (forced)
+		pos = 0;
+	else
+		stage_input(stage, inp, in_n, pos >> 3, HDR_STAGE, lane);
+	u32 r = 2, fin = 0, nlit = 0, noff = 0, used = 0, stat = 0;
 	if (lane == 0) {
 		struct par_bits b;
 		const u32 p0 = (u32)pos & 7;
-		pb_init(&b, stage, p0);
+		if (!forced)
+			pb_init(&b, stage, p0);
+		else
+			b.buf = 2;	/* BTYPE 01, not final, nothing consumed */
 		fin = (u32)b.buf & 1;
 		const u32 btype = ((u32)b.buf >> 1) & 3;
+		stat = btype == 1;
 		if (btype == 0) {
 			r = 1;
 			used = 3;
@@ -444,7 +453,7 @@ chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
 			nlit = 288;
 			noff = 32;
 			r = 0;
-			used = 3;
+			used = forced ? 0 : 3;
 		} else if (btype == 2) {
 			u8 plens[19];
 			nlit = 257 + (((u32)b.buf >> 3) & 31);
@@ -509,6 +518,7 @@ chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
 	nlit = bcast_first(nlit);
 	noff = bcast_first(noff);
 	used = bcast_first(used);
+	*static_ret = bcast_first(stat) != 0;
 	wave_sync();
 	if (r == 0) {
 		u32 s_lit, s_off;
@@ -525,7 +535,7 @@ chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
 		}
 		wave_sync();
 	}
-	if (pos + used > 8 * in_n)
+	if (!forced && pos + used > 8 * in_n)
 		r = 2;
 	*final_ret = fin;
 	*pos_ret = pos + used;
@@ -658,14 +668,17 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	u64 start_exact = cd->start_bit;
 	u32 final_blk = 0, status = LDA_STREAM_OK, bad = 0, at_boundary = 0;
 	bool in_block = false, first = cd->kind == LDA_CHUNK_HEADER;	/* its own header is not a stop */
-	bool after_stored = false;	/* the block before pos was a stored one */
+	bool gov_static = false;	/* the block pos lies in is a static one */
+	/* a chunk planned under the static codes stops at its block's end: it
+	 * cannot know whether that block is the stream's last (stream_kernels.h) */
+	const bool stop_at_eob = kind != LDA_CHUNK_HEADER && hdr == LDA_HDR_STATIC;
 	u64 ring_lo = out;
 
 	if (kind != LDA_CHUNK_HEADER) {
 		/* inside a block: its tables, then the start */
 		u64 p2;
-		const u32 r = chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2);
-		if (r != 0 || cd->start_bit < p2) {
+		const u32 r = chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static);
+		if (r != 0 || (!stop_at_eob && cd->start_bit < p2)) {
 			status = LDA_STREAM_ERR;
 		} else {
 			pos = cd->start_bit;
@@ -689,28 +702,17 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	while (status == LDA_STREAM_OK) {
 		if (!in_block) {
 			if (pos >= limit && !first) {
-				/* A run of stored blocks is walked to its end whatever the
-				 * limit says (for 256 Mbit at most): nothing in it can be a
-				 * chunk start - the finder does not look for stored blocks,
-				 * and what it finds INSIDE one (incompressible bytes: a
-				 * header-like pattern every few KiB) is false - so a chunk that
-				 * stopped in the middle of the run would only hand over to a
-				 * repair chunk per block. */
-				bool on = false;
-				if (after_stored && pos - limit < (1ull << 28) && (pos >> 3) + 1 < in_n) {
-					const u32 w = inp[pos >> 3] | ((u32)inp[(pos >> 3) + 1] << 8);
-					on = ((w >> ((u32)pos & 7)) & 6) == 0;	/* BTYPE 00 */
-				}
-				if (!on) {
-					at_boundary = 1;
-					break;
-				}
+				/* (also in the middle of a run of stored blocks: the host
+				 * walks such a run itself - it has the input - and gives
+				 * every stored block a chunk of its own, host_stream.hip) */
+				at_boundary = 1;
+				break;
 			}
 			first = false;
-			after_stored = false;
 			u64 p2;
 			hdr = pos;
-			const u32 r = chunk_header(inp, in_n, S, stage, lane, pos, &final_blk, &p2);
+			const u32 r = chunk_header(inp, in_n, S, stage, lane, pos, &final_blk, &p2,
+						   &gov_static);
 			if (r == 2) {
 				status = LDA_STREAM_ERR;
 				break;
@@ -729,14 +731,26 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 					break;
 				}
 				if (MODE == SM_MARK) {
-					for (u32 k = lane; k < len; k += 64)
-						sym[out + k] = inp[bp + 4 + k];
+					/* 8 bytes per lane and step (a stream of stored blocks
+					 * is copied at the rate of this loop) */
+					const u8 *src = inp + bp + 4;
+					u16 *dst = sym + out;
+					for (u32 k = 8 * lane; k < len; k += 512) {
+						if (k + 8 <= len) {
+							const u64 v = ld8(src + k);
+#pragma unroll
+							for (u32 j = 0; j < 8; j++)
+								dst[k + j] = (u16)((v >> (8 * j)) & 0xFF);
+						} else {
+							for (u32 j = k; j < len; j++)
+								dst[j] = src[j];
+						}
+					}
 					__threadfence();
 				}
 				out += len;
 				ring_lo = out;
 				pos = 8 * (bp + 4 + len);
-				after_stored = true;
 				if (final_blk) {
 					status = LDA_STREAM_FINAL;
 					break;
@@ -765,6 +779,10 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 		out = no;
 		if (pr == PAR_EOB) {
 			in_block = false;
+			if (stop_at_eob) {	/* the host knows what follows */
+				at_boundary = 1;
+				break;
+			}
 			if (final_blk) {
 				status = LDA_STREAM_FINAL;
 				at_boundary = 1;
@@ -775,11 +793,12 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	if (lane == 0) {
 		rs->start_bit = start_exact;
 		rs->end_bit = pos;
-		rs->end_hdr_bit = in_block ? hdr : pos;
+		rs->end_hdr_bit = in_block ? (gov_static ? LDA_HDR_STATIC : hdr) : pos;
 		rs->nout = out - chunk_abs;
 		rs->status = status;
 		rs->flags = (at_boundary || !in_block ? LDA_RES_BOUNDARY : 0) |
-			    (bad ? LDA_RES_BAD_DIST : 0);
+			    (bad ? LDA_RES_BAD_DIST : 0) |
+			    (in_block && final_blk && !stop_at_eob ? LDA_RES_GOV_FINAL : 0);
 	}
 }
 

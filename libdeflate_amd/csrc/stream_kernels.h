@@ -14,6 +14,15 @@
 				 * the first token boundary >= target_bit is the start */
 #define LDA_CHUNK_EXACT 2u	/* inside the block of hdr_bit, at the token boundary start_bit */
 
+/* hdr_bit of a chunk that starts inside a STATIC block: the static codes need
+ * no header, so such a chunk can be planned without knowing where its block
+ * began (a stream of static blocks has no header the finder could find).  It
+ * does not know either whether its block is the stream's last: it stops at
+ * the block's end-of-block symbol, a boundary like any other, and the host -
+ * which follows the chain from a chunk that did read the header - knows
+ * whether the stream ends there. */
+#define LDA_HDR_STATIC (~(uint64_t)1)
+
 /* All positions are bit offsets into the raw DEFLATE stream.  A chunk ends at
  * the first token boundary (the end of a block counts) at or after limit_bit,
  * or with the stream's final block. */
@@ -32,11 +41,14 @@ struct lda_stream_chunk {
 #define LDA_STREAM_ERR 2u	/* not decodable from here (or a garbage start) */
 #define LDA_RES_BOUNDARY 1u	/* end_bit is the first bit of a block header */
 #define LDA_RES_BAD_DIST 2u	/* a distance reaches back before the stream */
+#define LDA_RES_GOV_FINAL 4u	/* end_bit lies inside the stream's final block (as far as the
+				 * chunk knows: it read that block's header) */
 
 struct lda_stream_res {
 	uint64_t start_bit;	/* where the chunk really started (WARM: found) */
 	uint64_t end_bit;
-	uint64_t end_hdr_bit;	/* header of the block end_bit lies in (= end_bit at a boundary) */
+	uint64_t end_hdr_bit;	/* header of the block end_bit lies in (= end_bit at a boundary;
+				 * LDA_HDR_STATIC inside a static block, wherever it began) */
 	uint64_t nout;		/* bytes the chunk produces */
 	uint32_t status;
 	uint32_t flags;

@@ -129,23 +129,53 @@ def _static_block_stream(data):
 
 def test_streams_the_finder_cannot_enter(dec, oracle):
     """Stored-only, static-only and one-giant-block streams have no dynamic
-    block header to find (or only one): chunk 0 walks them, or the sequential
-    kernel answers; the bytes and codes are the oracle's either way."""
+    block header to find (or only one).  Round 5: they are decoded on many
+    waves all the same - the host walks runs of stored blocks itself (one
+    chunk per block, no count pass), and a static block needs no header to be
+    entered anywhere (chunks under the static codes); the bytes and codes are
+    the oracle's."""
     rnd = datagen.random_chunk(2 << 20, 5)
     stored = streams._zcompress("deflate", 0, rnd)
     r = dec.decompress_ex("deflate", stored, len(rnd))
-    print("stored-only:", binding.stream_stats())
+    st = binding.stream_stats()
+    print("stored-only:", st)
     assert r == (0, len(stored), len(rnd), rnd)
+    assert st["parallel"] == 1 and st["chunks_decoded"] >= 32, st
+    # truncated inside a stored block, and a stored LEN / NLEN that disagree
+    # truncated inside a block; the third block's NLEN no longer matches
+    h3 = 0
+    for _ in range(2):
+        h3 += 5 + (stored[h3 + 1] | stored[h3 + 2] << 8)
+    for bad in (stored[:len(stored) - 70000],
+                stored[:h3 + 3] + bytes([stored[h3 + 3] ^ 0x40]) + stored[h3 + 4:]):
+        got = dec.decompress_ex("deflate", bad, len(rnd))
+        assert got[0] == oracle.decompress_ex("deflate", bad, len(rnd))[0] != 0
     txt = datagen.text_chunk(1 << 20, 9)
     co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
     fixed = co.compress(txt) + co.flush()
     r = dec.decompress_ex("deflate", fixed, len(txt))
-    print("static blocks:", binding.stream_stats())
+    st = binding.stream_stats()
+    print("static blocks:", st)
     assert r == (0, len(fixed), len(txt), txt)
+    assert st["parallel"] == 1 and st["chunks_decoded"] >= 32, st
+    for cut in (len(fixed) // 2, len(fixed) - 1):
+        got = dec.decompress_ex("deflate", fixed[:cut], len(txt))
+        assert got[0] == oracle.decompress_ex("deflate", fixed[:cut], len(txt))[0] != 0
     giant = _static_block_stream(txt[:200000])
     r = dec.decompress_ex("deflate", giant, 200000)
-    print("one static block:", binding.stream_stats())
+    st = binding.stream_stats()
+    print("one static block:", st)
     assert r == (0, len(giant), 200000, txt[:200000])
+    assert st["parallel"] == 1 and st["chunks_decoded"] >= 8, st
+    # stored blocks between Huffman blocks (zlib's full flushes leave empty ones)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    mixed = b""
+    for i in range(24):
+        mixed += co.compress(txt[i * 40000:(i + 1) * 40000]) + co.flush(zlib.Z_FULL_FLUSH)
+    mixed += co.flush()
+    r = dec.decompress_ex("deflate", mixed, 24 * 40000)
+    assert r == (0, len(mixed), 24 * 40000, txt[:24 * 40000]), binding.stream_stats()
+    assert binding.stream_stats()["parallel"] == 1
     # one dynamic block as large as zlib makes them, then the same bytes twice
     co = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
     big = datagen.lowentropy_chunk(600000, 3)

@@ -19,6 +19,8 @@ def main():
     from libdeflate_amd import api, binding
     sizes = [float(a) for a in sys.argv[1:] if not a.startswith("-")] or [1, 4, 16, 64]
     kind = "mix" if "--mix" in sys.argv else "text"
+    # --stored: level 0 (stored blocks only); --fixed: zlib Z_FIXED (static blocks only)
+    shape = "stored" if "--stored" in sys.argv else "fixed" if "--fixed" in sys.argv else "dynamic"
     level = 6
     ref = oracle_util.load_ref()
     d = api.Decompressor()
@@ -29,7 +31,14 @@ def main():
             data = datagen.text_chunk(n, 0x0E110200)
         else:
             data = b"".join(datagen.chunk(i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
-        z = ref.compress("gzip", level, data) if ref else streams._zcompress("gzip", level, data)
+        if shape == "stored":
+            z = streams._zcompress("gzip", 0, data)
+        elif shape == "fixed":
+            import zlib
+            co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+            z = co.compress(data) + co.flush()
+        else:
+            z = ref.compress("gzip", level, data) if ref else streams._zcompress("gzip", level, data)
         zin = np.frombuffer(z, dtype=np.uint8)
         out = np.zeros(n, dtype=np.uint8)
         best, st = 1e9, None
@@ -44,7 +53,7 @@ def main():
                 best, st = dt, binding.stream_stats()
         assert out.tobytes() == data
         ph = {k: v for k, v in st.items() if k.startswith("us_")}
-        print(f"{mib:g} MiB {kind} L{level}: {best * 1e3:.2f} ms = {n / best / 1e9:.2f} GB/s "
+        print(f"{mib:g} MiB {kind} {shape} L{level}: {best * 1e3:.2f} ms = {n / best / 1e9:.2f} GB/s "
               f"parallel={st['parallel']} chunks={st['chunks_decoded']} repairs={st['repairs']} {ph}")
 
 
