@@ -69,6 +69,44 @@ def relaunch(a):
     return subprocess.call(cmd, env=env)
 
 
+def pmc_kernel(what, kernel):
+    """Per-launch PMC counters of `kernel` from the newest committed profile of
+    workload `what` (profiles/*pmc_<what>.json, written by tools/prof_pmc.sh:
+    separate counter passes over that workload) -> (dict, relative path) or
+    ({}, None).  NOT measured in this run; every use says so in the line."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{what}.json")))
+    if not files:
+        return {}, None
+    return (json.load(open(files[-1])).get(kernel, {}), os.path.relpath(files[-1], ROOT))
+
+
+def issue_roof(what, kernel, t_launch, launches=1):
+    """The roof the compress / decompress kernels actually run against: VALU
+    issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles, an
+    MI355X has 1024 SIMDs: issue_frac = VALU wave-instructions per launch x 4 /
+    (1024 x 2.4 GHz x launch time), instructions from the committed PMC pass
+    (static), time from this run.  None when no profile of the workload is
+    committed."""
+    k, src = pmc_kernel(what, kernel)
+    v = k.get("SQ_INSTS_VALU_per_launch")
+    if not v or not t_launch:
+        return None
+    out = {"kernel": kernel,
+           "valu_wave_insts_per_launch": int(v),
+           "issue_frac": round(v * launches * 4 / (1024 * 2.4e9 * t_launch), 3),
+           "source": f"{src} (static: PMC passes of tools/prof_pmc.sh, not this run) "
+                     "/ this run's launch time; nominal 2.4 GHz"}
+    if "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; KiB
+        out["traffic"] = int(launches * (2 * k["FETCH_SIZE_per_launch"] +
+                                         k["WRITE_SIZE_per_launch"]) * 1024)
+    if k.get("SQ_WAVE_CYCLES_per_launch") and k.get("SQ_WAIT_ANY_per_launch"):
+        out["wave_time_waiting"] = round(k["SQ_WAIT_ANY_per_launch"] /
+                                         k["SQ_WAVE_CYCLES_per_launch"], 3)
+    return out
+
+
 def pmc_static():
     """PMC figures of the compress kernel from a committed profile
     (tools/prof_pmc.sh bench -> profiles/*pmc_bench*.json: counter passes over
@@ -491,7 +529,8 @@ def end_to_end(torch, dev, stream, api, tensors, slices=8):
 
 
 def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
-                    shard, chunks, total, fmt, level, steps, scaling, cpu=True):
+                    shard, chunks, total, fmt, level, steps, scaling, cpu=True,
+                    pmc_of=None):
     """A non-headline BASELINE config: compress + decompress of `total`
     chunks (strong: partitioned over the ranks; weak: `total` per rank)."""
     if scaling == "strong":
@@ -519,9 +558,14 @@ def extra_roundtrip(name, workload, torch, dist, world, rank, dev, stream, api,
                         (f"every distinct compressed stream ({r['nref']} per rank) decoded by "
                          "the real reference (oracle/_ref) to the original bytes"
                          if r["nref"] else "oracle/_ref not on this box"),
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                         "compress": {"achieved": round((U + C) / world / tc / 1e9, 2),
-                                      "frac": round((U + C) / world / tc / 1e9 / HBM_PEAK_GBS, 5)},
+            "roofline": {"bound": "valu-issue", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "note": "frac = algorithmic bytes / launch time / HBM peak (the "
+                                 "contract's figure); what binds is VALU issue: issue_frac",
+                         "compress": dict(
+                             {"achieved": round((U + C) / world / tc / 1e9, 2),
+                              "frac": round((U + C) / world / tc / 1e9 / HBM_PEAK_GBS, 5)},
+                             **({"issue": issue_roof(*pmc_of[0], tc, pmc_of[1])}
+                                if pmc_of else {})),
                          "decompress": {"achieved": round((U + C) / world / td / 1e9, 2),
                                         "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5)}}}
 
@@ -594,9 +638,11 @@ def extra_inflate(torch, dist, world, rank, dev, stream, api, shard, total, step
          "compressed_ratio": round(C / U, 4),
          "verified": f"all {int(U)} output bytes equal the original; "
                      f"{verdict[0]} verdicts gathered, {verdict[1]} failed",
-         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+         "roofline": {"bound": "valu-issue", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                       "achieved": round((U + C) / world / td / 1e9, 2),
-                      "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5)}}
+                      "frac": round((U + C) / world / td / 1e9 / HBM_PEAK_GBS, 5),
+                      "issue": issue_roof("inflate64k", "lda_inflate_wave_kernel", td,
+                                          (U / world / CHUNK) / 65536.0)}}
     del d_in, d_blob, out, want
     torch.cuda.empty_cache()
     return r
@@ -740,7 +786,8 @@ def main():
             "compress then decompress, per GPU", torch, dist, world, rank, dev,
             stream, api, shard,
             gen_chunks(a.chunks, CHUNK, 0x0E110002 + rank * 100003),
-            a.chunks, "deflate", 1, 3, "weak", cpu=not a.no_cpu)
+            a.chunks, "deflate", 1, 3, "weak", cpu=not a.no_cpu,
+            pmc_of=(("l1", "lda_deflate_batch_kernel"), a.chunks / 4096.0))
         extras["configs[3]"] = extra_inflate(torch, dist, world, rank, dev, stream,
                                              api, shard, a.streams, 3, cpu=not a.no_cpu)
         extras["configs[4]"] = extra_roundtrip(
@@ -749,7 +796,8 @@ def main():
             "partitioned over the GPUs", torch, dist, world, rank, dev, stream,
             api, shard,
             gen_chunks(min(a.blocks, 16384), 4096, 0x0E110005, mix4k=True),
-            a.blocks, "zlib", 9, 2, "strong", cpu=not a.no_cpu)
+            a.blocks, "zlib", 9, 2, "strong", cpu=not a.no_cpu,
+            pmc_of=(("small", "lda_deflate_small_kernel"), a.blocks / world / 262144.0))
         if rank == 0:
             extras["single_stream"] = single_stream(cpu=not a.no_cpu)
 
@@ -782,7 +830,12 @@ def main():
                          "reference (oracle/_ref) to the original bytes, outside the timed region"
                          if head["nref"] else "oracle/_ref not on this box"),
             "roofline": {
-                "bound": "hbm", "kernel": "lda_deflate_batch_kernel",
+                "bound": "valu-issue", "kernel": "lda_deflate_batch_kernel",
+                "bound_note": "frac (below) = algorithmic bytes / launch time / HBM peak, "
+                              "the contract's figure; the binding resource is VALU issue "
+                              "and the latency of the waves' dependent LDS chains: issue_frac",
+                "issue_frac": (issue_roof("bench", "lda_deflate_batch_kernel", t_comp) or
+                               {}).get("issue_frac"),
                 "achieved": round((U + C) / t_comp / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((U + C) / t_comp / 1e9 / HBM_PEAK_GBS, 5),

@@ -691,6 +691,19 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			S[1] = WHY_NOFINAL;
 			return false;
 		}
+		/* an output buffer that is already too small is known now: no further
+		 * window is copied and searched for a call that cannot succeed here
+		 * (programs/gzip.c retries with a larger buffer: every attempt would
+		 * pay for all windows) */
+		{
+			uint64_t sofar = 0;
+			for (const lda_stream_res &r : accr)
+				sofar += r.nout;
+			if (sofar > out_avail) {
+				S[1] = WHY_SPACE;
+				return false;
+			}
+		}
 	}
 	const uint32_t na = (uint32_t)acc.size();
 	S[6] = na;

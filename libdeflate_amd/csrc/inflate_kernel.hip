@@ -748,6 +748,84 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 typedef __attribute__((address_space(1))) u8 gu8;	/* output bytes in HBM */
 
 /*
+ * A round whose passes do not converge.  The passes rest on a parse started
+ * at a wrong bit falling in step with the true one within a few tokens; a
+ * code whose codewords all have (nearly) one length never does - a dynamic
+ * block over incompressible bytes: 256 literals of 8 bits, a few of 7 or 9 -
+ * and then a pass makes exactly one more lane exact: 64 passes per round.
+ * But such a parse cannot be far off either: a lane's true start lies in the
+ * first PAR_PHASES bits of its piece (a literal overhangs the piece before by
+ * less than its own length).  So, once, every lane behind the first lane
+ * with a known start parses its piece from EACH of those starts (nothing
+ * kept but where the parse ends, 6 bits per start in one 64-bit word), and
+ * the chain - my end is the next lane's start - is followed through all
+ * lanes on the scalar unit.  Returns this lane's start on that chain
+ * (`cur` where the chain does not reach: a token that overhangs further, an
+ * end of block); the caller's next pass parses from there and the passes'
+ * own check (every start equals the end before it) decides as ever, so the
+ * result does not depend on any of this.  Ten parses instead of sixty-four.
+ * f: the first lane whose start changed, start_f its (exact) new start;
+ * cend: where this lane's piece ends for the caller (a limit may cut it).
+ */
+#define PAR_PHASES 9u
+#ifndef PAR_PHASE_MIN
+#define PAR_PHASE_MIN 16u	/* lanes still out of step after the second parse that trigger it */
+#endif
+static __device__ u32
+par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
+		 const struct par_long *plo, const lu8 *span, u32 bpos0, u32 cb, u32 cend,
+		 u32 lane, u32 NL, u32 f, u32 start_f, u32 cur)
+{
+	const u32 ps = bpos0 + lane * cb, pe = ps + cb;
+	u32 o = start_f - (bpos0 + f * cb);	/* wave-uniform */
+	if (o >= PAR_PHASES)
+		return cur;
+	u64 ends = ~0ull;	/* 63 = no usable end */
+	const bool mine = lane >= f && lane < NL && cend == pe;
+	for (u32 ph = 0; ph < PAR_PHASES; ph++) {
+		struct par_bits b;
+		bool run = mine, stop = false;
+		pb_init(&b, span, ps + ph);
+		while (__ballot(run)) {
+			run = run && PB_POS(b) < pe;
+			pb_refill(&b, span);
+			const struct par_token t = par_decode(S, SH, pll, plo, b.buf);
+#if PAR_PAIR
+			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < pe &&
+					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+#else
+			const u32 e1 = 0;
+			const bool two = false;
+#endif
+			if (run) {
+				u32 used = t.used + (two ? e1 & 15 : 0);
+				if (t.kind == K_EOB) {
+					stop = true;
+					run = false;
+				}
+				b.buf >>= used;
+				b.cnt -= used;
+			}
+		}
+		const u32 over = PB_POS(b) - pe;
+		const u64 code = mine && !stop && PB_POS(b) >= pe && over < PAR_PHASES ? over : 63;
+		ends = (ends & ~(63ull << (6 * ph))) | (code << (6 * ph));
+	}
+	u32 res = cur;
+	for (u32 i = f; i + 1 < NL; i++) {
+		const u64 e = readlane64(ends, i);
+		const u32 nx = (u32)(e >> (6 * o)) & 63;
+		if (nx >= PAR_PHASES)
+			break;
+		o = nx;
+		if (lane == i + 1)
+			res = ps + o;
+	}
+	return res;
+}
+
+/*
  * Output positions [flushed, end) are in the LDS mirror and not yet in
  * memory: store the whole 4-byte words among them (words of the POSITION, the
  * alignment the mirror can be read with) and return the new 'flushed'.  The
@@ -945,7 +1023,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		if (lane == 0)
 			ns = bpos0;
 		dirty = (ns != start || (pass == 0 && lane != 0)) && lane < NL;
-		start = ns;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {	/* end of block on the exact prefix */
@@ -955,6 +1032,17 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		}
 		if (!dm)
 			break;
+		if (pass == 1 && (u32)__builtin_popcountll(dm) >= PAR_PHASE_MIN) {
+			/* the passes are not converging: see par_phase_starts() */
+			const u32 f = (u32)__builtin_ctzll(dm);
+			const u32 g = par_phase_starts(S, SH, &pll, &plo, span, bpos0, cb, cend, lane,
+						       NL, f, bcast_lane(ns, f), ns);
+			if (lane > f && lane < NL) {
+				ns = g;
+				dirty = ns != start;
+			}
+		}
+		start = ns;
 	}
 	PROF_SEC(0);
 	/* ---- counts -> offsets; clip the round to the token scratch ---- */

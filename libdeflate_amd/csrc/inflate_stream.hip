@@ -195,7 +195,6 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 		if (lane == 0)
 			ns = bpos0;
 		dirty = (ns != start || (pass == 0 && lane != 0)) && lane < NL;
-		start = ns;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {
@@ -205,6 +204,18 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 		}
 		if (!dm)
 			break;
+		if (pass == 1 && (u32)__builtin_popcountll(dm) >= PAR_PHASE_MIN) {
+			/* the passes are not converging (a code of nearly one codeword
+			 * length): par_phase_starts() of inflate_kernel.hip */
+			const u32 f = (u32)__builtin_ctzll(dm);
+			const u32 g = par_phase_starts(S, SH, &pll, &plo, span, bpos0, cb, cend, lane,
+						       NL, f, bcast_lane(ns, f), ns);
+			if (lane > f && lane < NL) {
+				ns = g;
+				dirty = ns != start;
+			}
+		}
+		start = ns;
 	}
 	bool valid = lane <= K;
 	u32 tcnt = valid ? ntok : 0;

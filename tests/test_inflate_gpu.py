@@ -392,6 +392,41 @@ def test_static_tables_after_a_dynamic_block(dec, oracle, monkeypatch):
             assert dec.decompress_ex("deflate", s, len(want))[3] == want, (mode, i)
 
 
+def test_codes_of_one_codeword_length(dec, oracle, monkeypatch):
+    """Huffman blocks whose codewords all have (nearly) one length - bytes
+    drawn evenly from 2^k values, zlib's Huffman-only strategy: a parse started
+    at a wrong bit never falls in step, the rounds' passes would fix one lane
+    each (par_phase_starts() in csrc/inflate_kernel.hip parses every lane from
+    each possible start once instead).  Bytes and codes as the oracle's, both
+    mappings, valid / truncated / short output; and one large stream of them
+    through the many-wave path."""
+    rng = np.random.default_rng(0xC0DE)
+    cases, wants = [], []
+    for vals, n in ((128, 70000), (64, 30000), (16, 9000), (2, 5000), (200, 66000), (256, 40000)):
+        data = rng.integers(0, vals, n, dtype=np.uint8).tobytes()
+        # a match now and then: a token that overhangs the next lane's first bits
+        data = data[:n // 2] + data[100:400] + data[n // 2:]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY if vals != 200 else zlib.Z_DEFAULT_STRATEGY)
+        z = co.compress(data) + co.flush()
+        assert zlib.decompress(z, -15) == data
+        wants.append((z, data))
+        cases.append(("deflate", z, len(data), True, f"onelen{vals}"))
+        cases.append(("deflate", z, len(data), False, f"onelen{vals}/exact"))
+        cases.append(("deflate", z, len(data) - 1, True, f"onelen{vals}/short"))
+        cases.append(("deflate", z[:len(z) * 3 // 4], len(data), True, f"onelen{vals}/cut"))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()
+        _run_cases(dec, oracle, cases)
+        for z, data in wants:
+            assert dec.decompress_ex("deflate", z, len(data))[3] == data, mode
+    big = rng.integers(0, 128, 3 << 20, dtype=np.uint8).tobytes()
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_HUFFMAN_ONLY)
+    zb = co.compress(big) + co.flush()
+    r = dec.decompress_ex("gzip", zb, len(big))
+    assert r == (0, len(zb), len(big), big), binding.stream_stats()
+
+
 def test_parallel_round_corner_streams(dec, oracle, monkeypatch):
     """Streams aimed at the wave-per-stream rounds (more tokens in a piece
     than a lane records, copies inside a 64-byte slot, sources older than the

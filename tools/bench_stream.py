@@ -19,6 +19,10 @@ def main():
     from libdeflate_amd import api, binding
     sizes = [float(a) for a in sys.argv[1:] if not a.startswith("-")] or [1, 4, 16, 64]
     kind = "mix" if "--mix" in sys.argv else "text"
+    # --kind=K: chunks of kind K of the mix only (5 binary counters, 6 16-symbol text, 7 random)
+    for a in sys.argv:
+        if a.startswith("--kind="):
+            kind = "kind" + a.split("=")[1]
     # --stored: level 0 (stored blocks only); --fixed: zlib Z_FIXED (static blocks only)
     shape = "stored" if "--stored" in sys.argv else "fixed" if "--fixed" in sys.argv else "dynamic"
     level = 6
@@ -29,6 +33,9 @@ def main():
         n = int(mib * (1 << 20))
         if kind == "text":
             data = datagen.text_chunk(n, 0x0E110200)
+        elif kind.startswith("kind"):
+            k = int(kind[4:])
+            data = b"".join(datagen.chunk(k + 8 * i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
         else:
             data = b"".join(datagen.chunk(i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
         if shape == "stored":

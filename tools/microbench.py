@@ -107,6 +107,19 @@ def bench_inflate(a, fmt="gzip", level=6):
         chunks = [datagen.chunk(a.kind + 8 * (i % 8), a.size, 0x0E110004) for i in range(a.chunks)]
     comp = [ref.compress(fmt, level, c) if ref else streams._zcompress(fmt, level, c)
             for c in chunks[:distinct]]
+    if a.kind >= 100:
+        # codes of (nearly) one codeword length: bytes drawn evenly from (kind - 100)
+        # values, Huffman-only blocks (zlib) - a parse started anywhere never falls
+        # in step, the case of par_phase_starts()
+        import zlib
+        wb = {"deflate": -15, "zlib": 15, "gzip": 31}[fmt]
+        chunks = [np.random.default_rng(7000 + i).integers(0, a.kind - 100, a.size, dtype=np.uint8).tobytes()
+                  for i in range(distinct)]
+        chunks = [chunks[i % distinct] for i in range(a.chunks)]
+        comp = []
+        for c in chunks[:distinct]:
+            co = zlib.compressobj(6, zlib.DEFLATED, wb, 9, zlib.Z_HUFFMAN_ONLY)
+            comp.append(co.compress(c) + co.flush())
     offs, blob, sizes = [], bytearray(), []
     for i in range(a.chunks):
         c = comp[i % distinct]

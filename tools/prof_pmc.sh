@@ -1,11 +1,13 @@
 #!/bin/bash
 # PMC passes of one workload (separate from any tracing run; counters only:
 # no trace domains in the same rocprofv3 command).
-# usage: tools/prof_pmc.sh <bench|small|opt|stream>   (run on the GPU box via gpurun)
+# usage: tools/prof_pmc.sh <bench|small|opt|l1|l9|inflate64k|stream>   (run on the GPU box via gpurun)
 #   bench   bench.py's headline batch (4096 distinct 64 KiB chunks, gzip level 6:
 #           lda_deflate_batch_kernel, lda_inflate_wave_kernel, CRC-32)
 #   small   1 Mi/4 x 4 KiB zlib level 9 (lda_deflate_small_kernel), tools/microbench.py
 #   opt     4096 x 64 KiB level 12 (lda_deflate_opt_kernel), tools/microbench.py
+#   l1, l9  4096 x 64 KiB level 1 / 9 (lda_deflate_batch_kernel), tools/microbench.py
+#   inflate64k  65 536 gzip streams of 64 KiB (lda_inflate_wave_kernel), tools/microbench.py
 #   stream  one 16 MiB gzip stream through libdeflate_gzip_decompress (lda_stream_*)
 # writes gpurun_out/pmc_<what>.json: per kernel, counter -> value per launch
 set -e
@@ -16,6 +18,9 @@ case $what in
   bench)  cmd="python $R/bench.py --steps 2 --warmup 1 --no-cpu --configs headline" ;;
   small)  cmd="python $R/tools/microbench.py deflate --size 4096 --chunks 262144 --level 9 --fmt zlib --iters 2" ;;
   opt)    cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 12 --iters 2" ;;
+  l1)     cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 1 --fmt deflate --iters 2" ;;
+  l9)     cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 9 --iters 2" ;;
+  inflate64k) cmd="python $R/tools/microbench.py inflate --chunks 65536" ;;
   stream) cmd="python $R/tools/bench_stream.py 16" ;;
   *) echo "unknown workload $what"; exit 2 ;;
 esac
