@@ -152,6 +152,9 @@
 #endif
 static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
 	      "wave 0 parses, the last two waves insert: the tail waves lie between them");
+#ifndef STEP_BRANCHFREE
+#define STEP_BRANCHFREE 1
+#endif
 #ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
 #endif
@@ -497,6 +500,26 @@ find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 static __device__ __forceinline__ u32
 token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 {
+#if STEP_BRANCHFREE
+	/* without a branch: every lane evaluates both look-aheads and selects
+	 * (as nested ifs this compiled into a dozen EXEC-mask sections per call -
+	 * 72 scalar instructions and as many branches around 50 vector ones, on
+	 * the two step passes every position goes through).  log2 of a distance:
+	 * 31 - clz; a position without a match has length 0 and loses every
+	 * comparison whatever its "distance" gives. */
+	const u32 l0 = m0 & 0xFFFF, l1 = m1 & 0xFFFF, l2 = m2 & 0xFFFF;
+	if (mode == 0)		/* greedy (wave-uniform): nothing to look ahead at */
+		return l0 ? l0 : 1;
+	const s32 z0 = (s32)__builtin_clz((m0 >> 16) | 1), z1 = (s32)__builtin_clz((m1 >> 16) | 1),
+		  z2 = (s32)__builtin_clz((m2 >> 16) | 1);
+	/* b0 - b1 = z1 - z0 */
+	const bool lazy = mode >= 1 && l0 < nice;
+	const bool c1 = lazy && l1 >= l0 && 4 * (s32)(l1 - l0) + (z1 - z0) > 2;
+	const bool c2 = lazy && mode >= 2 && l2 >= l0 && 4 * (s32)(l2 - l0) + (z2 - z0) > 6;
+	u32 st = c2 ? 2 : l0;
+	st = c1 ? 1 : st;
+	return l0 == 0 ? 1 : st;
+#else
 	u32 l0 = m0 & 0xFFFF;
 
 	if (l0 == 0)
@@ -516,6 +539,7 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 		}
 	}
 	return l0;
+#endif
 }
 
 /* ---------------- min-cost parse (levels 10-12) ---------------- */
