@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace + stats of one workload (run via gpurun).
-# usage: tools/prof_trace.sh <tag> [bench|small|opt|stream|l1|inflate64k]
+# usage: tools/prof_trace.sh <tag> [bench|small|opt|stream|l1|l9|inflate64k]
 # Writes gpurun_out/trace_<tag>_<what>/ ; copy the *_kernel_stats.csv into profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
@@ -13,6 +13,7 @@ case $what in
   opt)    cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 12 --iters 2" ;;
   stream) cmd="python $R/tools/bench_stream.py 16" ;;
   l1)     cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 1 --fmt deflate --iters 3" ;;
+  l9)     cmd="python $R/tools/microbench.py deflate --chunks 4096 --level 9 --iters 3" ;;
   inflate64k) cmd="python $R/tools/microbench.py inflate --chunks 65536 --fmt gzip" ;;
 esac
 D=$R/gpurun_out/trace_${tag}_$what
