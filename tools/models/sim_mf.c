@@ -168,10 +168,78 @@ static void parse_seq_lazy(int D, int nice, int halve)
 	}
 }
 
+/* ---- row-hash match finder (mode 4): NROWS rows of ENT recent positions with
+ * one-byte tags, all of a tile inserted before it is searched (what a GPU
+ * kernel without chains would do): every position looks at the entries of its
+ * row whose tag matches, newest first, at most CAND of them ---- */
+static int NROWS = 1536, ENT = 15, CAND = 15, TILE_A = 4096, AHEAD = 1;
+static uint16_t rpos[8192][256];
+static uint8_t rtag[8192][256];
+static uint32_t rcnt[8192];
+static long rcands;
+static void row_reset(void) { memset(rcnt, 0, sizeof rcnt); }
+static void row_insert(int p)
+{
+	if (p + 4 > n) return;
+	/* (the row from the TOP bits of the product - the low ones depend on the
+	 * low input bytes only -, the tag from a second product) */
+	uint32_t hv = ld32(buf + p) * 0x9E3779B1u;
+	uint32_t row = (uint32_t)(((uint64_t)(hv >> 8) * NROWS) >> 24), slot = rcnt[row] % ENT;
+	rcnt[row]++;
+	rpos[row][slot] = (uint16_t)p;
+	rtag[row][slot] = (uint8_t)((ld32(buf + p) * 0x85EBCA6Bu) >> 24);
+}
+static int row_longest(int p, int nice, int *dist, int mode3dist)
+{
+	int maxl = n - p < 258 ? n - p : 258;
+	int best = 2, bd = 0;
+	searched++;
+	if (maxl < 3) return 0;
+	if (nice > maxl) nice = maxl;
+	if (p + 4 <= n) {
+		uint32_t hv = ld32(buf + p) * 0x9E3779B1u;
+		uint32_t row = (uint32_t)(((uint64_t)(hv >> 8) * NROWS) >> 24);
+		uint8_t tag = (uint8_t)((ld32(buf + p) * 0x85EBCA6Bu) >> 24);
+		int have = rcnt[row] < (uint32_t)ENT ? (int)rcnt[row] : ENT, tried = 0;
+		for (int a = 0; a < have && tried < CAND; a++) {
+			uint32_t slot = (rcnt[row] - 1 - a) % ENT;
+			if (rtag[row][slot] != tag) continue;
+			int c = rpos[row][slot];
+			if (c >= p || p - c > W) continue;
+			tried++; rcands++; steps++;
+			if (buf[c + best] == buf[p + best] || best < 3) {
+				int l = extend(c, p, maxl);
+				if (l > best && l >= 4) { best = l; bd = p - c; if (l >= nice) break; }
+			}
+		}
+	}
+	if (best < 4 && p3[p] >= 0 && p - p3[p] <= W) {
+		int l = extend(p3[p], p, maxl);
+		if (l >= 3 && l > best) { best = l; bd = p - p3[p]; }
+	}
+	if (best < 3) return 0;
+	if (best == 3 && bd > mode3dist) return 0;
+	if (best < min_len) return 0;
+	*dist = bd;
+	return best;
+}
+
 /* all-position search then the token_step rule (the current GPU scheme) */
 static int Mlen[CH + 4], Mdist[CH + 4];
+static int use_rows;
 static void parse_allpos(int D, int nice)
 {
+	if (use_rows) {
+		row_reset();
+		int inserted = 0;
+		for (int i = 0; i < n; i++) {
+			/* the tile of i (and AHEAD - 1 more) is in the rows before i is searched */
+			int upto = (i / TILE_A + AHEAD) * TILE_A;
+			if (upto > n) upto = n;
+			for (; inserted < upto; inserted++) row_insert(inserted);
+			int d = 0; Mlen[i] = row_longest(i, nice, &d, 8192); Mdist[i] = d;
+		}
+	} else
 	for (int i = 0; i < n; i++) { int d = 0; Mlen[i] = longest(i, D, nice, &d, 8192); Mdist[i] = d; }
 	Mlen[n] = Mlen[n + 1] = 0;
 	int p = 0;
@@ -243,6 +311,10 @@ int main(int argc, char **argv)
 	W = argc > 6 ? atoi(argv[6]) : 32768;
 	HB = argc > 7 ? atoi(argv[7]) : 16;
 	D0 = argc > 8 ? atoi(argv[8]) : 4; R = argc > 9 ? atoi(argv[9]) : 3;
+	if (getenv("NROWS")) NROWS = atoi(getenv("NROWS"));
+	if (getenv("ENT")) ENT = atoi(getenv("ENT"));
+	if (getenv("CAND")) CAND = atoi(getenv("CAND"));
+	if (getenv("AHEAD")) AHEAD = atoi(getenv("AHEAD"));
 	init_tabs();
 	uint64_t total = 0, per[8] = { 0 };
 	int idx = 0;
@@ -255,6 +327,7 @@ int main(int argc, char **argv)
 		else if (mode == 1) parse_allpos(D, nice);
 		else if (mode == 2) parse_seq_lazy(D, nice, 0);
 		else if (mode == 3) parse_prog(D, nice);
+		else if (mode == 4) { use_rows = 1; parse_allpos(D, nice); }
 		uint64_t c = (tok_cost() + 7) / 8;
 		total += c; per[idx & 7] += c; idx++;
 	}
