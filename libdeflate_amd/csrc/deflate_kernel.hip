@@ -352,16 +352,13 @@ static __device__ u32 block_scan(lds_t *L, u32 v, u32 *total)
 	if (lane == 63)
 		L->scan[0][wave] = incl;
 	__syncthreads();
-	u32 base = 0, tot = 0;
-#pragma unroll
-	for (u32 w = 0; w < NWAVES; w++) {
-		u32 s = L->scan[0][w];
-		if (w < wave)
-			base += s;
-		tot += s;
-	}
+	/* the waves' sums one per lane, a wave scan over them (a loop over the
+	 * sixteen words is six times the instructions, on every wave's path) */
+	const u32 sw = lane < NWAVES ? L->scan[0][lane] : 0;
+	const u32 iw = wave_scan_incl(sw);
+	const u32 base = bcast_lane(iw - sw, wave);
 	__syncthreads();
-	*total = bcast_first(tot);
+	*total = bcast_lane(iw, NWAVES - 1);
 	return base + incl - v;
 }
 
@@ -380,16 +377,10 @@ static __device__ u32 block_scan1(lds_t *L, u32 v, u32 *total,
 	if (lane == 63)
 		sc[wave] = incl;
 	__syncthreads();
-	u32 base = 0, tot = 0;
-#pragma unroll
-	for (u32 w = 0; w < NWAVES; w++) {
-		u32 s = sc[w];
-		if (w < wave)
-			base += s;
-		tot += s;
-	}
-	*total = bcast_first(tot);
-	return base + incl - v;
+	const u32 sw = lane < NWAVES ? sc[lane] : 0;
+	const u32 iw = wave_scan_incl(sw);
+	*total = bcast_lane(iw, NWAVES - 1);
+	return bcast_lane(iw - sw, wave) + incl - v;
 }
 
 /* length slot / extra bits (lib/deflate_compress.c:237-308 tables, computed) */
@@ -2148,14 +2139,12 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 	if (lane == 0)
 		L->scan[0][wave] = cw;
 	__syncthreads();
-	u32 base = 0, wc = 0;
-#pragma unroll
-	for (u32 w = 0; w < NWAVES; w++) {
-		const u32 c = L->scan[0][w];
-		if (w < wave)
-			base += c;
-		wc += c;
-	}
+	/* the waves' counts, one per lane, and a wave scan over them (a loop over
+	 * the sixteen words was a third of this function's instructions) */
+	const u32 cnt_w = lane < NWAVES ? L->scan[0][lane] : 0;
+	const u32 incl_w = wave_scan_incl(cnt_w);
+	u32 base = bcast_lane(incl_w - cnt_w, wave);
+	const u32 wc = bcast_lane(incl_w, NWAVES - 1);
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
 		const u32 j = base + rank_below(bal[k]);
