@@ -2077,9 +2077,15 @@ emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
  * Whole workgroup, two barriers.
  */
 static __device__ __forceinline__ u32
-build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
+build_worklist(lds_t *L, AS3 u32 *W, const AS3 u32 *src, u32 mode, u32 nice, u32 limit, u32 tid)
 {
 	const u32 lane = tid & 63, wave = tid >> 6;
+	/* `src`: the tile's shallow results still wait in MX - every thread moves
+	 * the entries of its own positions to M[] while it looks at them (a copy
+	 * pass of its own in front of this function cost a barrier and a second
+	 * read of every entry); what it needs of its neighbours' it reads from
+	 * MX, which nothing overwrites before this function's first barrier */
+	const AS3 u32 *Ms = src ? src : (const AS3 u32 *)L->M;
 
 	/* parse-based: the positions the lazy rule looked at are the one (lazy2:
 	 * two) after a token start that holds a match shorter than the nice
@@ -2091,7 +2097,7 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 	if (mode >= 1 && S3_HALF && wave) {
 		const u32 g0 = wave * (TILE / NT), q1 = 64 * g0 - 1;
 		const u64 pmask = L->pmA[g0 - 1];
-		const u32 l1 = L->M[4 + q1] & 0xFFFF, l2 = L->M[4 + q1 - 1] & 0xFFFF;
+		const u32 l1 = Ms[4 + q1] & 0xFFFF, l2 = Ms[4 + q1 - 1] & 0xFFFF;
 		if ((pmask >> 63) && l1 >= 3 && l1 < nice)
 			spill = mode >= 2 ? 3 : 1;
 		if (mode >= 2 && ((pmask >> 62) & 1) && l2 >= 3 && l2 < nice)
@@ -2115,7 +2121,10 @@ build_worklist(lds_t *L, AS3 u32 *W, u32 mode, u32 nice, u32 limit, u32 tid)
 		tm_[k] = L->pmA[g];
 		dh_[k] = L->dhalf[g];
 		df_[k] = L->dfull[g];
-		l0_[k] = L->M[4 + q] & 0xFFFF;
+		const u32 mq = Ms[4 + q];
+		if (src)
+			L->M[4 + q] = mq;
+		l0_[k] = mq & 0xFFFF;
 	}
 #pragma unroll
 	for (u32 k = 0; k < TILE / NT; k++) {
@@ -2843,9 +2852,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				u16 *c3ins = c3g + ((it + 1) & 1) * (TILE + 8);
 				const s32 limit = last_tile ? (s32)(tend - t) : (s32)TILE - 2;
 
+				/* (with a round B ahead, build_worklist() moves the results
+				 * and its first barrier is this block's) */
+				const bool wl_copies = cur_real && !optm && rounds && mx_pending;
 				if (cur_real) {
 					/* ---- tile cur: its shallow results into M[] ---- */
-					if (mx_pending)
+					if (mx_pending && !wl_copies)
 						for (u32 i = tid; i < TILE; i += NT)
 							L->M[4 + i] = MX[4 + i];
 					if (tid < 4) {
@@ -2863,7 +2875,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 						L->vars[V_NSEQ_PRE] = L->vars[V_NSEQ];
 						L->vars[V_WPOS_PRE] = walkpos;
 					}
-					__syncthreads();
+					if (!wl_copies)
+						__syncthreads();
 					PROF_MARK(6);
 				}
 				/* the input of the tile that S0 stages below is requested now:
@@ -2881,8 +2894,9 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					 * (pmA: it ran beside phase X of the iteration before) are
 					 * searched deeper ("progressive search") ---- */
 					if (rounds) {
-						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB, mode, nice,
-									      wq_limit, tid);
+						const u32 wc = build_worklist(L, (AS3 u32 *)L->nxtB,
+									      wl_copies ? (const AS3 u32 *)MX : NULL,
+									      mode, nice, wq_limit, tid);
 						PROF_MARK(39);
 						if (wc) {
 							AS3 u32 *tl = (AS3 u32 *)L->nxtB;
@@ -2904,9 +2918,12 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					}
 					/* steps of the final parse (it runs in phase X; behind a
 					 * deferred generation they are computed there as well) */
+					/* (no barrier here: S0 below writes what neither the steps
+					 * nor a tail wave's item load read - the ring's oldest tile,
+					 * which round B's last barrier has released, counters, and
+					 * of MX only entries behind the lists - and ends with one) */
 					if (!tail_n)
 						stage_steps(L, limit, mode, nice, tid);
-					__syncthreads();
 				}
 				if (cur_real && optm) {
 					/* levels 10-12 (mode 3): min-cost parse, see opt_parse_wave().
@@ -3223,16 +3240,16 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 					carryv = L->M[TILE + tid];
 				/* block split observations (see "block end?" below), by the
 				 * last wave while the others wait at the barrier */
-				if (!splits) {
-					if (tid == 0)
-						L->vars[V_SPLIT] = 0;
-				} else if (wave == NWAVES - 1 && optm) {
+				if (splits && wave == NWAVES - 1 && optm) {
 					/* (levels 0-9: done in phase X, beside the first parse of
 					 * the next tile) */
 					split_stats(L, walkpos, block_start, L->vars[V_FIT] == 2, lane);
 				}
 			}
-			__syncthreads();
+			/* (levels 0-9: the split decision was written inside phase X, in
+			 * front of its closing barrier) */
+			if (OPT && mode == 3)
+				__syncthreads();
 			PROF_MARK(32);
 
 			/* ---- block end? ----
@@ -3248,7 +3265,8 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * the tile's tokens (already in the match list) become the start
 			 * of the next block.  Only when that would leave a block shorter
 			 * than the minimum, the block ends after the tile. */
-			const u32 splitv = !stored_only && !last_tile ? bcast_first(L->vars[V_SPLIT]) : 0;
+			const u32 splitv = splits && !stored_only && !last_tile ?
+					   bcast_first(L->vars[V_SPLIT]) : 0;
 			bool end_block = last_tile || splitv ||
 				(!stored_only && bcast_first(L->vars[V_NSEQ]) + 2 * TOK_TILE_MAX > TOK_CAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
