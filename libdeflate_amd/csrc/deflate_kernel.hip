@@ -172,6 +172,21 @@ static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
 #define RA_PAIR 1
 #endif
 #endif
+#ifndef RA_PREF
+/* round A with its LDS round trips taken off the wave's dependent chain (the
+ * phase is a chain of LDS round trips per group of 64 positions):
+ *   1  the raw words of a measuring stage are all requested before any is used
+ *      (match_length*p()), the chain link of a position before its input words;
+ *   2  + the NEXT group is claimed and its first loads are requested while the
+ *      current group's candidates are on their way (not in the last
+ *      RA_PREF_TAIL groups of a tile: those stay with whoever is free);
+ *   3  + the length-3 probes' words are requested at the top of the group.
+ * Same results as 0 (tools/digest_deflate.py). */
+#define RA_PREF 0
+#endif
+#ifndef RA_PREF_TAIL
+#define RA_PREF_TAIL NWAVES
+#endif
 #ifndef RB_HITS
 #define RB_HITS 2		/* round B: filter hits a lane may queue per pass of 8 steps (4, 2 or 1; a lane with a full queue stalls until the pass's hits are measured: 4 -> 2 is -3 % time for +0.02 % size) */
 #endif
@@ -1436,10 +1451,18 @@ insert_tile3(lds_t *L, u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lane)
  * than 28 bytes are measured by the whole wave, 256 bytes per pass).  cur =
  * bytes p..p+3, nxt8 = bytes p+4..p+11.  0 when the first four bytes differ.
  */
+#if RA_PREF
+static __device__ __forceinline__ u32
+match_length_p(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
+	       u32 maxlen, u32 lane);
+#endif
 static __device__ __forceinline__ u32
 match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 	     u32 maxlen, u32 lane)
 {
+#if RA_PREF
+	return match_length_p(L, ev, p, cp, cur, nxt8, maxlen, lane);
+#endif
 	u64 x = nxt8 ^ ld64(L->in, cp + 4);
 	u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
 	ev = ev && ld32(L->in, cp) == cur;
@@ -1561,6 +1584,210 @@ match_length2(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 c
 	*len2o = ev2 ? len2 : 0;
 }
 
+#if RA_PREF
+/* raw aligned words of the ring (see ld32()): `i` is a multiple of 4 below RING,
+ * `k` <= 28 bytes further lies inside the ring or its 32-byte mirror */
+#define RAW(i, k) LDS32((i) + (k))
+#define AB(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
+/* the words of a stage are all in registers here: without it the compiler moves
+ * a load that only one branch below uses into that branch, behind the wait for
+ * the others (a second LDS round trip) */
+#define HAVE4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
+static __device__ __forceinline__ u64 mk64(u32 lo, u32 hi)
+{
+	return ((u64)hi << 32) | lo;
+}
+
+/* a claim from an LDS counter without a lane-0 branch: EXEC is narrowed to
+ * lane 0 around one returning add.  claim_issue() only sends it (the result
+ * register is valid in lane 0 once the LDS queue has drained to it),
+ * claim_get() waits and makes the value wave-uniform.  Both must run with all
+ * lanes active. */
+static __device__ __forceinline__ u32 claim_issue(u32 lds_byteaddr)
+{
+	u32 r;
+	u64 save;
+	asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+		     : "=&v"(r), "=&s"(save) : "v"(lds_byteaddr), "v"(1u) : "memory");
+	return r;
+}
+
+static __device__ __forceinline__ u32 claim_get(u32 r)
+{
+	u32 g;
+	asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1"
+		     : "=s"(g) : "v"(r) : "memory");
+	return g;
+}
+
+/*
+ * match_length() with every stage's raw words requested before any of them is
+ * used (one LDS round trip per stage instead of up to two): same result.
+ */
+static __device__ __forceinline__ u32
+match_length_p(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
+	       u32 maxlen, u32 lane)
+{
+	(void)L;
+	const u32 op = p & RMASK, ip = op & ~3u, sp = op & 3;
+	const u32 oc = cp & RMASK, ic = oc & ~3u, sc = oc & 3;
+	const u32 b0 = RAW(ic, 0), b1 = RAW(ic, 4), b2 = RAW(ic, 8), b3 = RAW(ic, 12);
+	const u64 x = nxt8 ^ mk64(AB(b2, b1, sc), AB(b3, b2, sc));
+	u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
+	ev = ev && AB(b1, b0, sc) == cur;
+	bool more = ev && x == 0 && 12 < maxlen;
+	if (__ballot(more)) {
+		const u32 p3 = RAW(ip, 12), p4 = RAW(ip, 16), p5 = RAW(ip, 20);
+		const u32 b4 = RAW(ic, 16), b5 = RAW(ic, 20);
+		HAVE4(p3, p5, b4, b5);
+		const u64 y = mk64(AB(p4, p3, sp), AB(p5, p4, sp)) ^ mk64(AB(b4, b3, sc), AB(b5, b4, sc));
+		if (more) {
+			len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
+			more = y == 0 && 20 < maxlen;
+		}
+		if (__ballot(more)) {
+			const u32 p6 = RAW(ip, 24), p7 = RAW(ip, 28);
+			const u32 b6 = RAW(ic, 24), b7 = RAW(ic, 28);
+			HAVE4(p6, p7, b6, b7);
+			const u64 z = mk64(AB(p6, p5, sp), AB(p7, p6, sp)) ^
+				      mk64(AB(b6, b5, sc), AB(b7, b6, sc));
+			if (more) {
+				len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
+				more = z == 0 && 28 < maxlen;
+			}
+		}
+	}
+	for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
+		u32 src = (u32)__builtin_ctzll(mm);
+		u32 bp = bcast_lane(p, src);
+		u32 bc = bcast_lane(cp, src);
+		u32 bmax = bcast_lane(maxlen, src);
+		u32 off = 28 + 4 * lane;
+		u32 x4 = 1;
+		if (off < bmax) {
+			const u32 o1 = (bp + off) & RMASK, i1 = o1 & ~3u;
+			const u32 o2 = (bc + off) & RMASK, i2 = o2 & ~3u;
+			const u32 w0 = RAW(i1, 0), w1 = RAW(i1, 4), v0 = RAW(i2, 0), v1 = RAW(i2, 4);
+			x4 = AB(w1, w0, o1 & 3) ^ AB(v1, v0, o2 & 3);
+		}
+		u64 ne = __ballot(x4 != 0);
+		u32 tot = bmax;	/* 28 + 256 >= 258 */
+		if (ne) {
+			u32 kk = (u32)__builtin_ctzll(ne);
+			u32 xk = bcast_lane(x4, kk);
+			u32 o = 28 + 4 * kk;
+			if (o < bmax)
+				tot = o + ((u32)__builtin_ctz(xk) >> 3);
+		}
+		if (lane == src)
+			len = tot;
+	}
+	if (len > maxlen)
+		len = maxlen;
+	return ev ? len : 0;
+}
+
+/*
+ * match_length2() the same way; `hook` runs between the request of the first
+ * stage's words and their use (round A requests the next group's first loads
+ * there).  Same results as match_length2().
+ */
+template <class F> static __device__ __forceinline__ void
+match_length2_p(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 cur,
+		u64 nxt8, u32 maxlen, u32 lane, u32 *len1o, u32 *len2o, F &&hook)
+{
+	(void)L;
+	const u32 op = p & RMASK, ip = op & ~3u, sp = op & 3;
+	const u32 o1 = cp1 & RMASK, i1 = o1 & ~3u, s1 = o1 & 3;
+	const u32 o2 = cp2 & RMASK, i2 = o2 & ~3u, s2 = o2 & 3;
+	const u32 b0 = RAW(i1, 0), b1 = RAW(i1, 4), b2 = RAW(i1, 8), b3 = RAW(i1, 12);
+	const u32 e0 = RAW(i2, 0), e1 = RAW(i2, 4), e2 = RAW(i2, 8), e3 = RAW(i2, 12);
+	hook();
+	const u64 x1 = nxt8 ^ mk64(AB(b2, b1, s1), AB(b3, b2, s1));
+	const u64 x2 = nxt8 ^ mk64(AB(e2, e1, s2), AB(e3, e2, s2));
+	u32 len1 = 4 + ((u32)__builtin_ctzll(x1 | (1ull << 63)) >> 3);
+	u32 len2 = 4 + ((u32)__builtin_ctzll(x2 | (1ull << 63)) >> 3);
+	ev1 = ev1 && AB(b1, b0, s1) == cur;
+	ev2 = ev2 && AB(e1, e0, s2) == cur;
+	bool m1 = ev1 && x1 == 0 && 12 < maxlen, m2 = ev2 && x2 == 0 && 12 < maxlen;
+	if (__ballot(m1 || m2)) {
+		const u32 p3 = RAW(ip, 12), p4 = RAW(ip, 16), p5 = RAW(ip, 20);
+		const u32 b4 = RAW(i1, 16), b5 = RAW(i1, 20);
+		const u32 e4 = RAW(i2, 16), e5 = RAW(i2, 20);
+		HAVE4(p3, p5, b4, b5);
+		HAVE4(p4, e4, e5, e5);
+		const u64 pw = mk64(AB(p4, p3, sp), AB(p5, p4, sp));
+		const u64 y1 = pw ^ mk64(AB(b4, b3, s1), AB(b5, b4, s1));
+		const u64 y2 = pw ^ mk64(AB(e4, e3, s2), AB(e5, e4, s2));
+		if (m1) {
+			len1 = 12 + ((u32)__builtin_ctzll(y1 | (1ull << 63)) >> 3);
+			m1 = y1 == 0 && 20 < maxlen;
+		}
+		if (m2) {
+			len2 = 12 + ((u32)__builtin_ctzll(y2 | (1ull << 63)) >> 3);
+			m2 = y2 == 0 && 20 < maxlen;
+		}
+		if (__ballot(m1 || m2)) {
+			const u32 p6 = RAW(ip, 24), p7 = RAW(ip, 28);
+			const u32 b6 = RAW(i1, 24), b7 = RAW(i1, 28);
+			const u32 e6 = RAW(i2, 24), e7 = RAW(i2, 28);
+			HAVE4(p6, p7, b6, b7);
+			HAVE4(e6, e7, e7, e7);
+			const u64 pz = mk64(AB(p6, p5, sp), AB(p7, p6, sp));
+			const u64 z1 = pz ^ mk64(AB(b6, b5, s1), AB(b7, b6, s1));
+			const u64 z2 = pz ^ mk64(AB(e6, e5, s2), AB(e7, e6, s2));
+			if (m1) {
+				len1 = 20 + ((u32)__builtin_ctzll(z1 | (1ull << 63)) >> 3);
+				m1 = z1 == 0 && 28 < maxlen;
+			}
+			if (m2) {
+				len2 = 20 + ((u32)__builtin_ctzll(z2 | (1ull << 63)) >> 3);
+				m2 = z2 == 0 && 28 < maxlen;
+			}
+		}
+	}
+#pragma unroll
+	for (u32 c = 0; c < 2; c++) {
+		const u32 cp = c ? cp2 : cp1;
+		for (u64 mm = __ballot(c ? m2 : m1); mm; mm &= mm - 1) {
+			u32 src = (u32)__builtin_ctzll(mm);
+			u32 bp = bcast_lane(p, src);
+			u32 bc = bcast_lane(cp, src);
+			u32 bmax = bcast_lane(maxlen, src);
+			u32 off = 28 + 4 * lane;
+			u32 x4 = 1;
+			if (off < bmax) {
+				const u32 oa = (bp + off) & RMASK, ia = oa & ~3u;
+				const u32 ob = (bc + off) & RMASK, ib = ob & ~3u;
+				const u32 w0 = RAW(ia, 0), w1 = RAW(ia, 4), v0 = RAW(ib, 0), v1 = RAW(ib, 4);
+				x4 = AB(w1, w0, oa & 3) ^ AB(v1, v0, ob & 3);
+			}
+			u64 ne = __ballot(x4 != 0);
+			u32 tot = bmax;	/* 28 + 256 >= 258 */
+			if (ne) {
+				u32 kk = (u32)__builtin_ctzll(ne);
+				u32 xk = bcast_lane(x4, kk);
+				u32 o = 28 + 4 * kk;
+				if (o < bmax)
+					tot = o + ((u32)__builtin_ctz(xk) >> 3);
+			}
+			if (lane == src) {
+				if (c)
+					len2 = tot;
+				else
+					len1 = tot;
+			}
+		}
+	}
+	if (len1 > maxlen)
+		len1 = maxlen;
+	if (len2 > maxlen)
+		len2 = maxlen;
+	*len1o = ev1 ? len1 : 0;
+	*len2o = ev2 ? len2 : 0;
+}
+#endif /* RA_PREF */
+
 /*
  * Minimum match length from the distinct bytes of a tile's input
  * (calculate_min_match_len, lib/deflate_compress.c:2329-2353, which the
@@ -1636,12 +1863,205 @@ stage_input(lds_t *L, const u8 *__restrict__ inp, u32 loaded, u32 want,
  * 3.9 chain steps per position instead of 15.0 at level 6 on text, output
  * 0.03 % smaller than the serial parse after two rounds.
  */
+#if RA_PREF
+/*
+ * round_a() for the usual case (the two nearest chain members of every
+ * position) with the LDS round trips off the dependent chain, see RA_PREF.
+ * A group's first loads - the chain link of each position, its input words
+ * p .. p + 15 and its 3-byte-table candidate - are in registers when its turn
+ * comes: requested by the iteration before (RA_PREF >= 2: the next group is
+ * claimed while this one's second chain link is on its way), or at the end of
+ * the previous iteration for the last RA_PREF_TAIL groups of a tile, which
+ * are not claimed ahead (a wave holding a group it has not started would
+ * keep a free wave from taking it).
+ */
+struct ra_first {
+	u32 c16, a0, a1, a2, a3, c3v;
+};
+
+static __device__ __forceinline__ struct ra_first
+ra_first_loads(const u16 *__restrict__ c3, u32 t, u32 g, u32 lane, bool want3)
+{
+	struct ra_first f;
+	const u32 i = 64 * g + lane, p = t + i;
+	const u32 ip = (p & RMASK) & ~3u;
+
+	/* (whole words, the 16-bit entry is cut out where it is used: a 16-bit
+	 * value carried around the loop is masked where it is loaded, and the
+	 * mask would wait for the load) */
+	f.c16 = LDS32(PREV_OFF + ((2 * (p & RMASK)) & ~3u));
+	f.a0 = RAW(ip, 0);
+	f.a1 = RAW(ip, 4);
+	f.a2 = RAW(ip, 8);
+	f.a3 = RAW(ip, 12);
+	/* (a group past the tile is only ever loaded for, never searched: the
+	 * counter ran out while the claim was on its way.  The load itself is
+	 * unconditional - of an entry inside the tile - so that the waits for
+	 * this load and for the one before it can be told apart) */
+	(void)want3;
+	f.c3v = *(const u32 *)((const u8 *)c3 + ((2 * (4 + (g < TILE / 64 ? i : lane))) & ~3u));
+	return f;
+}
+
+/* one group of 64 positions; PRE: the next group is claimed ahead (see above).
+ * On return `g` / `f` are the next group and its first loads. */
+template <bool PRE> static __device__ __forceinline__ void
+ra_group(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
+	 u32 lo_pos, u32 min_len, u32 done_class, u32 nice, u32 dlim3,
+	 u32 tag, u32 lane, u32 &g, const struct ra_first &f, struct ra_first &fnext)
+{
+	const u32 ctr = (u32)offsetof(struct deflate_lds, vars) + 4 * V_CTR;
+	const bool want3 = min_len <= 3;
+	const u32 i = 64 * g + lane, p = t + i;
+	const u32 sp = p & 3;
+	const u32 cur = AB(f.a1, f.a0, sp);
+	const u64 nxt8 = mk64(AB(f.a2, f.a1, sp), AB(f.a3, f.a2, sp));
+	const u32 hsh = 16 * (lane & 1);	/* p and i have the lane's parity */
+	const u32 c3v = want3 ? (f.c3v >> hsh) & 0xFFFF : 0;
+	const bool act0 = p < tend && p + 4 <= n;
+	const u32 maxlen = n - p < 258 ? n - p : 258;
+	const u32 dmaxp = p - lo_pos;
+	const u32 nic = nice < maxlen ? nice : maxlen;
+	u32 best = 3, bestd = 0;
+
+	const u32 d1 = (p - (f.c16 >> hsh)) & 0xFFFF;
+	const bool act1 = act0 && d1 > 0 && d1 <= dmaxp && 3 < nic;
+	const u32 cp1 = p - d1;
+	const u32 c2 = LDS16(PREV_OFF + 2 * (cp1 & RMASK));
+	/* the next group: claimed now, its loads requested below */
+	u32 rn = 0, gn = 0;
+	if (PRE)
+		rn = claim_issue(ctr);
+#if RA_PREF >= 3
+	/* the length-3 probes' words: the eight bytes before p, and the
+	 * 3-byte-table candidate's (find_len3()) */
+	const u32 i8 = ((p - 8) & RMASK) & ~3u;
+	const u32 q0 = RAW(i8, 0), q1 = RAW(i8, 4);
+	const u32 d3 = (p - c3v) & 0xFFFF;
+	const u32 o3 = (p - d3) & RMASK, i3 = o3 & ~3u;
+	const u32 r0 = RAW(i3, 0), r1 = RAW(i3, 4);
+#endif
+	const u32 d2 = (p - c2) & 0xFFFF;
+	const bool ch2 = act1 && d2 > d1 && d2 <= dmaxp;
+	const u32 cp2 = p - d2;
+	if (PRE)
+		gn = claim_get(rn);
+	const u32 c3n = LDS16(PREV_OFF + 2 * (cp2 & RMASK));
+	u32 len1, len2;
+	match_length2_p(L, act1, ch2, p, cp1, cp2, cur, nxt8, maxlen, lane,
+			&len1, &len2, [&]() {
+		if (PRE)
+			fnext = ra_first_loads(c3, t, gn, lane, want3);
+	});
+	if (len1 > best) {
+		best = len1;
+		bestd = d1;
+	}
+	const bool act2 = ch2 && best < nic;
+	if (act2 && len2 > best) {
+		best = len2;
+		bestd = d2;
+	}
+	u32 m = best >= 4 && best >= min_len ? best | (bestd << 16) : 0;
+	if (m == 0 && want3 && p < tend && p + 3 <= n) {
+#if RA_PREF >= 3
+		/* find_len3() on the words requested above */
+		const u32 dmax3 = dmaxp > dlim3 ? dlim3 : dmaxp;
+		u32 bd = 0;
+		if (p >= 8) {
+			const u32 A = AB(q1, q0, sp), B = AB(f.a0, q1, sp);
+			u32 mk = 0;
+#define LEN3_TRY(d, x) mk |= ((((x) ^ cur) & 0xFFFFFFu) == 0) << ((d) - 1)
+			LEN3_TRY(8, A);
+			LEN3_TRY(7, AB(B, A, 1));
+			LEN3_TRY(6, AB(B, A, 2));
+			LEN3_TRY(5, AB(B, A, 3));
+			LEN3_TRY(4, B);
+			LEN3_TRY(3, AB(cur, B, 1));
+			LEN3_TRY(2, AB(cur, B, 2));
+			LEN3_TRY(1, AB(cur, B, 3));
+#undef LEN3_TRY
+			if (dmax3 < 8)
+				mk &= (1u << dmax3) - 1;
+			if (mk)
+				bd = (u32)__builtin_ctz(mk) + 1;
+		}
+		if (!bd && d3 && d3 <= dmax3 &&
+		    ((AB(r1, r0, o3 & 3) ^ cur) & 0xFFFFFFu) == 0)
+			bd = d3;
+#else
+		u32 b3 = 0;
+		u32 bd = find_len3(L, p, cur, c3v, dmaxp, dlim3, &b3);
+#endif
+		if (bd)
+			m = 3 | (bd << 16);
+	}
+	Mo[4 + i] = m;
+	/* a chain that ended inside the shallow pass has been searched in full */
+	const u32 dn = (p - c3n) & 0xFFFF;
+	const u32 dcl = act2 && dn > d2 && dn <= dmaxp && best < nic ?
+			done_class : DC_FULL;
+	L->dhalf[g] = __ballot(dcl >= DC_HALF);
+	L->dfull[g] = __ballot(dcl == DC_FULL);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	*(volatile AS3 u32 *)&L->rdy[g] = tag;
+	if (PRE) {
+		g = gn;
+	} else {
+		g = claim_get(claim_issue(ctr));
+		if (g < TILE / 64)
+			fnext = ra_first_loads(c3, t, g, lane, want3);
+	}
+}
+
+static __device__ __forceinline__ void
+round_a_p(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
+	  u32 lo_pos, u32 min_len, u32 done_class, u32 nice, u32 dlim3,
+	  u32 tag, u32 tid)
+{
+	const u32 lane = tid & 63;
+	const u32 ctr = (u32)offsetof(struct deflate_lds, vars) + 4 * V_CTR;
+	u32 g = claim_get(claim_issue(ctr));
+	struct ra_first f = { 0, 0, 0, 0, 0, 0 };
+
+	if (g < TILE / 64)
+		f = ra_first_loads(c3, t, g, lane, min_len <= 3);
+#if RA_PREF >= 2
+	/* two groups per round, the two sets of first loads changing roles: a
+	 * copy at the end of the body would have to wait for the loads */
+	struct ra_first f2 = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+	while (g + RA_PREF_TAIL < TILE / 64) {
+		ra_group<true>(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
+			       tag, lane, g, f, f2);
+		if (!(g + RA_PREF_TAIL < TILE / 64)) {
+			f = f2;
+			break;
+		}
+		ra_group<true>(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
+			       tag, lane, g, f2, f);
+	}
+#endif
+#pragma unroll 1
+	while (g < TILE / 64)
+		ra_group<false>(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
+				tag, lane, g, f, f);
+}
+#endif /* RA_PREF */
+
 static __device__ __forceinline__ void
 round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
 	u32 lo_pos, u32 min_len, u32 ra_depth, u32 done_class, u32 nice, u32 dlim3,
 	u32 tag, u32 tid)
 {
 	const u32 lane = tid & 63;
+#if RA_PREF
+	if (ra_depth == 2 && RA_PAIR) {
+		round_a_p(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
+			  tag, tid);
+		return;
+	}
+#endif
 
 	/* groups of 64 positions are taken from a counter: the two waves that
 	 * insert the next tile meanwhile join in when they are done */
@@ -2399,18 +2819,29 @@ rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
 	const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
 	u32 dep = before < cdepth ? cdepth - before : 0;
 	dep = dep < qg ? dep : qg;
+#if RA_PREF
+	/* (the chain link and the match the position has are requested first:
+	 * they head the dependent loads) */
+	u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
+	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
+	const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
+#endif
 	const u32 cur = ld32(L->in, p);
 	const u64 nxt8 = ld64(L->in, p + 4);
 	const u32 maxlen = n - p < 258 ? n - p : 258;
 	const u32 dmaxp = p - lo_pos;
 	const u32 nic = nice < maxlen ? nice : maxlen;
+#if !RA_PREF
 	const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
+#endif
 	u32 best = l0 >= 4 ? l0 : 3, bestd = l0 >= 4 ? m >> 16 : 0;
 	const u32 best0 = best;
 	u32 boff = best - 3;
 	u32 curb = ld32(L->in, p + boff);
+#if !RA_PREF
 	u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
 	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
+#endif
 	bool act = have && p + 4 <= n && best < nic && dep;
 	bool ended = false;
 	for (u32 ps = 0; ps < npass_g; ps++) {

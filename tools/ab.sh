@@ -21,7 +21,7 @@ for v in "$@"; do
         --chunks $CHUNKS --level $l --iters 5 >> $out 2>&1 || echo "FAILED/TIMEOUT level $l rc=$?" >> $out
   done
   if [ -z "$NODIGEST" ]; then
-    LIBDEFLATE_AMD_LIB=$PWD/$lib timeout -k 5 ${DTMO:-150} python tools/digest_deflate.py --quick \
+    LIBDEFLATE_AMD_LIB=$PWD/$lib timeout -k 5 ${DTMO:-150} python tools/digest_deflate.py ${DIGEST_ARGS:---quick} \
         > gpurun_out/dig_$v.txt 2>&1 || echo "DIGEST FAILED rc=$?" >> $out
     md5sum gpurun_out/dig_$v.txt >> $out
     grep -c . gpurun_out/dig_$v.txt >> $out

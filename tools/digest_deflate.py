@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""digest_deflate.py [--quick] - compress a fixed, seeded set of inputs at
+"""digest_deflate.py [--quick] [--levels=L,...] - compress a fixed, seeded set of inputs at
 every level through the library LIBDEFLATE_AMD_LIB points at and print one
 sha256 per (level, case): two builds whose kernels make the same choices print
 the same lines (`diff` of two runs), which is how a re-scheduling of the
@@ -33,6 +33,9 @@ def main():
     small += datagen.batch(64, 4096, 0x0E110005, mix=datagen.MIX4K)
     big = [datagen.text_chunk(1 << 20, 77) + datagen.binary_chunk(300000, 78)]
     levels = [1, 6, 9, 12] if quick else list(range(13))
+    for a in sys.argv[1:]:
+        if a.startswith("--levels="):	# a subset, e.g. --levels=6,1 (tools/ab.sh)
+            levels = [int(x) for x in a[9:].split(",")]
     bad = 0
     for level in levels:
         fmt = ("deflate", "zlib", "gzip")[level % 3]
