@@ -68,6 +68,16 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#ifndef BALLOT_BUILTIN
+/* __ballot() of the HIP headers takes an int: a predicate that is not one plain
+ * compare is turned into 0 / 1 in a vector register and compared again (two
+ * vector instructions per use); the builtin takes the predicate as it is */
+#define BALLOT_BUILTIN 1
+#endif
+#if BALLOT_BUILTIN
+#define __ballot(p) __builtin_amdgcn_ballot_w64((bool)(p))
+#endif
+
 #ifndef NT
 #define NT LDA_DEFLATE_THREADS
 #endif
@@ -182,10 +192,39 @@ static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
  *      RA_PREF_TAIL groups of a tile: those stay with whoever is free);
  *   3  + the length-3 probes' words are requested at the top of the group.
  * Same results as 0 (tools/digest_deflate.py). */
-#define RA_PREF 0
+#define RA_PREF 2
 #endif
 #ifndef RA_PREF_TAIL
 #define RA_PREF_TAIL NWAVES
+#endif
+#ifndef RB_OPT
+/* round B's walk with fewer vector instructions per chain step (the walk is
+ * issue bound: 16 waves x 16..32 steps per tile): the candidate's LDS
+ * addresses straight from its 16-bit chain entry (a position and its low 16
+ * bits are the same ring slot), the steps left as a compare of the step index
+ * against the pass's budget (a lane that stops stays stopped for the rest of
+ * its pass), the queued-hit count as two wave-uniform masks.  Same results. */
+#define RB_OPT 1
+#endif
+#ifndef AB_NOMASK
+/* v_alignbyte_b32 takes bits 1:0 of its byte count: no mask in front of it
+ * (checked by the digests: a device that took more bits would produce other
+ * streams) */
+#define AB_NOMASK 1
+#endif
+#if AB_NOMASK
+#define ABSH(o, pos) (pos)
+#else
+#define ABSH(o, pos) ((o) & 3)
+#endif
+#ifndef PARSE_OPT
+/* the walk of parse_tile(), one wave's serial chain in phase X, with a third of
+ * the instructions in its first pass (the long one: no earlier path to meet
+ * yet): positions relative to the segment, the token starts kept as two sets
+ * of single bits - where a stretch of the path starts and where its last token
+ * starts - from which the stretches' bits follow in one subtraction at the end
+ * (they are disjoint: 2 x ends - starts).  Same masks. */
+#define PARSE_OPT 1
 #endif
 #ifndef RB_HITS
 #define RB_HITS 2		/* round B: filter hits a lane may queue per pass of 8 steps (4, 2 or 1; a lane with a full queue stalls until the pass's hits are measured: 4 -> 2 is -3 % time for +0.02 % size) */
@@ -307,7 +346,7 @@ static __device__ __forceinline__ u32 ld32(const AS3 u8 *ring, u32 pos)
 {
 	(void)ring;	/* in[] is the first member: byte offset 0 */
 	u32 o = pos & RMASK, i = o & ~3u;
-	return __builtin_amdgcn_alignbyte(LDS32(i + 4), LDS32(i), o & 3);
+	return __builtin_amdgcn_alignbyte(LDS32(i + 4), LDS32(i), ABSH(o, pos));
 }
 
 static __device__ __forceinline__ u64 ld64(const AS3 u8 *ring, u32 pos)
@@ -315,8 +354,8 @@ static __device__ __forceinline__ u64 ld64(const AS3 u8 *ring, u32 pos)
 	(void)ring;
 	u32 o = pos & RMASK, i = o & ~3u;
 	u32 a = LDS32(i), b = LDS32(i + 4), c = LDS32(i + 8);
-	u32 lo = __builtin_amdgcn_alignbyte(b, a, o & 3);
-	u32 hi = __builtin_amdgcn_alignbyte(c, b, o & 3);
+	u32 lo = __builtin_amdgcn_alignbyte(b, a, ABSH(o, pos));
+	u32 hi = __builtin_amdgcn_alignbyte(c, b, ABSH(o, pos));
 	return ((u64)hi << 32) | lo;
 }
 
@@ -2284,6 +2323,50 @@ parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u6
 	u64 mask = 0, nm = 0;
 	bool walking = q < hi;
 
+#if PARSE_OPT
+	/* ---- the first pass (every lane from its guess, nothing to meet) ----
+	 * A stretch of the path: lands at `rel`, a run of literals, then the
+	 * token at r2 = rel + run (or the segment ends inside the run: the
+	 * stretch then ends with its last literal).  Its bits are rel .. r2 =
+	 * 2 * (1 << r2) - (1 << rel); the stretches of a lane are disjoint, so
+	 * all of them are 2 * ends - starts. */
+	{
+		const u64 nlit = ~lit;
+		const s32 hirel = hi - seg_lo;	/* <= 64; positions hirel .. are not mine */
+		const AS3 u16 *const ml = (const AS3 u16 *)(Ms + 4 + seg_lo);	/* the lane's match lengths */
+		u64 starts = 0, ends = 0;
+		/* (a lane is walking while rel < hirel; one without positions to
+		 * walk starts at or past hirel) */
+		s32 rel = q - seg_lo;
+		while (__ballot(rel < hirel)) {
+			if (rel < hirel) {
+				const u64 x = nlit >> (u32)rel;	/* zeros come in: at most 64 - rel literals */
+				const u32 left = (u32)(hirel - rel);	/* > 0 */
+				u32 run = (u32)__builtin_ctzll(x | (1ull << 63));
+				run = x ? run : 64;
+				run = run < left ? run : left;
+				const u32 r2 = (u32)rel + run;	/* <= 64 */
+				const bool tok = run < left;	/* a token that is not a literal starts at r2 */
+				const u32 last = tok ? r2 : r2 - 1;
+				starts |= 1ull << (u32)rel;
+				ends |= 1ull << last;
+				/* (read past the segment where it ends with a literal: the
+				 * entry exists, M[] has 8 more than a tile's) */
+				const u32 len = ml[2 * r2];
+				const u32 st = (u32)(two >> (r2 & 63)) & 1 ? 2 : len;
+				rel = (s32)(tok ? r2 + st : r2);
+			}
+		}
+		/* (a lane that had nothing to walk keeps ex = ein and an empty mask) */
+		if (q < hi) {
+			mask = 2 * ends - starts;
+			ex = seg_lo + rel;
+		}
+		walking = false;
+	}
+#endif
+	/* (after the first pass above no lane is walking: the loop goes straight
+	 * to the exchange) */
 	for (;;) {
 		while (__ballot(walking)) {
 			if (walking) {
@@ -2843,6 +2926,80 @@ rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
 	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
 #endif
 	bool act = have && p + 4 <= n && best < nic && dep;
+#if RB_OPT
+	static_assert(RB_HITS == 2, "RB_OPT keeps the queued hits of a pass as two masks");
+	u64 endm = 0;	/* lanes whose chain has ended (wave-uniform mask) */
+	for (u32 ps = 0; ps < npass_g; ps++) {
+		u64 h1 = 0, h2 = 0;	/* lanes with >= 1 / 2 queued hits */
+		u32 qh = 0, nok = 0;
+		const u32 dep0 = dep;
+		const u64 actm = __ballot(act);
+#pragma unroll
+		for (int s = 0; s < 8; s++) {
+			/* (16-bit instructions of gfx9 clear the upper half of their
+			 * result: one instruction each for the distance and for the
+			 * chain entry's byte offset, 2 x (c16 mod 32768)) */
+			u32 d, c16x2;
+			asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(p), "v"(c16));
+			if (RING == 32768u)
+				asm("v_lshlrev_b16 %0, 1, %1" : "=v"(c16x2) : "v"(c16));
+			else
+				c16x2 = 2 * (c16 & RMASK);
+			/* (a lane that stops - a full queue, the end of its chain or of
+			 * its budget - stays stopped for the rest of the pass, so a lane
+			 * that reaches step s has walked s steps of it; one ballot per
+			 * compare: the masks are combined on the scalar unit) */
+			const u64 chainm = __ballot(dep0 > (u32)s) & __ballot(d > dprev) &
+					   __ballot(d <= dmaxp);
+			const u64 stallm = endm | h2;
+			const u64 okm = actm & ~stallm & chainm;
+			const u32 w = ld32(L->in, c16 + boff);
+			const u32 c16n = LDS16(PREV_OFF + c16x2);
+			const u64 hitm = okm & __ballot(w == curb);
+			const bool ok = lane_bit(okm);
+			c16 = ok ? c16n : c16;
+			dprev = ok ? d : dprev;
+			nok = ok ? (u32)s + 1 : nok;
+			endm |= actm & ~stallm & ~chainm;
+			qh = lane_bit(hitm) ? ((qh << 16) | d) : qh;
+			h2 |= h1 & hitm;
+			h1 |= hitm;
+			PROF_COUNT(20, __builtin_popcountll(okm));
+			PROF_COUNT(17, __builtin_popcountll(hitm));
+		}
+		PROF_COUNT(13, __builtin_popcountll(__ballot(have)));
+		PROF_COUNT(21, (h1 != 0) + (h2 != 0));
+		dep = dep0 - nok;
+		/* evaluate: every lane pops its oldest (closest) hit */
+		if (h1) {
+			const bool ev = lane_bit(h1);
+			const u32 d = lane_bit(h2) ? qh >> 16 : qh & 0xFFFF;
+			const u32 len = match_length(L, ev, p, p - d, cur, nxt8, maxlen, lane);
+			if (ev && len > best) {
+				best = len;
+				bestd = d;
+			}
+		}
+		if (h2) {
+			const bool ev = lane_bit(h2);
+			const u32 d = qh & 0xFFFF;
+			const u32 len = match_length(L, ev, p, p - d, cur, nxt8, maxlen, lane);
+			if (ev && len > best) {
+				best = len;
+				bestd = d;
+			}
+		}
+		if (best >= nic)
+			act = false;
+		if (npass_g > 1) {
+			if (!__ballot(act && !lane_bit(endm) && dep))
+				break;
+			boff = best - 3;
+			curb = ld32(L->in, p + boff);
+		}
+	}
+	const bool ended = lane_bit(endm);
+#else
 	bool ended = false;
 	for (u32 ps = 0; ps < npass_g; ps++) {
 		u32 cnt = 0;
@@ -2897,6 +3054,7 @@ rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
 			curb = ld32(L->in, p + boff);
 		}
 	}
+#endif
 	if (best > best0)
 		L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
 	*next = (e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);

@@ -13,6 +13,13 @@ for v in "$@"; do
   md5sum < gpurun_out/r5dig_$v.txt >> $out
   echo "== $v"; grep -E "deflate\[|FAILED|DIGEST" $out; tail -n 1 $out
 done
+for v in $LEVELS_OF; do	# more levels of the compress kernels only
+  out=gpurun_out/r5l_$v.txt; : > $out
+  for l in ${WLEVELS:-9 1 12}; do
+    LIBDEFLATE_AMD_LIB=$(lib $v) timeout -k 5 $T python tools/microbench.py deflate --chunks 4096 --level $l --iters 5 >> $out 2>&1 || echo "FAILED L$l rc=$?" >> $out
+  done
+  echo "== levels $v"; grep -E "flate\[|FAILED" $out
+done
 for v in $WIDE; do
   out=gpurun_out/r5w_$v.txt; : > $out
   for l in 9 1; do
