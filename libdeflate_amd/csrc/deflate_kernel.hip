@@ -68,15 +68,6 @@
 #include "device_common.h"
 #include "kernels.h"
 
-#ifndef BALLOT_BUILTIN
-/* __ballot() of the HIP headers takes an int: a predicate that is not one plain
- * compare is turned into 0 / 1 in a vector register and compared again (two
- * vector instructions per use); the builtin takes the predicate as it is */
-#define BALLOT_BUILTIN 1
-#endif
-#if BALLOT_BUILTIN
-#define __ballot(p) __builtin_amdgcn_ballot_w64((bool)(p))
-#endif
 
 #ifndef NT
 #define NT LDA_DEFLATE_THREADS
@@ -226,6 +217,9 @@ static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
  * (they are disjoint: 2 x ends - starts).  Same masks. */
 #define PARSE_OPT 1
 #endif
+#ifndef SPLIT_VEC
+#define SPLIT_VEC 1	/* split_stats() on ten lanes instead of ten wave sums and scalar 64-bit products */
+#endif
 #ifndef RB_HITS
 #define RB_HITS 2		/* round B: filter hits a lane may queue per pass of 8 steps (4, 2 or 1; a lane with a full queue stalls until the pass's hits are measured: 4 -> 2 is -3 % time for +0.02 % size) */
 #endif
@@ -272,7 +266,7 @@ struct deflate_lds {
 	u32 scan[2][NWAVES + 1];
 	u32 carry[6];		/* staging bytes kept between blocks */
 	u32 obs[1][10];		/* block-split observations of the block before this tile */
-	u32 vars[24];
+	u32 vars[24] __attribute__((aligned(16)));
 	u64 pm[TILE / 64];	/* parse: token starts of the tile, one bit per position */
 	u64 lit1[TILE / 64];	/* step of the position is 1 (a literal) */
 	u64 lit2[TILE / 64];	/* step is 2 (two literals, lazy2 deferral) */
@@ -305,8 +299,9 @@ static_assert(offsetof(struct deflate_lds, in) == 0, "ld32/ld64 assume in[] at L
 #define PREV_OFF ((u32)offsetof(struct deflate_lds, prev))
 
 enum {
-	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_NPRE, V_TMP0, V_TMP1, V_TMP2,
-	V_TMP3, V_CTR, V_MINLEN, V_SPLIT, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_UNUSED0,
+	/* (the first four are what every tile reads after phase X: one 16-byte read) */
+	V_NSEQ = 0, V_ENTRY, V_WALKPOS_LO, V_SPLIT, V_TMP0, V_TMP1, V_TMP2,
+	V_TMP3, V_CTR, V_MINLEN, V_NPRE, V_NSEQ_PRE, V_WPOS_PRE, V_FIT, V_UNUSED0,
 	V_CTR2, V_PFLAG, V_CTR3, V_STDONE, V_EMDONE, V_TAILDONE, V_CTR4, V_ST2DONE,
 	V_COUNT
 };
@@ -1482,6 +1477,38 @@ insert_tile3(lds_t *L, u16 *__restrict__ c3, u32 t, u32 tend, u32 n, u32 lane)
 	}
 }
 
+/* a claim from an LDS counter without a lane-0 branch: EXEC is narrowed to
+ * lane 0 around one returning add.  claim_issue() only sends it (the result
+ * register is valid in lane 0 once the LDS queue has drained to it),
+ * claim_get() waits and makes the value wave-uniform.  Both must run with all
+ * lanes active.  (As `if (lane == 0) atomicAdd(...)` the compiler's atomic
+ * optimizer wraps every such add in a dozen instructions of lane counting.) */
+static __device__ __forceinline__ u32 claim_issue(u32 lds_byteaddr)
+{
+	u32 r;
+	u64 save;
+	asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+		     : "=&v"(r), "=&s"(save) : "v"(lds_byteaddr), "v"(1u) : "memory");
+	return r;
+}
+
+static __device__ __forceinline__ u32 claim_get(u32 r)
+{
+	u32 g;
+	asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1"
+		     : "=s"(g) : "v"(r) : "memory");
+	return g;
+}
+
+/* the same without a result: one add by lane 0 */
+static __device__ __forceinline__ void lds_add_lane0(u32 lds_byteaddr, u32 v)
+{
+	u64 save;
+	asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+		     : "=&s"(save) : "v"(lds_byteaddr), "v"(v) : "memory");
+}
+#define VAR_ADDR(idx) ((u32)offsetof(struct deflate_lds, vars) + 4 * (idx))
+
 /* ---------------- match measurement ---------------- */
 
 /*
@@ -1635,28 +1662,6 @@ match_length2(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 c
 static __device__ __forceinline__ u64 mk64(u32 lo, u32 hi)
 {
 	return ((u64)hi << 32) | lo;
-}
-
-/* a claim from an LDS counter without a lane-0 branch: EXEC is narrowed to
- * lane 0 around one returning add.  claim_issue() only sends it (the result
- * register is valid in lane 0 once the LDS queue has drained to it),
- * claim_get() waits and makes the value wave-uniform.  Both must run with all
- * lanes active. */
-static __device__ __forceinline__ u32 claim_issue(u32 lds_byteaddr)
-{
-	u32 r;
-	u64 save;
-	asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
-		     : "=&v"(r), "=&s"(save) : "v"(lds_byteaddr), "v"(1u) : "memory");
-	return r;
-}
-
-static __device__ __forceinline__ u32 claim_get(u32 r)
-{
-	u32 g;
-	asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1"
-		     : "=s"(g) : "v"(r) : "memory");
-	return g;
 }
 
 /*
@@ -2232,13 +2237,9 @@ stage_steps_claimed(lds_t *L, const AS3 u32 *Ms, s32 limit, u32 mode, u32 nice, 
 
 #pragma unroll 1
 	for (;;) {
-		u32 g = 0;
-		if (lane == 0) {
-			if (had)
-				atomicAdd((u32 *)&L->vars[V_STDONE], 1u);
-			g = atomicAdd((u32 *)&L->vars[V_CTR3], 1u);
-		}
-		g = bcast_first(g);
+		if (had)
+			lds_add_lane0(VAR_ADDR(V_STDONE), 1u);
+		const u32 g = claim_get(claim_issue(VAR_ADDR(V_CTR3)));
 		if (g >= TILE / 64)
 			break;
 		had = true;
@@ -2270,13 +2271,9 @@ stage_steps_cur_claimed(lds_t *L, s32 limit, u32 mode, u32 nice, u32 lane)
 
 #pragma unroll 1
 	for (;;) {
-		u32 g = 0;
-		if (lane == 0) {
-			if (had)
-				atomicAdd((u32 *)&L->vars[V_ST2DONE], 1u);
-			g = atomicAdd((u32 *)&L->vars[V_CTR4], 1u);
-		}
-		g = bcast_first(g);
+		if (had)
+			lds_add_lane0(VAR_ADDR(V_ST2DONE), 1u);
+		const u32 g = claim_get(claim_issue(VAR_ADDR(V_CTR4)));
 		if (g >= TILE / 64)
 			break;
 		had = true;
@@ -2525,12 +2522,9 @@ emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
 		 * loop's one lane-0 section: see round_a(); its histogram atomics
 		 * are LDS operations of this wave and complete after the wait) */
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		if (lane == 0) {
-			if (had)
-				atomicAdd((u32 *)&L->vars[V_EMDONE], 1u);
-			g = atomicAdd((u32 *)&L->vars[V_CTR2], 1u);
-		}
-		g = bcast_first(g);
+		if (had)
+			lds_add_lane0(VAR_ADDR(V_EMDONE), 1u);
+		g = claim_get(claim_issue(VAR_ADDR(V_CTR2)));
 		if (g >= TILE / 64)
 			break;
 		had = true;
@@ -3136,6 +3130,43 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 static __device__ __forceinline__ void
 split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
 {
+#if SPLIT_VEC
+	/* The wave that computes this is the last thing of phase X (every token
+	 * of the tile has to be out first) with fifteen waves at the barrier: its
+	 * instruction count is on the tile's path.  Class sums: the 320 counts
+	 * added into ten LDS words (class of literal sy = lane + 64 j is 2 j +
+	 * (lane & 1); matches: length slots 0..5 (3..8) / 6..28); the rest on
+	 * lanes 0..9, one class each.  The products fit 32 bits: a tile adds at
+	 * most TOK_TILE_MAX < 2^13 observations to at most TOK_CAP < 2^17. */
+	static_assert(TOK_TILE_MAX < (1u << 13) && TOK_CAP < (1u << 17), "32-bit products");
+	AS3 u32 *const acc = (AS3 u32 *)&L->scan[1][0];	/* (no block scan runs beside this) */
+	if (lane < 10)
+		acc[lane] = 0;
+	wave_sync();
+#pragma unroll
+	for (u32 j = 0; j < 4; j++)
+		atomicAdd((u32 *)&acc[2 * j + (lane & 1)], L->freq[lane + 64 * j]);
+	if (lane < 29)
+		atomicAdd((u32 *)&acc[8 + (lane >= 6)], L->freq[257 + lane]);
+	wave_sync();
+	const u32 now = lane < 10 ? acc[lane] : 0;
+	const u32 prev = lane < 10 ? L->obs[0][lane] : 0;
+	const u32 d = now - prev;
+	const u32 nprev = row16_sum(prev), nnew = row16_sum(d);
+	const u32 a = d * nprev, e = prev * nnew;
+	const u32 df = a > e ? a - e : e - a;
+	const u64 delta = ((u64)row16_sum(df >> 16) << 16) + row16_sum(df & 0xFFFF);
+	bool sp = nprev && walkpos - block_start >= 5000 &&
+		  delta >= (u64)nnew * 200 / 512 * nprev;
+	if (fit_split && walkpos - block_start >= 5000)
+		sp = true;	/* see opt_build_costs() */
+	wave_sync();
+	if (lane < 10)
+		L->obs[0][lane] = sp ? 0 : now;
+	if (lane == 0)
+		L->vars[V_SPLIT] = !sp ? 0 :
+			L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
+#else
 	/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
 	 * matches: length slots 0..5 (3..8) / 6..28 */
 	u32 onow[10], oprev[10];
@@ -3183,6 +3214,7 @@ split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
 	if (lane == 0)
 		L->vars[V_SPLIT] = !sp ? 0 :
 			L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
+#endif
 }
 
 #ifdef LDA_DEBUG_SPLIT	/* per-tile trace of the block-split inputs of buffer 0 (debug builds) */
@@ -3822,7 +3854,10 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 				if (!cur_real)
 					continue;	/* iteration 0, dictionary tiles: nothing to emit */
 
-				walkpos = bcast_first(L->vars[V_WALKPOS_LO]);
+				/* (levels 0-9: walkpos, the split decision and the token count
+				 * come with one read, see "block end?") */
+				if (OPT && mode == 3)
+					walkpos = bcast_first(L->vars[V_WALKPOS_LO]);
 				/* the last 4 match entries go to the front of the next tile's,
 				 * for the positions the walk deferred */
 				if (tid < 4)
@@ -3854,10 +3889,22 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			 * the tile's tokens (already in the match list) become the start
 			 * of the next block.  Only when that would leave a block shorter
 			 * than the minimum, the block ends after the tile. */
-			const u32 splitv = splits && !stored_only && !last_tile ?
-					   bcast_first(L->vars[V_SPLIT]) : 0;
+			u32 splitv, nseq_now;
+			if (OPT && mode == 3) {
+				splitv = splits && !stored_only && !last_tile ?
+					 bcast_first(L->vars[V_SPLIT]) : 0;
+				nseq_now = stored_only ? 0 : bcast_first(L->vars[V_NSEQ]);
+			} else {
+				/* (three dependent LDS round trips were 3 % of a tile) */
+				const uint4 pv = *(const AS3 uint4 *)&L->vars[V_NSEQ];
+				static_assert(V_NSEQ == 0 && V_WALKPOS_LO == 2 && V_SPLIT == 3, "one 16-byte read");
+				if (!stored_only)
+					walkpos = bcast_first(pv.z);
+				splitv = splits && !stored_only && !last_tile ? bcast_first(pv.w) : 0;
+				nseq_now = stored_only ? 0 : bcast_first(pv.x);
+			}
 			bool end_block = last_tile || splitv ||
-				(!stored_only && bcast_first(L->vars[V_NSEQ]) + 2 * TOK_TILE_MAX > TOK_CAP) ||
+				(!stored_only && nseq_now + 2 * TOK_TILE_MAX > TOK_CAP) ||
 				walkpos - block_start > MAX_BLOCK_LEN;
 			if (!end_block)
 				continue;
@@ -3868,7 +3915,7 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 			const u32 bstart = block_start;
 			const u32 bend = last_tile ? n : retro ? bcast_first(L->vars[V_WPOS_PRE]) : walkpos;
 			const u32 blen = bend - bstart;
-			const u32 nseq_all = stored_only ? 0 : bcast_first(L->vars[V_NSEQ]);
+			const u32 nseq_all = nseq_now;
 			const u32 nseq = retro ? bcast_first(L->vars[V_NSEQ_PRE]) : nseq_all;
 			const u32 is_final = last_tile && seg_last ? 1 : 0;
 			if (retro) {

@@ -10,6 +10,21 @@
 
 #define LDA_WAVE 64
 
+/*
+ * __ballot() of the HIP headers takes an int: a predicate that is not one plain
+ * compare is turned into 0 / 1 in a vector register and compared again (two
+ * vector instructions per use, in loops whose cost is their instruction count);
+ * the builtin takes the predicate as it is.  Where a predicate is a conjunction
+ * of compares, one ballot per compare and the masks combined on the scalar
+ * unit is cheaper still (rb_batch() in deflate_kernel.hip).
+ */
+#ifndef BALLOT_BUILTIN
+#define BALLOT_BUILTIN 1
+#endif
+#if BALLOT_BUILTIN
+#define __ballot(p) __builtin_amdgcn_ballot_w64((bool)(p))
+#endif
+
 typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
@@ -107,6 +122,17 @@ static __device__ __forceinline__ u32 wave_scan_incl(u32 v)
 	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);	/* row_bcast15 -> rows 1, 3 */
 	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);	/* row_bcast31 -> rows 2, 3 */
 	return v;
+}
+
+/* sum over lanes 0..15 (the first row), wave-uniform; the caller's lanes 16..63
+ * take no part */
+static __device__ __forceinline__ u32 row16_sum(u32 v)
+{
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);	/* row_shr:1 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);	/* row_shr:2 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);	/* row_shr:4 */
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);	/* row_shr:8 */
+	return (u32)__builtin_amdgcn_readlane((int)v, 15);
 }
 
 /* sum over the wave, wave-uniform: the last lane of the DPP scan */
