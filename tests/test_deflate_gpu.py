@@ -207,6 +207,53 @@ def test_device_batch_roundtrip(oracle):
         d.close()
 
 
+@pytest.mark.timeout(180)
+def test_many_buffers_per_workgroup(oracle):
+    """A batch several times the number of CUs: every workgroup takes buffer after buffer
+    from the batch's counter, so whatever state a buffer leaves in the LDS or in the
+    workgroup's HBM scratch meets the next buffer.  (A variant of the token emission that
+    passed every single-buffer-per-workgroup test hung exactly here: round 5,
+    tools/experiments/.)  Checked against zlib and the oracle on a sample, against our own
+    decoder on every byte; under a timeout, because the failure to expect is a hang."""
+    import torch
+    from libdeflate_amd import api
+    n, size = 2560, 65536          # 10 buffers per workgroup on 256 CUs
+    chunks = datagen.batch(n, size, 0x0E110077, distinct=48)
+    data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * size
+    in_n = torch.full((n,), size, dtype=torch.int64, device="cuda")
+    for fmt, lvl in (("gzip", 6), ("deflate", 1), ("zlib", 9)):
+        c = api.Compressor(lvl)
+        d = api.Decompressor()
+        bound = (c.bound(fmt, size) + 15) // 16 * 16
+        comp = torch.zeros(n * bound, dtype=torch.uint8, device="cuda")
+        c_off = torch.arange(n, dtype=torch.int64, device="cuda") * bound
+        c_av = torch.full((n,), bound, dtype=torch.int64, device="cuda")
+        c_n = torch.zeros(n, dtype=torch.int64, device="cuda")
+        c.compress_batch(fmt, data, in_off, in_n, comp, c_off, c_av, c_n)
+        torch.cuda.synchronize()
+        sizes = c_n.cpu().numpy()
+        assert (sizes > 0).all() and (sizes <= c.bound(fmt, size)).all()
+        out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+        res = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        d.decompress_batch(fmt, comp, c_off, c_n, out, in_off, in_n, res)
+        torch.cuda.synchronize()
+        assert int((res != 0).sum()) == 0
+        assert torch.equal(out, data)
+        cb = comp.cpu().numpy()
+        for i in range(7, n, 211):
+            z = cb[i * bound:i * bound + sizes[i]].tobytes()
+            _check_roundtrip(oracle, fmt, chunks[i], z, (fmt, i))
+        # the same chunk gives the same stream wherever it sits in the batch
+        first = {}
+        for i in range(n):
+            k = i % 48
+            z = cb[i * bound:i * bound + sizes[i]].tobytes()
+            assert first.setdefault(k, z) == z, (fmt, i)
+        c.close()
+        d.close()
+
+
 def test_small_blocks_zlib_level9(oracle):
     """Config-5 shape, 262 144 blocks (1 GiB): 4 KiB filesystem-block mix,
     zlib, level 9, device batch round trip, every byte compared + Adler-32
