@@ -81,6 +81,31 @@ def pmc_kernel(what, kernel):
     return (json.load(open(files[-1])).get(kernel, {}), os.path.relpath(files[-1], ROOT))
 
 
+def kernel_src_digest():
+    """sha256 prefix over the kernel sources and their build flags: which build
+    a committed PMC profile belongs to (tools/prof_pmc.sh records it in the
+    profile's `_workload`).  A profile of another build gives no issue_frac."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libdeflate_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) +
+                    [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_is_of_this_build(path):
+    """(True / False / None = the profile does not say) - ADVICE r5: instruction
+    counts of another build must not be combined with this run's launch time."""
+    try:
+        w = json.load(open(path)).get("_workload", {})
+    except (OSError, ValueError):
+        return None
+    sha = w.get("kernel_src_sha16")
+    return None if sha is None else sha == kernel_src_digest()
+
+
 def issue_roof(what, kernel, t_launch, launches=1):
     """The roof the compress / decompress kernels actually run against: VALU
     issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles, an
@@ -92,9 +117,12 @@ def issue_roof(what, kernel, t_launch, launches=1):
     v = k.get("SQ_INSTS_VALU_per_launch")
     if not v or not t_launch:
         return None
+    same = profile_is_of_this_build(os.path.join(ROOT, src))
     out = {"kernel": kernel,
            "valu_wave_insts_per_launch": int(v),
-           "issue_frac": round(v * launches * 4 / (1024 * 2.4e9 * t_launch), 3),
+           # only a profile of THIS build may be combined with this run's time
+           "issue_frac": round(v * launches * 4 / (1024 * 2.4e9 * t_launch), 3) if same else None,
+           "profile_of_this_build": same,
            "source": f"{src} (static: PMC passes of tools/prof_pmc.sh, not this run) "
                      "/ this run's launch time; nominal 2.4 GHz"}
     if "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
@@ -126,6 +154,8 @@ def pmc_static():
         traffic = int(2 * k["FETCH_SIZE_per_launch"] * 1024 +
                       k["WRITE_SIZE_per_launch"] * 1024)
     valu = k.get("SQ_INSTS_VALU_per_launch")
+    if not profile_is_of_this_build(files[-1]):
+        valu = None  # another build's instruction count says nothing about this run
     return traffic, valu, src
 
 
@@ -142,7 +172,7 @@ def inflate_static(t_dec):
     if "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
         out["traffic"] = int(2 * k["FETCH_SIZE_per_launch"] * 1024 +
                              k["WRITE_SIZE_per_launch"] * 1024)
-    if k.get("SQ_INSTS_VALU_per_launch"):
+    if k.get("SQ_INSTS_VALU_per_launch") and profile_is_of_this_build(files[-1]):
         v = k["SQ_INSTS_VALU_per_launch"]
         out["issue"] = {"valu_wave_insts_per_launch": int(v),
                         "simd_issue_frac": round(v * 4 / (1024 * 2.4e9 * t_dec), 3),
@@ -738,6 +768,10 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses cuda:0 (with --backend gloo: the "
                          "multi-rank path on a single-GPU box)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run every collective of "
+                         "the N > 1 path even at world size 1 (RCCL executed on a "
+                         "single-GPU box: tests/test_rccl_gpu.py)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -752,9 +786,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -825,6 +863,8 @@ def main():
             "decompress_MBps": round(U * world / t_dec / 1e6, 1),
             "compressed_ratio": round(C / U, 4),
             "verdicts": {"chunks": int(total_chunks), "failed": int(n_fail)},
+            "collectives": {"backend": dist.get_backend() if dist else None, "world": world,
+                            "forced_at_world_1": bool(a.force_dist and world == 1)},
             "verified": "round trip byte-exact on every rank (torch.equal over the batch); " +
                         (f"all {head['nref']} compressed streams of rank 0 decoded by the real "
                          "reference (oracle/_ref) to the original bytes, outside the timed region"

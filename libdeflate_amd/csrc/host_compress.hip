@@ -280,8 +280,15 @@ libdeflate_amd_compress_batch_host(struct libdeflate_compressor *c, int format,
 			o.free_func = c->free_func;
 			if (on.ok())
 				c->shard[k] = libdeflate_alloc_compressor_ex(c->level, &o);
-			if (!c->shard[k])
-				return (int)LIBDEFLATE_AMD_NO_DEVICE;
+			if (!c->shard[k]) {
+				/* a device that cannot take its shard (out of memory,
+				 * refused by the self-check, busy): the batch stays on
+				 * the object's own device rather than fail - the reason
+				 * stays in libdeflate_amd_last_error() */
+				fanout_note(1);
+				return compress_batch_host_body(c, format, n, in, in_nbytes, out, out_avail,
+							out_nbytes);
+			}
 		}
 		return fanout_run(shards, [&](size_t k) {
 			const size_t lo = bounds[k], cnt = bounds[k + 1] - lo;

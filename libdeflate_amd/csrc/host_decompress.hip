@@ -307,8 +307,15 @@ libdeflate_amd_decompress_batch_host(struct libdeflate_decompressor *d,
 			o.free_func = d->free_func;
 			if (on.ok())
 				d->shard[k] = libdeflate_alloc_decompressor_ex(&o);
-			if (!d->shard[k])
-				return (int)LIBDEFLATE_AMD_NO_DEVICE;
+			if (!d->shard[k]) {
+				/* a device that cannot take its shard (out of memory,
+				 * refused by the self-check, busy): the batch stays on
+				 * the object's own device rather than fail - the reason
+				 * stays in libdeflate_amd_last_error() */
+				fanout_note(1);
+				return decompress_batch_host_body(d, format, n, in, in_nbytes, out, out_avail,
+							  results, actual_in, actual_out);
+			}
 		}
 		return fanout_run(shards, [&](size_t k) {
 			const size_t lo = bounds[k], cnt = bounds[k + 1] - lo;

@@ -20,8 +20,9 @@
  * one process with threads; it is the multi-device entry point the C-ABI did
  * not have.
  */
+#include <new>
+#include <stdio.h>
 #include <thread>
-#include <vector>
 
 #include "host_objects.h"
 
@@ -64,31 +65,56 @@ size_t fanout_plan(int own_device, size_t n, const size_t *nbytes, size_t *bound
 
 int fanout_run(size_t shards, const std::function<int(size_t)> &fn)
 {
-	std::vector<int> rc(shards, (int)LIBDEFLATE_AMD_OK);
-	std::vector<std::thread> th;
-	size_t started = 1;
+	/* Nothing may unwind past a joinable std::thread (that is std::terminate),
+	 * and the error text is per thread: every shard - the calling thread's
+	 * included - runs inside no_unwind, leaves its status and its message in
+	 * its own slot, and the first failing shard's message becomes the
+	 * caller's libdeflate_amd_last_error() after ALL threads were joined. */
+	struct Slot {
+		int rc = (int)LIBDEFLATE_AMD_OK;
+		char msg[256] = { 0 };
+	};
+	Slot *slot = new (std::nothrow) Slot[shards];
+	if (!slot) {
+		set_error("fan-out: out of host memory");
+		return (int)LIBDEFLATE_AMD_OOM;
+	}
+	auto run = [slot, &fn](size_t k) {
+		slot[k].rc = no_unwind("fan-out shard", (int)LIBDEFLATE_AMD_OOM,
+				       [&]() { return fn(k); });
+		if (slot[k].rc != LIBDEFLATE_AMD_OK) {
+			const char *m = libdeflate_amd_last_error();
+			snprintf(slot[k].msg, sizeof(slot[k].msg), "%s", m ? m : "");
+		}
+	};
+	std::thread *th = new (std::nothrow) std::thread[shards];
+	size_t started = 0;	/* threads th[1..started] run shards 1..started */
 
-	th.reserve(shards);
-	for (size_t k = 1; k < shards; k++) {
-		try {
-			th.emplace_back([&rc, &fn, k] {
-				rc[k] = no_unwind("fan-out shard", (int)LIBDEFLATE_AMD_OOM,
-						  [&]() { return fn(k); });
-			});
-			started++;
-		} catch (...) {
-			break;	/* no thread to be had: the calling one takes the rest */
+	if (th) {
+		for (size_t k = 1; k < shards; k++) {
+			try {
+				th[k] = std::thread(run, k);
+				started = k;
+			} catch (...) {
+				break;	/* no thread to be had: the calling one takes the rest */
+			}
 		}
 	}
-	rc[0] = fn(0);
-	for (size_t k = started; k < shards; k++)
-		rc[k] = fn(k);
-	for (std::thread &t : th)
-		t.join();
+	run(0);
+	for (size_t k = started + 1; k < shards; k++)
+		run(k);
+	for (size_t k = 1; k <= started; k++)
+		th[k].join();
+	delete[] th;
+	int rc = (int)LIBDEFLATE_AMD_OK;
 	for (size_t k = 0; k < shards; k++)
-		if (rc[k] != LIBDEFLATE_AMD_OK)
-			return rc[k];
-	return LIBDEFLATE_AMD_OK;
+		if (slot[k].rc != LIBDEFLATE_AMD_OK) {
+			rc = slot[k].rc;
+			set_error("shard %zu of %zu: %s", k, shards, slot[k].msg);
+			break;
+		}
+	delete[] slot;
+	return rc;
 }
 
 } /* namespace lda */

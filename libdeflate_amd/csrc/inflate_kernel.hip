@@ -53,9 +53,6 @@
 #include "kernels.h"
 
 #ifndef PAR_PRIO
-#ifndef FAR_SC1
-#define FAR_SC1 0	/* far match sources through the L2 (measured: see DESIGN 3.2) */
-#endif
 #define PAR_PRIO 1	/* wave-per-stream: issue priority by the share of the input still ahead */
 #endif
 #define LIT_TB 9
@@ -562,9 +559,6 @@ ring_fill(lu8 *ring, const u8 *inp, u64 in_n, u64 at)
 #ifndef PAR_CB
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
 #endif
-#ifndef PAR_PAIR
-#define PAR_PAIR 1
-#endif
 #define PAR_LANECAP (PAR_CB / 2)	/* tokens one lane may find in its piece (2 bits each) */
 #define PAR_SCRATCH (64u * PAR_LANECAP)	/* u32 words per wave */
 #define PAR_MAP_BYTES (256u + 128u)	/* tok_fetch: marks + tbase table */
@@ -623,6 +617,7 @@ static __device__ __forceinline__ void pb_init(struct par_bits *b, const lu8 *in
  * (length, distance), bits used; long codewords take the bit-serial path */
 struct par_token {
 	u32 kind, lit, length, dist, used;
+	u32 e1;		/* the litlen table entry behind the first codeword */
 };
 
 /*
@@ -698,6 +693,12 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	 * a handful of ALU operations where a table would put another LDS round
 	 * trip on the token-to-token dependence chain */
 	u64 bb = buf >> cl;
+	/* what follows a literal is looked up now, beside the offset codeword of
+	 * a match and not behind it: a step is two dependent LDS round trips
+	 * for every kind of token (the callers pair two literals) */
+#ifndef E1_LATE
+	t.e1 = S->lit_tab[(u32)bb & ((1u << LIT_TB) - 1)];
+#endif
 	u32 lbase, xb;
 	len_sym(pay & 31, &lbase, &xb);
 	t.length = lbase + ((u32)bb & ((1u << xb) - 1));
@@ -718,6 +719,9 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	t.kind = kind;
 	t.lit = pay & 0xFF;
 	t.used = cl + (kind == K_LEN ? xb + ol + dxb : 0);
+#ifdef E1_LATE	/* (A/B knob of round 6: the lookup behind the offset codeword, as before) */
+	t.e1 = S->lit_tab[(u32)(buf >> t.used) & ((1u << LIT_TB) - 1)];
+#endif
 	return t;
 }
 
@@ -746,6 +750,25 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 }
 
 typedef __attribute__((address_space(1))) u8 gu8;	/* output bytes in HBM */
+
+/*
+ * Output bytes one lane of the wave stored are read back by another lane
+ * (match sources older than the LDS mirror; the sequential decoder's matches
+ * behind a parallel round or a stored block).  Between such a store and such
+ * a load the wave waits until every earlier vector-memory operation has
+ * completed - s_waitcnt vmcnt(0): on gfx9 a store leaves the counter when the
+ * L2 has it, and the wave's L1 is write-through - which is what the
+ * compiler's memory model emits for a workgroup-scope release / acquire pair
+ * (AMDGPUUsage, memory model gfx942, non-tgsplit mode).  Nothing here rests
+ * on how the L1 treats a store that is still in flight.
+ */
+static __device__ __forceinline__ void global_stores_visible(void)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 /*
  * A round whose passes do not converge.  The passes rest on a parse started
@@ -790,14 +813,9 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 			run = run && PB_POS(b) < pe;
 			pb_refill(&b, span);
 			const struct par_token t = par_decode(S, SH, pll, plo, b.buf);
-#if PAR_PAIR
-			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const u32 e1 = t.e1;
 			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < pe &&
 					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
-#else
-			const u32 e1 = 0;
-			const bool two = false;
-#endif
 			if (run) {
 				u32 used = t.used + (two ? e1 & 15 : 0);
 				if (t.kind == K_EOB) {
@@ -945,7 +963,11 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
 						  load_in(inp, in_n, pos);
 		}
-		wave_sync();
+		/* the staged words have arrived, and with them every store the
+		 * wave issued before this round (the rounds before, the sequential
+		 * decoder, a stored block): what this round reads back from the
+		 * output below `out0` is in memory */
+		global_stores_visible();
 	}
 	const lu8 *span = stage;	/* the parse reads the staged copy */
 	const u32 bpos0 = (u32)bpos_abs & 7;	/* positions relative to the span */
@@ -979,18 +1001,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, span);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
-#if PAR_PAIR
 			/* A literal takes a second one with it when that one starts
 			 * inside the piece and its codeword is in the table: a pass
 			 * lasts as long as its lane with the most tokens, and those
 			 * are the lanes full of literals. */
-			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const u32 e1 = t.e1;
 			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
 					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
-#else
-			const u32 e1 = 0;
-			const bool two = false;
-#endif
 			if (run) {
 				u32 used = t.used;
 				if (t.kind == K_EOB) {
@@ -1098,6 +1115,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		gu8 *gout = (gu8 *)outp;
 		u64 gbase = out0;
 		u64 flushed = out0;	/* output below this is in memory */
+		u64 safe_hi = out0;	/* ... and below this its stores have been waited for */
 		u32 g = 0;		/* a multiple of 4: 16-byte token loads */
 		/* four consecutive tokens per lane; the next group's are requested
 		 * as soon as this group's extent is known, so their trip to the
@@ -1216,26 +1234,20 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					bad |= toofar;
 					vfar[k] = 0x100;	/* not a byte: no far source */
 					if (__ballot(far)) {
-						/* the source may be a byte another lane of this
-						 * wave stored earlier in the round (flush_ring):
-						 * a wave's vector-memory operations are performed
-						 * in issue order and the store is visible to the
-						 * load (tools/hwtest_global_visibility.hip measures
-						 * exactly this, tests/test_hw_gpu.py runs it; a
-						 * s_waitcnt vmcnt(0) here would also wait for the
-						 * token rows requested ahead and cost 5 % on 65 536
-						 * streams) */
-#if FAR_SC1
-						/* (device scope: served by the L2, which this
-						 * wave's earlier store has reached in order) */
-						if (far)
-							vfar[k] = __hip_atomic_load(
-								(const u8 *)&gfar[bi + 32768u - dist],
-								__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
+						/* The source may be a byte another lane of this
+						 * wave stored earlier in THIS round (flush_ring);
+						 * everything below safe_hi was stored before a
+						 * wait.  Only a source at or above it - rare: it
+						 * must be older than the mirror and younger than
+						 * the last wait - makes the wave wait for its
+						 * stores (and for the token rows requested ahead)
+						 * before it loads. */
+						if (__ballot(far && dist - bi <= (u32)(gbase - safe_hi))) {
+							global_stores_visible();
+							safe_hi = flushed;
+						}
 						if (far)
 							vfar[k] = gfar[bi + 32768u - dist];
-#endif
 					}
 				}
 				/* copies inside a slot: where each lane's byte finally comes
@@ -1643,7 +1655,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				}
 				if ((len & ~7ull) + lane < len)
 					dst[(len & ~7ull) + lane] = src[(len & ~7ull) + lane];
-				wave_sync();	/* later matches read these bytes */
+				global_stores_visible();	/* later matches read these bytes */
 				if (state == ST_STORED) {
 					/* the register history describes the bytes before
 					 * the stored block: a short-distance match of the
@@ -1744,6 +1756,10 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				if (pr == PAR_EOB)
 					break;
 			}
+			/* lane 0's sequential decoder may copy from what all lanes
+			 * stored in the rounds above (once per block; the staged
+			 * input of a following round waits the same way) */
+			global_stores_visible();
 		}
 
 		/* ------------ fast token loop ------------

@@ -133,7 +133,7 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 			*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
 						  load_in(inp, in_n, pos);
 		}
-		wave_sync();
+		global_stores_visible();	/* as par_round(): the stores of the rounds before */
 	}
 	const lu8 *span = stage;
 	struct par_long pll, plo;
@@ -161,7 +161,7 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 			run = run && PB_POS(b) < cend;
 			pb_refill(&b, span);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
-			const u32 e1 = S->lit_tab[(u32)(b.buf >> t.used) & ((1u << LIT_TB) - 1)];
+			const u32 e1 = t.e1;
 			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
 					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
 			if (run) {
@@ -256,6 +256,7 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 		lu16 *R = (lu16 *)((lu32 *)stage + 256);
 		u64 gbase = out0;
 		u64 flushed = out0;
+		u64 safe_hi = out0;	/* symbols below this were stored before a wait (stage_input) */
 		u32 g = 0;
 		bool bad = false;
 		uint4 tq_next = tok_fetch(tokS, mk, tb, tbase, own_cnt, 0, total_tok, lane);
@@ -356,8 +357,12 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 					if (outside)
 						vfar[k] = 0x8000u | (32768u - (back - in_chunk));
 					if (__ballot(far)) {
-						/* (store -> load visibility inside a wave: see
-						 * par_round() and tools/hwtest_global_visibility.hip) */
+						/* a symbol stored in this round, after the last
+						 * wait: see par_round() */
+						if (__ballot(far && back <= (u32)(gbase - safe_hi))) {
+							global_stores_visible();
+							safe_hi = flushed;
+						}
 						if (far)
 							vfar[k] = sym[gbase - back];
 					}
@@ -422,7 +427,8 @@ stage_input(lu8 *stage, const u8 *inp, u64 in_n, u64 byte0, u32 nbytes, u32 lane
 		*(lu64 *)(stage + 8 * w) = pos + 8 <= in_n ? ld8(inp + pos) :
 					  load_in(inp, in_n, pos);
 	}
-	wave_sync();
+	/* ... and every store of the rounds before has completed (par_round()) */
+	global_stores_visible();
 }
 
 /*

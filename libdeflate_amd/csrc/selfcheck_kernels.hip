@@ -10,14 +10,20 @@
  *     address must be served in ascending lane order.  A device that serves
  *     them otherwise would still produce valid streams (candidates are
  *     byte-verified) but worse ones.
- *  2. a wave's global store is visible to its own following load from another
- *     lane.  par_round() (inflate_kernel.hip) reads match sources older than
- *     its LDS mirror from the output in HBM, where another lane of the same
- *     wave may have stored them a moment earlier, with a wavefront-scope fence
- *     in between (no instructions on gfx9: the compiler's memory model takes a
- *     wave's vector memory operations to be performed in order).  A device on
- *     which that load could return the old byte would corrupt raw DEFLATE
- *     output silently.
+ *  2. a wave's global store is visible to a following load of another lane
+ *     of the same wave.  par_round() (inflate_kernel.hip) reads match sources
+ *     older than its LDS mirror from the output in HBM, where another lane of
+ *     the same wave may have stored them earlier in the round.  Since round 6
+ *     the kernel waits for its outstanding stores first (s_waitcnt vmcnt(0):
+ *     global_stores_visible(), the compiler's workgroup-scope release /
+ *     acquire sequence), so this is architected behaviour; the probe is kept
+ *     as a belt and uses the product's own kind of access - plain
+ *     (non-volatile) global stores and loads, no sc0 / sc1 bits in the ISA
+ *     (tests/test_abi.py checks the encoding), separated by exactly that
+ *     sequence.  A device on which such a load could return the old byte
+ *     would corrupt raw DEFLATE output silently and is refused.  (The form
+ *     without the wait, which the kernel used until round 5, is still
+ *     measured at length by tools/hwtest_global_visibility.hip.)
  *
  * Both are measured at length by tools/hwtest_lds_order.hip and
  * tools/hwtest_global_visibility.hip (tests/test_hw_gpu.py); these are their
@@ -92,13 +98,20 @@ lda_selfcheck_lds_order_kernel(u64 *__restrict__ counters /* [0] lanes, [1] mism
 #define SC_ROUNDS 256
 #define SC_REGION 8192	/* bytes per wave */
 
+typedef __attribute__((address_space(1))) u8 sc_gu8;
+typedef __attribute__((address_space(1))) u32 sc_gu32;
+
 extern "C" __global__ void __launch_bounds__(64, 4)
 lda_selfcheck_visibility_kernel(u8 *__restrict__ buf,
 				u64 *__restrict__ counters /* [3] loads, [4] stale */)
 {
 	const u32 lane = threadIdx.x & 63;
-	volatile u8 *r = buf + (size_t)blockIdx.x * SC_REGION;
-	volatile u32 *rw = (volatile u32 *)r;
+	/* plain global accesses, like gout[] / gfar[] of par_round(): the
+	 * compiler must not see through the store -> load pairs (it cannot: the
+	 * loading lane differs from the storing one) and must not reorder them
+	 * (the fences) */
+	sc_gu8 *r = (sc_gu8 *)(buf + (size_t)blockIdx.x * SC_REGION);
+	sc_gu32 *rw = (sc_gu32 *)r;
 	unsigned long long bad = 0;
 	u32 x = 0x9E3779B9u * (blockIdx.x + 1);
 
@@ -107,17 +120,20 @@ lda_selfcheck_visibility_kernel(u8 *__restrict__ buf,
 		const u32 base = (x >> 8) % (SC_REGION - 1024);
 		const u32 perm = ((x >> 3) | 1) & 63;	/* odd multiplier: a permutation of the lanes */
 		const u32 val = it * 64 + lane;
-		/* lane l stores byte l of a 64-byte slot, lane (l * perm) & 63 reads it */
-		r[base + lane] = (u8)val;
-		__builtin_amdgcn_wave_barrier();	/* a compiler barrier, like wave_sync()'s */
 		const u32 src = (lane * perm) & 63;
-		const u8 gotb = r[base + src];
-		bad += gotb != (u8)(it * 64 + src);
+		/* the product's form: store, wait for the stores, load */
+		r[base + lane] = (u8)val;
 		const u32 wb = ((base + 512) & ~3u) / 4;
 		rw[wb + lane] = val ^ 0xA5A5A5A5u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_wave_barrier();
-		const u32 gw = rw[wb + src];
-		bad += gw != ((it * 64 + src) ^ 0xA5A5A5A5u);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const u8 gotb = r[base + src];
+		const u32 gotw = rw[wb + src];
+		bad += gotb != (u8)(it * 64 + src);
+		bad += gotw != ((it * 64 + src) ^ 0xA5A5A5A5u);
+		wave_sync();
 	}
 	bad = wave_sum64(bad);
 	if (lane == 0) {

@@ -16,6 +16,11 @@ GPUs, gloo in the CPU tests:
 
 Under gloo the collectives run on host copies of the tensors, so that the
 same control flow can be exercised by several ranks sharing one GPU.
+
+A caller without a process group passes dist=None and gets its own data back.
+A process group of ONE rank still goes through every collective (all_reduce,
+gather; no peer, so no send / recv): `bench.py --gpus 1 --force-dist` and
+tests/test_rccl_gpu.py run the RCCL code path that way on a single-GPU box.
 """
 import torch
 
@@ -40,7 +45,7 @@ def gather_verdicts(sizes, results, dist, world):
     (total_chunks, n_failed) on rank 0 and (local count, local failed)
     elsewhere.  sizes: int64[n]; results: int32[n]."""
     packed = torch.stack([sizes, results.to(torch.int64)], dim=1).contiguous()
-    if dist is None or world == 1:
+    if dist is None:
         return packed.shape[0], int((packed[:, 1] != 0).sum())
     packed = _coll(packed, dist)
     rank = dist.get_rank()
@@ -80,7 +85,7 @@ def gather_payload(segment, dist, world):
     first; then every other rank sends its bytes to the root and the root
     posts the matching receives (one transfer per peer, nothing travels to a
     rank that does not need it - SURVEY.md 8(e): grouped ncclSend/ncclRecv)."""
-    if dist is None or world == 1:
+    if dist is None:
         return [segment]
     segment = _coll(segment.contiguous(), dist)
     rank = dist.get_rank()

@@ -411,7 +411,13 @@ def parallel_round_streams():
                       from 1 to 200: long matches whose distance is below,
                       at and above the 64-byte slot size (copies inside a
                       slot, across slots, runs);
-      far             matches that reach 5..30 KiB back, past the LDS mirror."""
+      far             matches that reach 5..30 KiB back, past the LDS mirror;
+      flushed*        (round 6) hand-built static blocks whose matches take their
+                      sources from just behind the 4 KiB LDS mirror, 2.9..11 KiB
+                      back in a sweep: bytes the wave stored to the output
+                      earlier in the SAME round (the round's first group, the
+                      group before the last wait, ...) and now loads back -
+                      the case global_stores_visible() exists for."""
     import random
     import zlib
     out = []
@@ -437,6 +443,27 @@ def parallel_round_streams():
     data = b"".join(pieces)
     co = zlib.compressobj(9, zlib.DEFLATED, -15)
     out.append(("far", co.compress(data) + co.flush(), data))
+    for v, (lo, hi, step, lits) in enumerate(((2900, 11000, 37, 3), (3900, 4400, 1, 0),
+                                              (3000, 9000, 211, 40))):
+        w = BitWriter()
+        w.put(1, 1)
+        w.put(1, 2)                     # final, static
+        data = bytearray(rng.randrange(256) for _ in range(12000))
+        for b in data:
+            _static_lit(w, b)
+        d = lo
+        while len(data) < 150000:
+            length = rng.choice((3, 4, 9, 30, 64, 65, 130, 258))
+            _static_match(w, length, d)
+            for k in range(length):
+                data.append(data[-d])
+            for _ in range(rng.randrange(0, lits + 1)):
+                b = rng.randrange(256)
+                _static_lit(w, b)
+                data.append(b)
+            d = lo if d + step > hi else d + step
+        _static_lit(w, 256)
+        out.append((f"flushed{v}", w.finish(), bytes(data)))
     return out
 
 

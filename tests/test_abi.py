@@ -94,7 +94,8 @@ def test_compress_kernels_keep_their_register_budget():
     in a slower bench: the report of the compile itself, no GPU needed."""
     csrc = os.path.join(os.path.dirname(__file__), "..", "libdeflate_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read()
-    assert re.search(r"deflate_kernel\.o.*deflate_small\.o: CXXFLAGS \+= -mllvm -disable-machine-licm", mk)
+    assert re.search(r"^NOLICM \?= .*\bdeflate_kernel\b.*\bdeflate_small\b", mk, re.M)
+    assert re.search(r"\$\(NOLICM\).*: CXXFLAGS \+= -mllvm -disable-machine-licm", mk)
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
@@ -111,3 +112,48 @@ def test_compress_kernels_keep_their_register_budget():
     spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", rep)]
     assert vgprs and max(vgprs) <= 96, vgprs      # round 5's final build: 85 / 83
     assert spills and max(spills) == 0, spills
+
+
+def _device_asm(src, *flags):
+    csrc = os.path.join(os.path.dirname(__file__), "..", "libdeflate_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        *flags, "--cuda-device-only", "-S", src, "-o", "-"],
+                       cwd=csrc, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def _kernel_body(asm, name):
+    m = re.search(r"^%s:[^\n]*\n(.*?)\n\s*s_endpgm" % re.escape(name), asm, re.M | re.S)
+    assert m, name
+    return m.group(1)
+
+
+def test_visibility_probe_uses_the_products_access_pattern():
+    """the self-check that admits a device must test the access the product
+    makes.  The inflate kernel reads back output bytes another lane of the wave stored
+    with PLAIN global loads (served by the L1) behind an explicit `s_waitcnt vmcnt(0)`
+    (global_stores_visible()); a volatile access would compile to `sc0 sc1`, system
+    scope, and test something else.  Checked on the ISA of both, no GPU needed: the
+    probe's and the product's byte loads / stores carry no sc / nt bits, and both
+    contain the wait as inline asm."""
+    probe = _kernel_body(_device_asm("selfcheck_kernels.hip"), "lda_selfcheck_visibility_kernel")
+    mem = [l.strip() for l in probe.splitlines()
+           if re.match(r"\s*(global|flat|buffer)_(load|store)", l)]
+    assert len(mem) >= 4, mem
+    assert not [l for l in mem if re.search(r"\b(sc0|sc1|nt)\b", l)], mem
+    assert all(l.startswith("global_") for l in mem), mem
+    assert re.search(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)", probe)
+    from libdeflate_amd import binding  # noqa: F401  (the Makefile's flags for this object)
+    mk = open(os.path.join(os.path.dirname(__file__), "..", "libdeflate_amd", "csrc", "Makefile")).read()
+    nolicm = re.search(r"^NOLICM \?= (.*)$", mk, re.M).group(1).split()
+    flags = ("-mllvm", "-disable-machine-licm") if "inflate_kernel" in nolicm else ()
+    wave = _kernel_body(_device_asm("inflate_kernel.hip", *flags), "lda_inflate_wave_kernel")
+    far = [l.strip() for l in wave.splitlines() if re.match(r"\s*global_load_ubyte", l)]
+    assert far, "no byte loads from the output in the wave kernel?"
+    assert not [l for l in far if re.search(r"\b(sc0|sc1|nt)\b", l)], far
+    # the four slots of a batch each have their conditional wait + the round start + the block end
+    assert len(re.findall(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)", wave)) >= 6

@@ -146,8 +146,11 @@ def test_container_bytes(oracle):
 
 
 def test_ratio_tracks_reference(oracle):
-    """Reported, loosely gated: GPU level L within 3% of the reference's
-    compressed size at level L on the 64 KiB mix."""
+    """GPU level L against the reference's compressed size at level L on the
+    64 KiB mix, gated where the documents claim it: within
+    1.2 % at levels 1 / 6 / 9 and 1.0 % at levels 10 / 12 (measured: 1.004 -
+    1.007x; the gate was 3 % until round 5, which a 2 % regression would have
+    passed)."""
     from libdeflate_amd import api
     from tests import oracle_util
     ref = oracle_util.load_ref()
@@ -164,7 +167,7 @@ def test_ratio_tracks_reference(oracle):
         else:
             theirs = sum(len(streams._zcompress("deflate", lvl, d)) for d in chunks)
         print(f"level {lvl}: ours {ours} ref {theirs} ratio {ours/theirs:.4f}")
-        assert ours <= theirs * 1.03
+        assert ours <= theirs * (1.012 if lvl <= 9 else 1.010), (lvl, ours, theirs)
         c.close()
     # the min-cost parse of levels 10-12 must pay for itself
     assert sizes[10] < sizes[9] and sizes[12] <= sizes[10]

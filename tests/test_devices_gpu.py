@@ -24,12 +24,16 @@ def test_one_visible_device_is_one_shard(monkeypatch):
     from libdeflate_amd import api
     monkeypatch.setenv("LDA_DEVICES", "all")
     binding.reload_env()
-    chunks = _chunks(64, 65536, 0xD0)
+    # a shard is at least 1 MiB (fanout_plan): 2 MiB per visible device, so that
+    # an 8-GPU node gets its 8 shards (64 chunks gave at most 4)
+    ndev = torch.cuda.device_count()
+    chunks = _chunks(32 * max(2, ndev), 65536, 0xD0)
+    mib = sum(map(len, chunks)) >> 20
     c, d = api.Compressor(6), api.Decompressor()
     comp = c.compress_batch_host("gzip", chunks)
-    assert binding.last_fanout() == min(torch.cuda.device_count(), 16)
+    assert binding.last_fanout() == min(ndev, 16, mib)
     got = d.decompress_batch_host("gzip", comp, [len(x) for x in chunks])
-    assert binding.last_fanout() == min(torch.cuda.device_count(), 16)
+    assert binding.last_fanout() == min(ndev, 16, mib)
     assert all(g[0] == 0 and g[3] == x for g, x in zip(got, chunks))
     c.close(); d.close()
 

@@ -48,7 +48,11 @@ for f in sorted(glob.glob("$R/gpurun_out/pmc_$what/*/**/*counter_collection.csv"
         for c, v in d.items():
             out[k][c + "_per_launch"] = v / max(1, len(disp[k]))
         out[k]["launches_seen"] = max(out[k].get("launches_seen", 0), len(disp[k]))
-out["_workload"] = {"what": "$what", "command": "$cmd".replace("$R/", "")}
+import sys
+sys.path.insert(0, "$R")
+import bench
+out["_workload"] = {"what": "$what", "command": "$cmd".replace("$R/", ""),
+                    "kernel_src_sha16": bench.kernel_src_digest()}
 json.dump(out, open("$R/gpurun_out/pmc_$what.json", "w"), indent=1, sort_keys=True)
 for k, d in out.items():
     if k != "_workload":
