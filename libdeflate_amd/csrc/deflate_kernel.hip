@@ -111,127 +111,39 @@
 #define TOK_CAP (MAX_BLOCK_LEN + 2 * TILE + 64)	/* u32 entries */
 #define SEQ_GCAP (TOK_CAP / 2)			/* the same in u64 words */
 #define SEQ_STRIDE (SEQ_GCAP + (TILE + 8) / 2 + 320 + 256 + (TILE + 8) / 2)	/* u64 words of HBM scratch per workgroup */
-#ifndef S3_WALK
 #define S3_WALK 8		/* chain steps per walk pass (a lane stalls while its 4-entry hit queue is full) */
-#endif
-#ifndef S3_EVMIN
 #define S3_EVMIN 1u		/* lanes with a queued hit that trigger an evaluate round */
-#endif
-#ifndef S3_TAIL
 #define S3_TAIL 256u		/* positions at the end of a tile searched with reduced depth */
-#endif
-#ifndef S3_CLAIM
 #define S3_CLAIM 24u		/* finished lanes that trigger a claim pass */
-#endif
-#ifndef S3_RA_DEPTH
 #define S3_RA_DEPTH 2u		/* chain members the shallow pass measures at every position */
-#endif
-#ifndef S6_ALWAYS_FLUSH
 #define S6_ALWAYS_FLUSH 0
-#endif
-#ifndef S3_HALF_SHIFT
 #define S3_HALF_SHIFT 1		/* the look-ahead positions are searched to depth >> this (the reference: 1) */
-#endif
-#ifndef S3_HALF
 #define S3_HALF 1		/* 0: the lazy rule's look-ahead positions are not searched deeper */
-#endif
-#ifndef P1_PASSES
 #define P1_PASSES 0xFFFFFFFFu	/* passes of the first (worklist) parse */
-#endif
-#ifndef RB_DEFER
-/* the last generation of round B runs inside phase X, beside the next tile's
- * shallow search (see rb_last_gen() and the schedule); not in the small-buffer
- * kernel: its four waves have no eight to spare */
+/* The last generation of round B runs inside phase X, beside the next tile's
+ * shallow search (rb_last_gen() and the schedule), and round A measures its two
+ * candidates side by side (match_length2_p()).  Neither in the small-buffer
+ * kernel: its four waves have no eight to spare, and several workgroups share a
+ * CU there and hide each other's LDS round trips already (the longer code
+ * measured 12 % slower). */
 #ifdef LDA_SMALL
 #define RB_DEFER 0
+#define RA_PAIR 0
 #else
 #define RB_DEFER 1
+#define RA_PAIR 1
 #endif
-#endif
-#ifndef RB_TAIL_WAVES
 #define RB_TAIL_WAVES 8u	/* waves 1..8 take a deferred generation: at most 512 items */
-#endif
 static_assert(!RB_DEFER || RB_TAIL_WAVES + 3 <= NWAVES,
 	      "wave 0 parses, the last two waves insert: the tail waves lie between them");
-#ifndef STEP_BRANCHFREE
-#define STEP_BRANCHFREE 1
-#endif
-#ifndef S3_ROUNDS
 #define S3_ROUNDS 1u		/* deepening rounds (parse -> search what it visits) per tile */
-#endif
 #ifndef WQ_CAP
 #define WQ_CAP 2048u		/* round B items per round; the rest waits for the next round */
 #endif
 #define WQ_SEG (WQ_CAP / NWAVES)
-#ifndef RA_PAIR
-/* round A measures its two candidates side by side (match_length2()).  Not
- * in the small-buffer kernel: several workgroups share a CU there and hide each
- * other's LDS round trips already; the longer code measured 12 % slower. */
-#ifdef LDA_SMALL
-#define RA_PAIR 0
-#else
-#define RA_PAIR 1
-#endif
-#endif
-#ifndef RA_PREF
-/* round A with its LDS round trips taken off the wave's dependent chain (the
- * phase is a chain of LDS round trips per group of 64 positions):
- *   1  the raw words of a measuring stage are all requested before any is used
- *      (match_length*p()), the chain link of a position before its input words;
- *   2  + the NEXT group is claimed and its first loads are requested while the
- *      current group's candidates are on their way (not in the last
- *      RA_PREF_TAIL groups of a tile: those stay with whoever is free);
- *   3  + the length-3 probes' words are requested at the top of the group.
- * Same results as 0 (tools/digest_deflate.py). */
-#define RA_PREF 2
-#endif
-#ifndef RA_PREF_TAIL
 #define RA_PREF_TAIL NWAVES
-#endif
-#ifndef RB_OPT
-/* round B's walk with fewer vector instructions per chain step (the walk is
- * issue bound: 16 waves x 16..32 steps per tile): the candidate's LDS
- * addresses straight from its 16-bit chain entry (a position and its low 16
- * bits are the same ring slot), the steps left as a compare of the step index
- * against the pass's budget (a lane that stops stays stopped for the rest of
- * its pass), the queued-hit count as two wave-uniform masks.  Same results. */
-#define RB_OPT 1
-#endif
-#ifndef AB_NOMASK
-/* v_alignbyte_b32 takes bits 1:0 of its byte count: no mask in front of it
- * (checked by the digests: a device that took more bits would produce other
- * streams) */
-#define AB_NOMASK 1
-#endif
-#if AB_NOMASK
 #define ABSH(o, pos) (pos)
-#else
-#define ABSH(o, pos) ((o) & 3)
-#endif
-#ifndef PARSE_OPT
-/* the walk of parse_tile(), one wave's serial chain in phase X, with a third of
- * the instructions in its first pass (the long one: no earlier path to meet
- * yet): positions relative to the segment, the token starts kept as two sets
- * of single bits - where a stretch of the path starts and where its last token
- * starts - from which the stretches' bits follow in one subtraction at the end
- * (they are disjoint: 2 x ends - starts).  Same masks. */
-#define PARSE_OPT 1
-#endif
-#ifndef SPLIT_VEC
-#define SPLIT_VEC 1	/* split_stats() on ten lanes instead of ten wave sums and scalar 64-bit products */
-#endif
-#ifndef RB_HITS
-#define RB_HITS 2		/* round B: filter hits a lane may queue per pass of 8 steps (4, 2 or 1; a lane with a full queue stalls until the pass's hits are measured: 4 -> 2 is -3 % time for +0.02 % size) */
-#endif
-#ifndef GEN_TRIM
-#define GEN_TRIM 1		/* round B: the depth ends with a generation, see search_queue() */
-#endif
-#ifndef GEN_GROW
-#define GEN_GROW 1		/* round B: generation g walks (g + 1) quanta */
-#endif
-#ifndef WQ_LIMIT
 #define WQ_LIMIT WQ_CAP		/* items taken per round (<= WQ_CAP) */
-#endif
 /* nxtA / nxtB: two scratch arrays of NXT_ELEMS u16 (round B lists of WQ_CAP
  * u32 each, the bit staging area, block-end tables) */
 #define NXT_ELEMS (2 * WQ_CAP + 8)
@@ -276,6 +188,7 @@ struct deflate_lds {
 	u32 qn[4];		/* round B: item counts of three generations in rotation */
 	u32 gbase[TILE / 64];	/* emit: first token-list index of each group of 64 positions */
 	u32 rdy[TILE / 64 + 1];	/* round A: the iteration that last finished this group of nxt (+ 1) */
+	u8 lslot[256];		/* length - 3 -> length slot (length_code()), built once per workgroup */
 };
 
 /* LDS-resident: every pointer into the block carries the address space, and
@@ -499,27 +412,29 @@ find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 		dmax = dlim;
 	if (p >= 8) {
 		/* the eight nearest distances without a branch: the three bytes at
-		 * p - d for d = 8..1 are byte windows of (p-8..p-5, p-4..p-1, cur) -
-		 * one funnel shift each - and the smallest matching distance is the
-		 * lowest set bit of the eight comparison results */
+		 * p - d for d = 8..1 are byte windows of (p-8..p-5, p-4..p-1, cur);
+		 * v_perm_b32 cuts each out with a zero byte on top (selector 0x0C),
+		 * so a window is one instruction and its test one compare with the
+		 * position's own three bytes; the nearest distance that matches wins
+		 * (a chain of selects, farthest first) and is valid iff it is within
+		 * dmax - every other match is farther */
 		const u64 w8 = ld64(L->in, p - 8);
 		const u32 A = (u32)w8, B = (u32)(w8 >> 32);
-		u32 m = 0;
-#define LEN3_TRY(d, x) m |= ((((x) ^ cur) & 0xFFFFFFu) == 0) << ((d) - 1)
-		LEN3_TRY(8, A);
-		LEN3_TRY(7, __builtin_amdgcn_alignbyte(B, A, 1));
-		LEN3_TRY(6, __builtin_amdgcn_alignbyte(B, A, 2));
-		LEN3_TRY(5, __builtin_amdgcn_alignbyte(B, A, 3));
-		LEN3_TRY(4, B);
-		LEN3_TRY(3, __builtin_amdgcn_alignbyte(cur, B, 1));
-		LEN3_TRY(2, __builtin_amdgcn_alignbyte(cur, B, 2));
-		LEN3_TRY(1, __builtin_amdgcn_alignbyte(cur, B, 3));
+		const u32 cur3 = cur & 0xFFFFFFu;
+		u32 bd = 0;
+#define LEN3_TRY(d, hi, lo, sel) bd = __builtin_amdgcn_perm(hi, lo, sel) == cur3 ? (d) : bd
+		LEN3_TRY(8, A, A, 0x0C020100u);
+		LEN3_TRY(7, A, A, 0x0C030201u);
+		LEN3_TRY(6, B, A, 0x0C040302u);
+		LEN3_TRY(5, B, A, 0x0C050403u);
+		LEN3_TRY(4, B, B, 0x0C020100u);
+		LEN3_TRY(3, B, B, 0x0C030201u);
+		LEN3_TRY(2, cur, B, 0x0C040302u);
+		LEN3_TRY(1, cur, B, 0x0C050403u);
 #undef LEN3_TRY
-		if (dmax < 8)
-			m &= (1u << dmax) - 1;
-		if (m) {
+		if (bd && bd <= dmax) {
 			*best = 3;
-			return (u32)__builtin_ctz(m) + 1;
+			return bd;
 		}
 	}
 	u32 d = (p - c3_16) & 0xFFFF;
@@ -540,7 +455,6 @@ find_len3(const lds_t *L, u32 p, u32 cur, u32 c3_16, u32 dmax,
 static __device__ __forceinline__ u32
 token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 {
-#if STEP_BRANCHFREE
 	/* without a branch: every lane evaluates both look-aheads and selects
 	 * (as nested ifs this compiled into a dozen EXEC-mask sections per call -
 	 * 72 scalar instructions and as many branches around 50 vector ones, on
@@ -559,696 +473,10 @@ token_step(u32 m0, u32 m1, u32 m2, u32 mode, u32 nice)
 	u32 st = c2 ? 2 : l0;
 	st = c1 ? 1 : st;
 	return l0 == 0 ? 1 : st;
-#else
-	u32 l0 = m0 & 0xFFFF;
-
-	if (l0 == 0)
-		return 1;
-	if (mode >= 1 && l0 < nice) {
-		s32 b0 = 31 - __builtin_clz(m0 >> 16);
-		u32 l1 = m1 & 0xFFFF;
-		if (l1 >= l0 &&
-		    4 * (s32)(l1 - l0) + (b0 - (s32)(31 - __builtin_clz(m1 >> 16))) > 2)
-			return 1;
-		if (mode >= 2) {
-			u32 l2 = m2 & 0xFFFF;
-			if (l2 >= l0 &&
-			    4 * (s32)(l2 - l0) +
-			    (b0 - (s32)(31 - __builtin_clz(m2 >> 16))) > 6)
-				return 2;
-		}
-	}
-	return l0;
-#endif
 }
 
-/* ---------------- min-cost parse (levels 10-12) ---------------- */
-
-/*
- * The reference's levels 10-12 (lib/deflate_compress.c:3327-3849) collect all
- * matches per position with a binary-tree finder, run a backward min-cost DP
- * over a whole block and re-cost it several times.  Restated for the tile
- * pipeline:
- *   - the candidates of a position are all the lengths 3..L of its best
- *     (longest, then nearest) match from the chain search;
- *   - symbol prices are -log2 of the frequencies of the block so far, in
- *     1/16 bit.  The first tile of a block has no history: it is parsed
- *     lazily into the histogram first (a dry run that is rolled back), and if
- *     pure literals priced by the tile's own byte statistics would be
- *     cheaper than that parse, literal prices come from the byte statistics
- *     and match prices from flat defaults (the role of the reference's
- *     default-cost tables, :2986-3102);
- *   - the DP runs backwards, per wave over 256 positions plus 64 positions
- *     of warm-up beyond them (a min-cost parse forgets where it started
- *     within a few tokens, like a Huffman parse re-synchronises), with the
- *     cost-to-go of the positions ahead held in registers: no memory traffic
- *     inside the recurrence (opt_parse_wave());
- *   - the chosen lengths replace the match lengths in M[], and the ordinary
- *     token walk (S4, greedy rule) follows them.
- */
-#define OPT_SEG 256
-#define OPT_WARM 64
-#define OPT_BIG 0x40000000u
-#ifndef OPT_FIT_NUM
-#define OPT_FIT_NUM 7u	/* the block's literal statistics "fit" a tile up to 7/4 of */
-#define OPT_FIT_DEN 4u	/* the tile's own literal-only estimate */
-#endif
-/* price tables (u16, 1/16 bit) and the byte histogram live in the block-end
- * scratch, which is dead until S4 uses nxtB */
-#define OPT_LIT(L) ((AS3 u16 *)(L)->sorted)	/* [256] by literal */
-#define OPT_LEN(L) ((AS3 u16 *)(L)->codes)	/* [259] by length, extra bits included */
-#define OPT_OFF(L) ((AS3 u16 *)(L)->pre_items)	/* [30] by offset slot, extra bits included */
-#define OPT_HIST(L) ((AS3 u32 *)(L)->hw)	/* [256] bytes of the tile */
-
-static __device__ __forceinline__ u32 opt_price(u32 f, float lg_total, float maxbits)
-{
-	float b = lg_total - __log2f((float)f + 0.4f);
-	b = fminf(fmaxf(b, 1.0f), maxbits);
-	return (u32)(b * 16.0f + 0.5f);
-}
-
-/* Prices from freq[]; with try_flat (freq[] = lazy parse of this tile alone)
- * the literal-only estimate decides between them and the flat start.
- * Without try_flat (freq[] = the block so far) the return value tells whether
- * the block's literal statistics fit this tile's bytes at all: 0 = they do;
- * 1 = poorly: the tile is better parsed by the lazy rule than with prices
- * that describe other data; 2 = not at all: the content has changed, the
- * block should end here whatever the observation classes of the split
- * heuristic say (they cannot tell a 16-letter alphabet from text once both
- * are mostly literals).
- * Whole workgroup; ends with a barrier. */
-static __device__ u32
-opt_build_costs(lds_t *L, u32 tid, bool try_flat, bool check_fit, u32 t, u32 tn, u32 *bsave)
-{
-	u32 *osave = bsave + 256;
-	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
-	AS3 u32 *o0 = OPT_HIST(L);
-	u32 tl, to;
-	(void)block_scan(L, tid < 286 ? L->freq[tid] : 0, &tl);
-	(void)block_scan(L, tid >= 288 && tid < 318 ? L->freq[tid] : 0, &to);
-	const float lgl = __log2f((float)tl + 1.0f), lgo = __log2f((float)to + 1.0f);
-	u32 est = 0, lsl = 0, lxb = 0, lxv = 0;
-	if (tid < 256) {
-		u32 f = L->freq[tid], c = opt_price(f, lgl, 14.0f);
-		lit[tid] = (u16)c;
-		est = f * c;
-	} else if (tid < 512) {
-		u32 l = tid - 253;	/* 3..258 */
-		length_code(l, &lsl, &lxb, &lxv);
-		u32 f = L->freq[257 + lsl], c = opt_price(f, lgl, 14.0f) + 16 * lxb;
-		len[l] = (u16)c;
-		if (lxv == 0)
-			est = f * c;
-	} else if (tid < 542) {
-		u32 sl = tid - 512, xb = sl < 4 ? 0 : (sl >> 1) - 1;
-		u32 f = L->freq[288 + sl], c = opt_price(f, lgo, 12.0f) + 16 * xb;
-		off[sl] = (u16)c;
-		est = f * c;
-	}
-	if (try_flat) {
-		u32 el, e0;
-		(void)block_scan(L, est, &el);
-		for (u32 i = tid; i < 256; i += NT)
-			o0[i] = 0;
-		__syncthreads();
-		for (u32 i = tid; i < tn; i += NT)
-			atomicAdd((u32 *)&o0[L->in[(t + i) & RMASK]], 1u);
-		__syncthreads();
-		u32 cf = 0, e = 0;
-		if (tid < 256) {
-			u32 f = o0[tid];
-			cf = opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
-			e = f * cf;
-			bsave[tid] = 0;	/* the block's bytes start with this tile */
-			osave[tid] = f;
-		}
-		(void)block_scan(L, e, &e0);
-		if (e0 < el) {
-			if (tid < 256)
-				lit[tid] = (u16)cf;
-			else if (tid < 512)
-				len[tid - 253] = (u16)(16 * (7 + lxb));
-			else if (tid < 542) {
-				u32 sl = tid - 512;
-				off[sl] = (u16)(16 * (5 + (sl < 4 ? 0 : (sl >> 1) - 1)));
-			}
-		}
-		__syncthreads();
-		return 0;
-	}
-	if (!check_fit) {	/* prices only (second pass over a first tile) */
-		__syncthreads();
-		return 0;
-	}
-	/* fit: the tile's bytes priced as literals of this block vs by their own
-	 * statistics (both without the share of the matches) */
-	u32 tlit, e_blk, e_own;
-	(void)block_scan(L, tid < 256 ? L->freq[tid] : 0, &tlit);
-	for (u32 i = tid; i < 256; i += NT)
-		o0[i] = 0;
-	__syncthreads();
-	for (u32 i = tid; i < tn; i += NT)
-		atomicAdd((u32 *)&o0[L->in[(t + i) & RMASK]], 1u);
-	__syncthreads();
-	u32 eb = 0, eo = 0, bb = 0, tb, tv2;
-	if (tid < 256) {
-		u32 f = o0[tid];
-		eb = f * opt_price(L->freq[tid], __log2f((float)tlit + 1.0f), 14.0f);
-		eo = f * opt_price(f, __log2f((float)tn + 1.0f), 14.0f);
-		/* bytes of the block so far (the previous tile joins them now) */
-		bb = bsave[tid] + osave[tid];
-		bsave[tid] = bb;
-		osave[tid] = f;
-	}
-	(void)block_scan(L, eb, &e_blk);
-	(void)block_scan(L, eo, &e_own);
-	/* total variation between the byte distributions of this tile and of
-	 * the block: homogeneous data stays below 0.5 (drifting binary counters
-	 * reach it), a change of content is 0.7 and up */
-	(void)block_scan(L, bb, &tb);
-	u32 dv = 0;
-	if (tid < 256 && tb) {
-		float d = (float)o0[tid] / (float)tn - (float)bb / (float)tb;
-		dv = (u32)(fabsf(d) * 65536.0f);
-	}
-	(void)block_scan(L, dv, &tv2);	/* 2 TV in 1/65536 */
-	__syncthreads();
-	if (tv2 > (u32)(2 * 0.6f * 65536.0f))
-		return 2;
-#ifdef LDA_DEBUG_SPLIT
-	if (tid == 0)
-		L->vars[V_TMP3] = 100 * e_blk / (e_own ? e_own : 1);
-#endif
-	return OPT_FIT_DEN * e_blk <= OPT_FIT_NUM * e_own ? 0 : 2 * e_blk <= 5 * e_own ? 1 : 2;
-}
-
-/* minimum over the wave, wave-uniform */
-static __device__ __forceinline__ u32 wave_min_u32(u32 v)
-{
-	u32 o;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x111, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x112, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x114, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x118, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x142, 0xA, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x143, 0xC, 0xF, false);
-	v = o < v ? o : v;
-	return (u32)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-/* minimum over lanes 0..15, wave-uniform */
-static __device__ __forceinline__ u32 row0_min_u32(u32 v)
-{
-	u32 o;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x111, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x112, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x114, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	o = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, v, 0x118, 0xF, 0xF, false);
-	v = o < v ? o : v;
-	return (u32)__builtin_amdgcn_readlane((int)v, 15);
-}
-
-/*
- * One wave's part of the min-cost parse: chosen length (1 = literal) for the
- * tile-relative positions [lo, hi) into ch16[position + 4]; positions up to
- * 'e' are parsed as warm-up.  Backwards, one position p per step.  The stage
- * is bound by VALU issue (16 waves x 4 cycles per instruction), so the step
- * is built to need few vector instructions:
- *   - c(p) = min(c(p+1) + literal, best match candidate) runs on the scalar
- *     unit; the costs are packed as cost << 9 so that adding the packed
- *     length price (price << 9 | length) and taking the minimum yields the
- *     cost and the length together;
- *   - the costs of the 64 positions p+3.. sit in w0 (lane j = position
- *     p + 3 + j): the candidates of a match of up to 66 bytes are one add,
- *     one select and a DPP reduction (over one row of 16 lanes when the
- *     match is no longer than 18); w0 slides by one lane per step, and
- *     c(p+2) enters at lane 0;
- *   - longer matches are rare: the costs further ahead are kept as
- *     snapshots of w0 taken every 64 steps (ws1..ws4; at step s of a group
- *     lane j of ws_k is length s + 3 + j + 64 (k - 1)) and looked at only
- *     then, with the length prices read from LDS.
- */
-static __device__ void
-opt_parse_wave(lds_t *L, AS3 u16 *ch16, u32 t, s32 lo_, s32 hi_, s32 e_, u32 lane)
-{
-	AS3 u16 *lit = OPT_LIT(L), *len = OPT_LEN(L), *off = OPT_OFF(L);
-	/* wave-uniform by construction; tell the compiler, or the step loop
-	 * is compiled as a divergent one */
-	const s32 lo = __builtin_amdgcn_readfirstlane(lo_);
-	const s32 hi = __builtin_amdgcn_readfirstlane(hi_);
-	const s32 e = __builtin_amdgcn_readfirstlane(e_);
-	const u32 lcp0 = ((u32)len[3 + lane] << 9) | (3 + lane);
-	const bool lane0 = lane == 0;
-	u32 w0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0;
-	const u32 nsteps = (u32)(e - lo);
-	u32 ch = 0, c1 = 0, c2 = 0;	/* c1 = c(p+1), c2 = c(p+2) */
-	/* groups of 64 steps: position data in, snapshots rotated, choices out */
-	for (u32 g0 = 0; g0 < nsteps; g0 += 64) {
-		const u32 cnt = (u32)__builtin_amdgcn_readfirstlane(
-			(int)(nsteps - g0 < 64 ? nsteps - g0 : 64));
-		const s32 ptop = e - 1 - (s32)g0;	/* lane j = position ptop - j */
-		u32 pk = 0;
-		{
-			s32 pj = ptop - (s32)lane;
-			if (pj >= lo) {
-				u32 m = L->M[pj + 4], lm = m & 0xFFFF, oc = 0;
-				if (lm >= 3) {
-					u32 ds, xb, xv;
-					dist_code(m >> 16, &ds, &xb, &xv);
-					oc = off[ds];
-				} else {
-					lm = 0;
-				}
-				u32 lc = lit[L->in[(t + (u32)pj) & RMASK]];
-				pk = lm | (oc << 9) | (lc << 18);
-			}
-		}
-		ws4 = ws3;
-		ws3 = ws2;
-		ws2 = ws1;
-		ws1 = w0;
-		for (u32 sl = 0; sl < cnt; sl++) {
-			const u32 q = (u32)__builtin_amdgcn_readlane((int)pk, sl);
-			const u32 lm = q & 511, oc = (q >> 9) & 511, lc = q >> 18;
-			u32 best = c1 + (lc << 9) + 1;
-			if (lm >= 3) {
-				u32 cand = lane + 3 <= lm ? w0 + lcp0 : OPT_BIG;
-				u32 mn;
-				if (lm <= 18) {
-					mn = row0_min_u32(cand);
-				} else {
-					if (lm > 66) {
-						/* the asm statement keeps this a branch instead
-						 * of predicated instructions on every step */
-						u32 ln = lane;	/* opaque: no address induction
-								 * variable in the common path */
-						asm volatile("; long match" : "+v"(ln));
-						const u32 l1 = sl + 3 + ln;
-						u32 x1 = l1 <= lm ? ws1 + (((u32)len[l1] << 9) | l1) : OPT_BIG;
-						u32 x2 = l1 + 64 <= lm ? ws2 + (((u32)len[l1 + 64] << 9) | (l1 + 64)) : OPT_BIG;
-						u32 x3 = l1 + 128 <= lm ? ws3 + (((u32)len[l1 + 128] << 9) | (l1 + 128)) : OPT_BIG;
-						u32 l4 = l1 + 192 <= 258 ? l1 + 192 : 258;
-						u32 x4 = l1 + 192 <= lm ? ws4 + (((u32)len[l4] << 9) | l4) : OPT_BIG;
-						x1 = x2 < x1 ? x2 : x1;
-						x3 = x4 < x3 ? x4 : x3;
-						cand = x1 < cand ? x1 : cand;
-						cand = x3 < cand ? x3 : cand;
-					}
-					mn = wave_min_u32(cand);
-				}
-				mn += oc << 9;
-				best = mn < best ? mn : best;
-			}
-			{	/* ch[lane sl] = chosen length.  v_writelane_b32 takes one
-				 * SGPR, so the lane select travels in m0 - saved and put back
-				 * inside the statement (m0 is a reserved register: it may not
-				 * simply be declared clobbered); the s_nop covers the
-				 * lane-select hazard the compiler cannot see in the asm */
-				const u32 cl = best & 511;
-				u32 m0save;
-				asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\t"
-				    "v_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-				    : "+v"(ch), "=&s"(m0save) : "s"(cl), "s"(sl));
-			}
-			/* slide: every cost moves one lane up, c(p+2) enters at lane 0
-			 * (wave_ror:1; every lane has a source, 'old' is unused) */
-			const u32 r0 = __builtin_amdgcn_update_dpp(w0, w0, 0x13C, 0xF, 0xF, false);
-			w0 = lane0 ? c2 : r0;
-			c2 = c1;
-			c1 = best & ~511u;
-		}
-		{
-			s32 pj = ptop - (s32)lane;
-			if (lane < cnt && pj < hi)	/* pj >= lo: lane < cnt */
-				ch16[pj + 4] = (u16)ch;
-		}
-	}
-}
-
-/* ---------------- Huffman code construction (wave 0) ---------------- */
-
-/*
- * Length-limited canonical code for freq[0..n) -> lens[], codes[] (codewords
- * bit-reversed, ready for LSB-first output).  Called by ONE wave.
- *   - rank sort by (freq, sym): by the whole workgroup beforehand
- *     (presorted) or by this wave;
- *   - optimal tree by the in-place two-queue method on lane 0;
- *   - depth clamp with Kraft repair (what lib/deflate_compress.c:1022-1091
- *     achieves with its length-count shuffle);
- *   - fewer than two used symbols -> two 1-bit codewords
- *     (lib/deflate_compress.c:1369-1378).
- */
-/* W: the type of a weight.  A block of the small-buffer kernel has at most
- * 4097 tokens: its weights (and everything else these arrays hold: node
- * indices, depths) fit 16 bits, and the scratch of the litlen tree fits the
- * 4 KiB of the bit staging area, idle while the codes are built - M[] of a
- * tile of 1024 positions has no room for it */
-template <int N, typename W = u32> struct huff_scratch {
-	W A[N];	/* leaf weights, later hop pointers */
-	W NW[N];	/* internal node weights, later depths */
-	W P[N];	/* parent of each internal node */
-	u32 cntI[40];	/* internal nodes per depth */
-	u32 cnt[40];	/* leaves per depth (code lengths) */
-	u32 start[16];	/* first index in sorted[] for each length */
-	u32 nc[16];	/* next canonical codeword per length */
-	u16 S[2 * N];	/* merge rounds: the items of a round in merged order */
-};
-
-/* a block end builds its codes in M[]: keys and sorted symbols in the first
- * 2 KiB, the litlen tree's scratch behind them - or, where M[] is a tile of
- * 1024 positions (small-buffer kernel), in the bit staging area with 16-bit
- * entries (a build that kept it in M[] wrote over the histogram) */
-#ifdef LDA_SMALL
-typedef huff_scratch<288, u16> huff_litlen_t;
-#define HUFF_LITLEN(L) ((huff_litlen_t *)(L)->nxtA)
-static_assert(sizeof(((struct deflate_lds *)0)->nxtA) >= sizeof(huff_litlen_t) &&
-	      sizeof(((struct deflate_lds *)0)->M) >= 2048 && RING + 1 < 65536,
-	      "the staging area holds the litlen tree's scratch, M[] the keys");
-#else
-typedef huff_scratch<288, u32> huff_litlen_t;
-#define HUFF_LITLEN(L) ((huff_litlen_t *)((L)->M + 512))
-static_assert(sizeof(((struct deflate_lds *)0)->M) >= 2048 + sizeof(huff_litlen_t),
-	      "M[] holds the block-end scratch");
-#endif
-
-template <int N, typename W> static __device__ void
-make_code(const u32 *freq, u32 n, u32 maxlen, u8 *lens, u16 *codes,
-	  u16 *sorted, huff_scratch<N, W> *H, u32 used, bool presorted, u32 lane)
-{
-	PROF_DECL;
-	PROF_START();
-	/* a serial stretch (the merge is one lane): where other workgroups share
-	 * the CU (small-buffer kernel) it gets its SIMD's issue slots first */
-	__builtin_amdgcn_s_setprio(3);
-	for (u32 s = lane; s < n; s += 64)
-		lens[s] = 0;
-	if (!presorted) {
-		/* rank sort of the used symbols by (freq, sym), one wave */
-		used = 0;
-		for (u32 s0 = 0; s0 < n; s0 += 64) {
-			u32 s = s0 + lane;
-			u32 f = s < n ? freq[s] : 0;
-			used += __builtin_popcountll(__ballot(f != 0));
-		}
-		for (u32 s = lane; s < n; s += 64) {
-			u32 f = freq[s];
-			if (!f)
-				continue;
-			u32 key = (f << 9) | s, rank = 0;	/* freq < 2^22 */
-			for (u32 t = 0; t < n; t++) {
-				u32 ft = freq[t];
-				rank += (ft != 0) & (((ft << 9) | t) < key);
-			}
-			sorted[rank] = (u16)s;
-		}
-	}
-	wave_sync();
-	const u32 m = used;
-	if (m < 2) {
-		if (lane == 0) {
-			u32 s = m ? sorted[0] : 0;
-			u32 other = s ? 0 : 1;
-			lens[s] = 1;
-			lens[other] = 1;
-			for (u32 d = 0; d < 16; d++)
-				H->cnt[d] = 0;
-			H->cnt[1] = 2;
-		}
-		wave_sync();
-	} else {
-		for (u32 i = lane; i < m; i += 64)
-			H->A[i] = freq[sorted[i]];
-		if (lane < 40)
-			H->cntI[lane] = 0;
-		wave_sync();
-		if (N == 288) PROF_MARK(13);
-		/* The two-queue merge (leaves A[] ascending, nodes NW[] in creation
-		 * order, ascending too) in ROUNDS by the whole wave.  The next node
-		 * to be created weighs T = the sum of the two smallest items; every
-		 * node created from now on weighs at least T, and every node that
-		 * exists weighs at most T (the sums never decrease), so all items of
-		 * at most T - the leaves up to T and all queued nodes - are consumed
-		 * before any new node is, in merged order, two by two: that is one
-		 * round.  An odd item out waits for the next round (where it is one of
-		 * the two smallest).  The serial loop below does the same merges one
-		 * at a time: 375 cycles each on one lane, 45 K cycles for a block's
-		 * litlen tree; a round is ~250 wave instructions and a block takes
-		 * 9-15 of them.  Weights that grow like Fibonacci numbers give one
-		 * merge per round: after MERGE_ROUNDS rounds the serial loop takes
-		 * over from where the rounds are. */
-		u32 leaf = 0, node = 0, made = 0;	/* consumed leaves / nodes, created nodes */
-#ifndef MERGE_ROUNDS
-#define MERGE_ROUNDS 40u
-#endif
-		if (m >= 24) {
-			const u32 INF = 0x7FFFFFFFu;
-			for (u32 round = 0; round < MERGE_ROUNDS && made + 1 < m; round++) {
-				const u32 wl0 = leaf < m ? H->A[leaf] : INF;
-				const u32 wl1 = leaf + 1 < m ? H->A[leaf + 1] : INF;
-				const u32 wn0 = node < made ? H->NW[node] : INF;
-				const u32 wn1 = node + 1 < made ? H->NW[node + 1] : INF;
-				u32 T = wl0 + wl1;	/* (INF + INF does not wrap) */
-				T = wl0 + wn0 < T ? wl0 + wn0 : T;
-				T = wn0 + wn1 < T ? wn0 + wn1 : T;
-				/* leaves of at most T: a prefix of what is left */
-				u32 cl = 0;
-				for (u32 b0 = leaf; b0 < m; b0 += 64) {
-					const u32 i = b0 + lane;
-					const u32 c = (u32)__builtin_popcountll(__ballot(i < m && H->A[i] <= T));
-					cl += c;
-					if (c < 64)
-						break;
-				}
-				u32 cn = made - node;
-				if ((cl + cn) & 1) {
-					/* the last item of the merged order stays (a node
-					 * follows a leaf of the same weight) */
-					if (cn && (cl == 0 || H->NW[node + cn - 1] >= H->A[leaf + cl - 1]))
-						cn--;
-					else
-						cl--;
-				}
-				const u32 tot = cl + cn;
-				for (u32 k = lane; k < tot; k += 64)
-					H->S[k] = 0xFFFF;
-				wave_sync();
-				/* a leaf's place: its index + the nodes that weigh less (the
-				 * first 64 queued nodes sit in a register, one per lane, and
-				 * are read lane by lane: no LDS round trip per node) */
-				const u32 wnode = lane < cn ? H->NW[node + lane] : 0;
-				const u32 cn64 = cn < 64 ? cn : 64;
-				for (u32 i0 = 0; i0 < cl; i0 += 64) {
-					const u32 i = i0 + lane;
-					const u32 wv = i < cl ? H->A[leaf + i] : 0;
-					u32 r = i;
-					for (u32 j = 0; j < cn64; j++)
-						r += bcast_lane(wnode, j) < wv;
-					for (u32 j = 64; j < cn; j++)
-						r += H->NW[node + j] < wv;
-					if (i < cl)
-						H->S[r] = (u16)i;
-				}
-				wave_sync();
-				/* the nodes take the places left, in order */
-				u32 nfree = 0;
-				for (u32 k0 = 0; k0 < tot; k0 += 64) {
-					const u32 k = k0 + lane;
-					const bool fr = k < tot && H->S[k] == 0xFFFF;
-					const u64 mk = __ballot(fr);
-					if (fr)
-						H->S[k] = (u16)(0x8000u | (nfree + rank_below(mk)));
-					nfree += (u32)__builtin_popcountll(mk);
-				}
-				wave_sync();
-				for (u32 q = lane; q < tot / 2; q += 64) {
-					const u32 a = H->S[2 * q], b = H->S[2 * q + 1];
-					const u32 wa = a & 0x8000 ? H->NW[node + (a & 0x7FFF)] : H->A[leaf + a];
-					const u32 wb = b & 0x8000 ? H->NW[node + (b & 0x7FFF)] : H->A[leaf + b];
-					if (a & 0x8000)
-						H->P[node + (a & 0x7FFF)] = made + q;
-					if (b & 0x8000)
-						H->P[node + (b & 0x7FFF)] = made + q;
-					H->NW[made + q] = wa + wb;
-				}
-				wave_sync();
-				leaf += cl;
-				node += cn;
-				made += tot / 2;
-			}
-		}
-		if (lane == 0 && made + 1 < m) {
-			/* one merge at a time; heads cached in registers (a variant that
-			 * also prefetched the following entries had more instructions on
-			 * this single-lane path and was slower) */
-			u32 wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
-			u32 wn = node < made ? H->NW[node] : 0xFFFFFFFFu;
-			for (u32 k = made; k + 1 < m; k++) {
-				u32 w;
-				if (leaf < m && wl <= wn) {
-					w = wl;
-					leaf++;
-					wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
-				} else {
-					w = wn;
-					H->P[node] = k;
-					node++;
-					wn = node < k ? H->NW[node] : 0xFFFFFFFFu;
-				}
-				if (leaf < m && wl <= wn) {
-					w += wl;
-					leaf++;
-					wl = leaf < m ? H->A[leaf] : 0xFFFFFFFFu;
-				} else {
-					w += wn;
-					H->P[node] = k;
-					node++;
-					wn = node < k ? H->NW[node] : 0xFFFFFFFFu;
-				}
-				H->NW[k] = w;
-				if (node == k)
-					wn = w;	/* the new node is the only one queued */
-			}
-		}
-		wave_sync();
-		if (N == 288) PROF_MARK(14);
-		/* depth of every internal node by pointer jumping (root = m-2) */
-		{
-			const u32 root = m - 2;
-			enum { NJ = (N + 63) / 64 };	/* internal nodes per lane */
-			u32 dd[NJ], hh[NJ];
-#pragma unroll
-			for (u32 j = 0; j < NJ; j++) {
-				u32 k = lane + 64 * j;
-				dd[j] = (k < root) ? 1 : 0;
-				hh[j] = (k < root) ? H->P[k] : root;
-			}
-			wave_sync();
-#pragma unroll
-			for (u32 j = 0; j < NJ; j++) {
-				u32 k = lane + 64 * j;
-				if (k <= root) {
-					H->NW[k] = dd[j];
-					H->A[k] = hh[j];
-				}
-			}
-			wave_sync();
-			for (u32 r = 0; r < 6; r++) {	/* depth < 64 */
-#pragma unroll
-				for (u32 j = 0; j < NJ; j++) {
-					u32 k = lane + 64 * j;
-					if (k <= root) {
-						u32 h = H->A[k];
-						dd[j] = H->NW[k] + H->NW[h];
-						hh[j] = H->A[h];
-					}
-				}
-				wave_sync();
-#pragma unroll
-				for (u32 j = 0; j < NJ; j++) {
-					u32 k = lane + 64 * j;
-					if (k <= root) {
-						H->NW[k] = dd[j];
-						H->A[k] = hh[j];
-					}
-				}
-				wave_sync();
-			}
-#pragma unroll
-			for (u32 j = 0; j < NJ; j++) {
-				u32 k = lane + 64 * j;
-				if (k <= root)
-					atomicAdd((u32 *)&H->cntI[dd[j] < 39 ? dd[j] : 39], 1u);
-			}
-			wave_sync();
-			/* leaves at depth d = 2 * internal(d-1) - internal(d) */
-			if (lane < 40)
-				H->cnt[lane] = lane ? 2 * H->cntI[lane - 1] - H->cntI[lane] : 0;
-			wave_sync();
-		}
-		if (N == 288) PROF_MARK(15);
-		if (lane == 0) {
-			/* clamp to maxlen, repair Kraft sum (zlib-style) */
-			u32 over = 0;
-			for (u32 d = maxlen + 1; d < 40; d++) {
-				over += H->cnt[d];
-				H->cnt[maxlen] += H->cnt[d];
-				H->cnt[d] = 0;
-			}
-			if (over) {
-				u32 kraft = 0;
-				for (u32 d = 1; d <= maxlen; d++)
-					kraft += H->cnt[d] << (maxlen - d);
-				while (kraft > (1u << maxlen)) {
-					u32 d = maxlen - 1;
-					while (H->cnt[d] == 0)
-						d--;
-					H->cnt[d]--;
-					H->cnt[d + 1] += 2;
-					H->cnt[maxlen]--;
-					kraft -= 1;
-				}
-			}
-			/* rarest symbols get the longest codewords */
-			u32 at = 0;
-			for (u32 d = maxlen; d >= 1; d--) {
-				H->start[d] = at;
-				at += H->cnt[d];
-			}
-		}
-		wave_sync();
-		for (u32 i = lane; i < m; i += 64) {
-			u32 d = 1;
-			for (u32 q = 2; q <= maxlen; q++)
-				if (H->cnt[q] && i >= H->start[q] &&
-				    i < H->start[q] + H->cnt[q])
-					d = q;
-			lens[sorted[i]] = (u8)d;
-		}
-		wave_sync();
-	}
-	if (N == 288) PROF_MARK(17);
-	/* canonical codewords, bit-reversed: codes of one length go to the
-	 * symbols in increasing symbol order -> ballot ranks */
-	if (lane == 0) {
-		u32 code = 0;
-		H->nc[0] = 0;
-		for (u32 d = 1; d < 16; d++) {
-			code = (code + (d > 1 ? H->cnt[d - 1] : 0)) << 1;
-			H->nc[d] = code;
-		}
-	}
-	wave_sync();
-	{
-		u32 run[16];
-#pragma unroll
-		for (u32 d = 1; d < 16; d++)
-			run[d] = H->nc[d];
-		for (u32 s0 = 0; s0 < n; s0 += 64) {
-			u32 s = s0 + lane;
-			u32 l = s < n ? lens[s] : 0;
-			u32 mycode = 0;
-#pragma unroll
-			for (u32 d = 1; d < 16; d++) {
-				u64 mm = __ballot(l == d);
-				if (l == d)
-					mycode = run[d] + __builtin_popcountll(mm & ((1ull << lane) - 1));
-				run[d] += __builtin_popcountll(mm);
-			}
-			if (s < n)
-				codes[s] = l ? (u16)(__brev(mycode) >> (32 - l)) : 0;
-		}
-	}
-	wave_sync();
-	__builtin_amdgcn_s_setprio(0);
-}
+#include "deflate_opt.h"
+#include "deflate_huffman.h"
 
 /* ---------------- bit output through the LDS staging area ---------------- */
 
@@ -1511,146 +739,6 @@ static __device__ __forceinline__ void lds_add_lane0(u32 lds_byteaddr, u32 v)
 
 /* ---------------- match measurement ---------------- */
 
-/*
- * Length of the match of position p against cp (both absolute), for the
- * lanes with ev set; every lane of the wave must call it (matches longer
- * than 28 bytes are measured by the whole wave, 256 bytes per pass).  cur =
- * bytes p..p+3, nxt8 = bytes p+4..p+11.  0 when the first four bytes differ.
- */
-#if RA_PREF
-static __device__ __forceinline__ u32
-match_length_p(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
-	       u32 maxlen, u32 lane);
-#endif
-static __device__ __forceinline__ u32
-match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
-	     u32 maxlen, u32 lane)
-{
-#if RA_PREF
-	return match_length_p(L, ev, p, cp, cur, nxt8, maxlen, lane);
-#endif
-	u64 x = nxt8 ^ ld64(L->in, cp + 4);
-	u32 len = 4 + ((u32)__builtin_ctzll(x | (1ull << 63)) >> 3);
-	ev = ev && ld32(L->in, cp) == cur;
-	bool more = ev && x == 0 && 12 < maxlen;
-	/* bytes 12..27 lane by lane; only longer matches go to the wave */
-	if (__ballot(more)) {
-		u64 y = ld64(L->in, p + 12) ^ ld64(L->in, cp + 12);
-		if (more) {
-			len = 12 + ((u32)__builtin_ctzll(y | (1ull << 63)) >> 3);
-			more = y == 0 && 20 < maxlen;
-		}
-		if (__ballot(more)) {
-			u64 z = ld64(L->in, p + 20) ^ ld64(L->in, cp + 20);
-			if (more) {
-				len = 20 + ((u32)__builtin_ctzll(z | (1ull << 63)) >> 3);
-				more = z == 0 && 28 < maxlen;
-			}
-		}
-	}
-	for (u64 mm = __ballot(more); mm; mm &= mm - 1) {
-		u32 src = (u32)__builtin_ctzll(mm);
-		u32 bp = bcast_lane(p, src);
-		u32 bc = bcast_lane(cp, src);
-		u32 bmax = bcast_lane(maxlen, src);
-		u32 off = 28 + 4 * lane;
-		u32 x4 = off < bmax ?
-			(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
-		u64 ne = __ballot(x4 != 0);
-		u32 tot = bmax;	/* 28 + 256 >= 258 */
-		if (ne) {
-			u32 kk = (u32)__builtin_ctzll(ne);
-			u32 xk = bcast_lane(x4, kk);
-			u32 o = 28 + 4 * kk;
-			if (o < bmax)
-				tot = o + ((u32)__builtin_ctz(xk) >> 3);
-		}
-		if (lane == src)
-			len = tot;
-	}
-	if (len > maxlen)
-		len = maxlen;
-	return ev ? len : 0;
-}
-
-/*
- * The same for TWO candidates of one position, the loads of each stage issued
- * together: half the LDS round trips of two calls (the shallow search measures
- * the two nearest chain members of every position, and a wave's time there is
- * the sum of its dependent LDS waits).  Same results as two match_length().
- */
-static __device__ __forceinline__ void
-match_length2(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 cur,
-	      u64 nxt8, u32 maxlen, u32 lane, u32 *len1o, u32 *len2o)
-{
-	const u32 a1 = ld32(L->in, cp1), a2 = ld32(L->in, cp2);
-	const u64 x1 = nxt8 ^ ld64(L->in, cp1 + 4), x2 = nxt8 ^ ld64(L->in, cp2 + 4);
-	u32 len1 = 4 + ((u32)__builtin_ctzll(x1 | (1ull << 63)) >> 3);
-	u32 len2 = 4 + ((u32)__builtin_ctzll(x2 | (1ull << 63)) >> 3);
-	ev1 = ev1 && a1 == cur;
-	ev2 = ev2 && a2 == cur;
-	bool m1 = ev1 && x1 == 0 && 12 < maxlen, m2 = ev2 && x2 == 0 && 12 < maxlen;
-	if (__ballot(m1 || m2)) {
-		const u64 pw = ld64(L->in, p + 12);
-		const u64 y1 = pw ^ ld64(L->in, cp1 + 12), y2 = pw ^ ld64(L->in, cp2 + 12);
-		if (m1) {
-			len1 = 12 + ((u32)__builtin_ctzll(y1 | (1ull << 63)) >> 3);
-			m1 = y1 == 0 && 20 < maxlen;
-		}
-		if (m2) {
-			len2 = 12 + ((u32)__builtin_ctzll(y2 | (1ull << 63)) >> 3);
-			m2 = y2 == 0 && 20 < maxlen;
-		}
-		if (__ballot(m1 || m2)) {
-			const u64 pz = ld64(L->in, p + 20);
-			const u64 z1 = pz ^ ld64(L->in, cp1 + 20), z2 = pz ^ ld64(L->in, cp2 + 20);
-			if (m1) {
-				len1 = 20 + ((u32)__builtin_ctzll(z1 | (1ull << 63)) >> 3);
-				m1 = z1 == 0 && 28 < maxlen;
-			}
-			if (m2) {
-				len2 = 20 + ((u32)__builtin_ctzll(z2 | (1ull << 63)) >> 3);
-				m2 = z2 == 0 && 28 < maxlen;
-			}
-		}
-	}
-#pragma unroll
-	for (u32 c = 0; c < 2; c++) {
-		const u32 cp = c ? cp2 : cp1;
-		for (u64 mm = __ballot(c ? m2 : m1); mm; mm &= mm - 1) {
-			u32 src = (u32)__builtin_ctzll(mm);
-			u32 bp = bcast_lane(p, src);
-			u32 bc = bcast_lane(cp, src);
-			u32 bmax = bcast_lane(maxlen, src);
-			u32 off = 28 + 4 * lane;
-			u32 x4 = off < bmax ?
-				(ld32(L->in, bp + off) ^ ld32(L->in, bc + off)) : 1;
-			u64 ne = __ballot(x4 != 0);
-			u32 tot = bmax;	/* 28 + 256 >= 258 */
-			if (ne) {
-				u32 kk = (u32)__builtin_ctzll(ne);
-				u32 xk = bcast_lane(x4, kk);
-				u32 o = 28 + 4 * kk;
-				if (o < bmax)
-					tot = o + ((u32)__builtin_ctz(xk) >> 3);
-			}
-			if (lane == src) {
-				if (c)
-					len2 = tot;
-				else
-					len1 = tot;
-			}
-		}
-	}
-	if (len1 > maxlen)
-		len1 = maxlen;
-	if (len2 > maxlen)
-		len2 = maxlen;
-	*len1o = ev1 ? len1 : 0;
-	*len2o = ev2 ? len2 : 0;
-}
-
-#if RA_PREF
 /* raw aligned words of the ring (see ld32()): `i` is a multiple of 4 below RING,
  * `k` <= 28 bytes further lies inside the ring or its 32-byte mirror */
 #define RAW(i, k) LDS32((i) + (k))
@@ -1665,11 +753,15 @@ static __device__ __forceinline__ u64 mk64(u32 lo, u32 hi)
 }
 
 /*
- * match_length() with every stage's raw words requested before any of them is
- * used (one LDS round trip per stage instead of up to two): same result.
+ * Length of the match of position p against cp (both absolute), for the
+ * lanes with ev set; every lane of the wave must call it (matches longer
+ * than 28 bytes are measured by the whole wave, 256 bytes per pass).  cur =
+ * bytes p..p+3, nxt8 = bytes p+4..p+11.  0 when the first four bytes differ.
+ * Every stage's raw words are requested before any of them is used: one LDS
+ * round trip per stage.
  */
 static __device__ __forceinline__ u32
-match_length_p(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
+match_length(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 	       u32 maxlen, u32 lane)
 {
 	(void)L;
@@ -1732,9 +824,12 @@ match_length_p(const lds_t *L, bool ev, u32 p, u32 cp, u32 cur, u64 nxt8,
 }
 
 /*
- * match_length2() the same way; `hook` runs between the request of the first
- * stage's words and their use (round A requests the next group's first loads
- * there).  Same results as match_length2().
+ * The same for TWO candidates of one position, the loads of each stage issued
+ * together: half the LDS round trips of two calls (the shallow search measures
+ * the two nearest chain members of every position, and a wave's time there is
+ * the sum of its dependent LDS waits).  `hook` runs between the request of the
+ * first stage's words and their use (round A requests the next group's first
+ * loads there).  Same results as two match_length().
  */
 template <class F> static __device__ __forceinline__ void
 match_length2_p(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32 cur,
@@ -1830,7 +925,6 @@ match_length2_p(const lds_t *L, bool ev1, bool ev2, u32 p, u32 cp1, u32 cp2, u32
 	*len1o = ev1 ? len1 : 0;
 	*len2o = ev2 ? len2 : 0;
 }
-#endif /* RA_PREF */
 
 /*
  * Minimum match length from the distinct bytes of a tile's input
@@ -1907,7 +1001,6 @@ stage_input(lds_t *L, const u8 *__restrict__ inp, u32 loaded, u32 want,
  * 3.9 chain steps per position instead of 15.0 at level 6 on text, output
  * 0.03 % smaller than the serial parse after two rounds.
  */
-#if RA_PREF
 /*
  * round_a() for the usual case (the two nearest chain members of every
  * position) with the LDS round trips off the dependent chain, see RA_PREF.
@@ -1976,15 +1069,6 @@ ra_group(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32
 	u32 rn = 0, gn = 0;
 	if (PRE)
 		rn = claim_issue(ctr);
-#if RA_PREF >= 3
-	/* the length-3 probes' words: the eight bytes before p, and the
-	 * 3-byte-table candidate's (find_len3()) */
-	const u32 i8 = ((p - 8) & RMASK) & ~3u;
-	const u32 q0 = RAW(i8, 0), q1 = RAW(i8, 4);
-	const u32 d3 = (p - c3v) & 0xFFFF;
-	const u32 o3 = (p - d3) & RMASK, i3 = o3 & ~3u;
-	const u32 r0 = RAW(i3, 0), r1 = RAW(i3, 4);
-#endif
 	const u32 d2 = (p - c2) & 0xFFFF;
 	const bool ch2 = act1 && d2 > d1 && d2 <= dmaxp;
 	const u32 cp2 = p - d2;
@@ -2008,35 +1092,8 @@ ra_group(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32
 	}
 	u32 m = best >= 4 && best >= min_len ? best | (bestd << 16) : 0;
 	if (m == 0 && want3 && p < tend && p + 3 <= n) {
-#if RA_PREF >= 3
-		/* find_len3() on the words requested above */
-		const u32 dmax3 = dmaxp > dlim3 ? dlim3 : dmaxp;
-		u32 bd = 0;
-		if (p >= 8) {
-			const u32 A = AB(q1, q0, sp), B = AB(f.a0, q1, sp);
-			u32 mk = 0;
-#define LEN3_TRY(d, x) mk |= ((((x) ^ cur) & 0xFFFFFFu) == 0) << ((d) - 1)
-			LEN3_TRY(8, A);
-			LEN3_TRY(7, AB(B, A, 1));
-			LEN3_TRY(6, AB(B, A, 2));
-			LEN3_TRY(5, AB(B, A, 3));
-			LEN3_TRY(4, B);
-			LEN3_TRY(3, AB(cur, B, 1));
-			LEN3_TRY(2, AB(cur, B, 2));
-			LEN3_TRY(1, AB(cur, B, 3));
-#undef LEN3_TRY
-			if (dmax3 < 8)
-				mk &= (1u << dmax3) - 1;
-			if (mk)
-				bd = (u32)__builtin_ctz(mk) + 1;
-		}
-		if (!bd && d3 && d3 <= dmax3 &&
-		    ((AB(r1, r0, o3 & 3) ^ cur) & 0xFFFFFFu) == 0)
-			bd = d3;
-#else
 		u32 b3 = 0;
 		u32 bd = find_len3(L, p, cur, c3v, dmaxp, dlim3, &b3);
-#endif
 		if (bd)
 			m = 3 | (bd << 16);
 	}
@@ -2070,7 +1127,6 @@ round_a_p(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u3
 
 	if (g < TILE / 64)
 		f = ra_first_loads(c3, t, g, lane, min_len <= 3);
-#if RA_PREF >= 2
 	/* two groups per round, the two sets of first loads changing roles: a
 	 * copy at the end of the body would have to wait for the loads */
 	struct ra_first f2 = { 0, 0, 0, 0, 0, 0 };
@@ -2085,13 +1141,11 @@ round_a_p(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u3
 		ra_group<true>(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
 			       tag, lane, g, f2, f);
 	}
-#endif
 #pragma unroll 1
 	while (g < TILE / 64)
 		ra_group<false>(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
 				tag, lane, g, f, f);
 }
-#endif /* RA_PREF */
 
 static __device__ __forceinline__ void
 round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 n,
@@ -2099,13 +1153,11 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 	u32 tag, u32 tid)
 {
 	const u32 lane = tid & 63;
-#if RA_PREF
 	if (ra_depth == 2 && RA_PAIR) {
 		round_a_p(L, Mo, c3, t, tend, n, lo_pos, min_len, done_class, nice, dlim3,
 			  tag, tid);
 		return;
 	}
-#endif
 
 	/* groups of 64 positions are taken from a counter: the two waves that
 	 * insert the next tile meanwhile join in when they are done */
@@ -2129,34 +1181,6 @@ round_a(lds_t *L, AS3 u32 *Mo, const u16 *__restrict__ c3, u32 t, u32 tend, u32 
 		u32 c16 = LDS16(PREV_OFF + 2 * (p & RMASK));
 		u32 best = 3, bestd = 0, dprev = 0;
 
-		if (ra_depth == 2 && RA_PAIR) {
-			/* the usual case: both chain links first, then both candidates
-			 * measured side by side (match_length2()); the same results as
-			 * two rounds of the loop below */
-			const u32 d1 = (p - c16) & 0xFFFF;
-			const bool act1 = act && d1 > 0 && d1 <= dmaxp && 3 < nic;
-			const u32 cp1 = p - d1;
-			const u32 c2 = LDS16(PREV_OFF + 2 * (cp1 & RMASK));
-			const u32 d2 = (p - c2) & 0xFFFF;
-			const bool ch2 = act1 && d2 > d1 && d2 <= dmaxp;
-			const u32 cp2 = p - d2;
-			const u32 c3n = LDS16(PREV_OFF + 2 * (cp2 & RMASK));
-			u32 len1, len2;
-			match_length2(L, act1, ch2, p, cp1, cp2, cur, nxt8, maxlen, lane,
-				      &len1, &len2);
-			if (len1 > best) {
-				best = len1;
-				bestd = d1;
-			}
-			const bool act2 = ch2 && best < nic;
-			if (act2 && len2 > best) {
-				best = len2;
-				bestd = d2;
-			}
-			act = act2;
-			c16 = c3n;
-			dprev = d2;
-		} else
 		for (u32 s = 0; s < ra_depth; s++) {
 			u32 d = (p - c16) & 0xFFFF;
 			act = act && d > dprev && d <= dmaxp && best < nic;
@@ -2320,7 +1344,6 @@ parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u6
 	u64 mask = 0, nm = 0;
 	bool walking = q < hi;
 
-#if PARSE_OPT
 	/* ---- the first pass (every lane from its guess, nothing to meet) ----
 	 * A stretch of the path: lands at `rel`, a run of literals, then the
 	 * token at r2 = rel + run (or the segment ends inside the run: the
@@ -2361,7 +1384,6 @@ parse_tile(const AS3 u32 *Ms, const AS3 u64 *lit1p, const AS3 u64 *lit2p, AS3 u6
 		}
 		walking = false;
 	}
-#endif
 	/* (after the first pass above no lane is walking: the loop goes straight
 	 * to the exchange) */
 	for (;;) {
@@ -2533,30 +1555,31 @@ emit_groups(lds_t *L, u32 *__restrict__ tokg, u32 t, u32 lane)
 			continue;
 		const u64 two = pmk & L->lit2[g];
 		if ((pmk >> lane) & 1) {
+			/* One path for both kinds of token (as two branches the wave ran
+			 * both, one after the other, with the mask juggling in between):
+			 * the first list entry and histogram symbol are the match's
+			 * (entry, length slot from the table) or the literal's, the
+			 * second symbol is the match's offset slot or the second literal
+			 * of a "two literals" step; both literal bytes are read whatever
+			 * the token is (the ring is mirrored past its end). */
 			const u32 q = 64 * g + lane, idx = q + 4;
 			const u32 m0 = L->M[idx];
-			const u32 l0 = m0 & 0xFFFF;
+			const u32 l0 = m0 & 0xFFFF, dist = m0 >> 16;
 			const u32 st = (L->lit1[g] >> lane) & 1 ? 1 : (two >> lane) & 1 ? 2 : l0;
-			const u32 pos = t + q;
+			const u32 o = (t + q) & RMASK;
+			const u32 b0 = L->in[o], b1 = L->in[o + 1];
+			const u32 lsl = L->lslot[(l0 - 3) & 255];
 			const u32 at = L->gbase[g] + (u32)__builtin_popcountll(pmk & lt) +
 				       (u32)__builtin_popcountll(two & lt);
-			if (st == l0 && l0) {
-				u32 sl, xb, xv;
-				tokg[at] = TOK_MATCH | (l0 - 3) | (((m0 >> 16) - 1) << 8);
-				length_code(l0, &sl, &xb, &xv);
-				atomicAdd((u32 *)&L->freq[257 + sl], 1u);
-				dist_code(m0 >> 16, &sl, &xb, &xv);
-				atomicAdd((u32 *)&L->freq[288 + sl], 1u);
-			} else {
-				const u32 b0 = L->in[pos & RMASK];
-				tokg[at] = b0;
-				atomicAdd((u32 *)&L->freq[b0], 1u);
-				if (st == 2) {
-					const u32 b1 = L->in[(pos + 1) & RMASK];
-					tokg[at + 1] = b1;
-					atomicAdd((u32 *)&L->freq[b1], 1u);
-				}
-			}
+			const bool ism = st == l0 && l0;
+			u32 dsl, xb, xv;
+			dist_code(dist, &dsl, &xb, &xv);
+			tokg[at] = ism ? TOK_MATCH | (l0 - 3) | ((dist - 1) << 8) : b0;
+			atomicAdd((u32 *)&L->freq[ism ? 257 + lsl : b0], 1u);
+			if (ism || st == 2)
+				atomicAdd((u32 *)&L->freq[ism ? 288 + dsl : b1], 1u);
+			if (!ism && st == 2)
+				tokg[at + 1] = b1;
 		}
 	}
 	/* the token list is read back by other waves at the end of the block */
@@ -2851,19 +1874,17 @@ static __device__ __forceinline__ u32 rb_trim_depth(u32 depth)
 {
 	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;	/* walk passes per generation */
 	const u32 quantum = 8 * npass;
-#if GEN_TRIM
 	/* a depth a few steps past the end of a generation (level 6: 35 = 16 +
 	 * 16 + 3, level 7: 100 = 16 + 32 + 48 + 4) would cost a whole round of
 	 * batches - or a third pass for every batch of the last generation - for
 	 * those few steps: up to an eighth of the depth is given up instead */
-	for (u32 g = 1, end = quantum; end < depth; g++, end += quantum * (GEN_GROW ? g : 1))
+	for (u32 g = 1, end = quantum; end < depth; g++, end += quantum * g)
 		if (depth - end <= depth / 8)
 			depth = end;
 	/* and the same for a pass of 8 steps (level 6: 35 -> 32, two passes in
 	 * the second generation instead of three) */
 	if (depth >= 16 && (depth & 7) <= depth / 8)
 		depth &= ~7u;
-#endif
 	return depth;
 }
 
@@ -2874,9 +1895,9 @@ rb_gen_params(u32 depth, u32 gen, u32 *before, u32 *npass_g)
 	const u32 npass = depth >= 256 ? 4 : depth >= 32 ? 2 : 1;
 	const u32 quantum = 8 * npass;
 	/* the survivors of a generation are the deep chains: later
-	 * generations walk longer before they repack (GEN_GROW) */
-	*npass_g = GEN_GROW ? npass * (gen + 1) : npass;
-	*before = GEN_GROW ? quantum * (gen * (gen + 1) / 2) : quantum * gen;
+	 * generations walk longer before they repack */
+	*npass_g = npass * (gen + 1);
+	*before = quantum * (gen * (gen + 1) / 2);
 }
 
 /*
@@ -2896,32 +1917,21 @@ rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
 	const u32 cdepth = ((e >> 12) & 3) == DC_FULL ? depth : half;
 	u32 dep = before < cdepth ? cdepth - before : 0;
 	dep = dep < qg ? dep : qg;
-#if RA_PREF
 	/* (the chain link and the match the position has are requested first:
 	 * they head the dependent loads) */
 	u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
 	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
 	const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
-#endif
 	const u32 cur = ld32(L->in, p);
 	const u64 nxt8 = ld64(L->in, p + 4);
 	const u32 maxlen = n - p < 258 ? n - p : 258;
 	const u32 dmaxp = p - lo_pos;
 	const u32 nic = nice < maxlen ? nice : maxlen;
-#if !RA_PREF
-	const u32 m = L->M[4 + i], l0 = m & 0xFFFF;
-#endif
 	u32 best = l0 >= 4 ? l0 : 3, bestd = l0 >= 4 ? m >> 16 : 0;
 	const u32 best0 = best;
 	u32 boff = best - 3;
 	u32 curb = ld32(L->in, p + boff);
-#if !RA_PREF
-	u32 dprev = gen ? (p - (e >> 16)) & 0xFFFF : 0;
-	u32 c16 = LDS16(PREV_OFF + 2 * ((p - dprev) & RMASK));
-#endif
 	bool act = have && p + 4 <= n && best < nic && dep;
-#if RB_OPT
-	static_assert(RB_HITS == 2, "RB_OPT keeps the queued hits of a pass as two masks");
 	u64 endm = 0;	/* lanes whose chain has ended (wave-uniform mask) */
 	for (u32 ps = 0; ps < npass_g; ps++) {
 		u64 h1 = 0, h2 = 0;	/* lanes with >= 1 / 2 queued hits */
@@ -2993,62 +2003,6 @@ rb_batch(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth, u32 nice,
 		}
 	}
 	const bool ended = lane_bit(endm);
-#else
-	bool ended = false;
-	for (u32 ps = 0; ps < npass_g; ps++) {
-		u32 cnt = 0;
-#if RB_HITS <= 2
-		u32 qh = 0;
-#else
-		u64 qh = 0;
-#endif
-#pragma unroll
-		for (int s = 0; s < 8; s++) {
-			u32 d = (p - c16) & 0xFFFF;
-			bool chain = dep && d > dprev && d <= dmaxp;
-			bool stall = ended || cnt >= RB_HITS;
-			bool ok = act && !stall && chain;
-			u32 cp = p - d;
-			u32 w = ld32(L->in, cp + boff);
-			u32 c16n = LDS16(PREV_OFF + 2 * (cp & RMASK));
-			bool hit = ok && w == curb;
-			c16 = ok ? c16n : c16;
-			dprev = ok ? d : dprev;
-			dep -= ok ? 1 : 0;
-			ended = ended || (act && !stall && !chain);
-			qh = hit ? ((qh << 16) | d) : qh;
-			cnt += hit ? 1 : 0;
-			PROF_COUNT(20, __builtin_popcountll(__ballot(ok)));
-			PROF_COUNT(17, __builtin_popcountll(__ballot(hit)));
-		}
-		PROF_COUNT(13, __builtin_popcountll(__ballot(have)));
-		/* evaluate: every lane pops its oldest (closest) hit.  (Dealing
-		 * the wave's hits out to all lanes through LDS - they are a
-		 * third of a hit per lane - measured slower: the five
-		 * cross-lane fetches per round cost more than the rounds
-		 * saved.) */
-		while (__ballot(cnt > 0)) {
-			PROF_COUNT(21, 1);
-			const bool ev = cnt > 0;
-			const u32 d = (u32)(qh >> (16 * ((cnt - 1) & (RB_HITS - 1)))) & 0xFFFF;
-			cnt -= ev ? 1 : 0;
-			const u32 len = match_length(L, ev, p, p - d, cur, nxt8,
-						     maxlen, lane);
-			if (ev && len > best) {
-				best = len;
-				bestd = d;
-			}
-		}
-		if (best >= nic)
-			act = false;
-		if (npass_g > 1) {
-			if (!__ballot(act && !ended && dep))
-				break;
-			boff = best - 3;
-			curb = ld32(L->in, p + boff);
-		}
-	}
-#endif
 	if (best > best0)
 		L->M[4 + i] = best >= min_len ? best | (bestd << 16) : 0;
 	*next = (e & 0x3FFF) | (((p - dprev) & 0xFFFF) << 16);
@@ -3130,7 +2084,6 @@ search_queue(lds_t *L, u32 t, u32 n, u32 lo_pos, u32 min_len, u32 depth,
 static __device__ __forceinline__ void
 split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
 {
-#if SPLIT_VEC
 	/* The wave that computes this is the last thing of phase X (every token
 	 * of the tile has to be out first) with fifteen waves at the barrier: its
 	 * instruction count is on the tile's path.  Class sums: the 320 counts
@@ -3166,55 +2119,6 @@ split_stats(lds_t *L, u32 walkpos, u32 block_start, bool fit_split, u32 lane)
 	if (lane == 0)
 		L->vars[V_SPLIT] = !sp ? 0 :
 			L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
-#else
-	/* class of literal sy = lane + 64 j is 2 j + (lane & 1);
-	 * matches: length slots 0..5 (3..8) / 6..28 */
-	u32 onow[10], oprev[10];
-#pragma unroll
-	for (u32 j = 0; j < 4; j++) {
-		u32 f = L->freq[lane + 64 * j];
-		onow[2 * j] = wave_sum(lane & 1 ? 0 : f);
-		onow[2 * j + 1] = wave_sum(lane & 1 ? f : 0);
-	}
-	{
-		u32 f = lane < 29 ? L->freq[257 + lane] : 0;
-		onow[8] = wave_sum(lane < 6 ? f : 0);
-		onow[9] = wave_sum(lane < 6 ? 0 : f);
-	}
-	u32 nprev = 0, nnew = 0;
-	u64 delta = 0;
-	/* (one LDS round trip for the ten words, then lane reads: wave-uniform
-	 * values, scalar arithmetic) */
-	const u32 ov = lane < 10 ? L->obs[0][lane] : 0;
-#pragma unroll
-	for (u32 i = 0; i < 10; i++) {
-		oprev[i] = (u32)__builtin_amdgcn_readlane((int)ov, i);
-		nprev += oprev[i];
-		nnew += onow[i] - oprev[i];
-	}
-#pragma unroll
-	for (u32 i = 0; i < 10; i++) {
-		u64 a = (u64)(onow[i] - oprev[i]) * nprev;
-		u64 e = (u64)oprev[i] * nnew;
-		delta += a > e ? a - e : e - a;
-	}
-	/* cutoff 200/512 of the mass as :2179-2193; blocks below
-	 * the minimum length of :2204 are never cut */
-	bool sp = nprev && walkpos - block_start >= 5000 &&
-		  delta >= (u64)nnew * 200 / 512 * nprev;
-	if (fit_split && walkpos - block_start >= 5000)
-		sp = true;	/* see opt_build_costs() */
-	wave_sync();
-#pragma unroll
-	for (u32 i = 0; i < 10; i++)
-		if (lane == i)
-			L->obs[0][i] = sp ? 0 : onow[i];
-	/* 2: the part before this tile is a block of its own
-	 * (>= the minimum block length of :2204) */
-	if (lane == 0)
-		L->vars[V_SPLIT] = !sp ? 0 :
-			L->vars[V_WPOS_PRE] - block_start >= 5000 ? 2 : 1;
-#endif
 }
 
 #ifdef LDA_DEBUG_SPLIT	/* per-tile trace of the block-split inputs of buffer 0 (debug builds) */
@@ -3273,6 +2177,11 @@ deflate_batch_body(u8 *lds_raw, u64 n_chunks, int format, int level, u32 depth,
 	u32 tog = 0;		/* which scan[] array the next single-barrier scan uses */
 	PROF_DECL;
 
+	for (u32 i = tid; i < 256; i += NT) {
+		u32 sl, xb, xv;
+		length_code(i + 3, &sl, &xb, &xv);
+		L->lslot[i] = (u8)sl;
+	}
 	/* Buffers are handed out dynamically (one global counter): their cost
 	 * depends on their content, and a fixed stride gives every workgroup
 	 * the same kind of buffer whenever the batch is periodic. */

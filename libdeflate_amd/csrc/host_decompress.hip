@@ -67,6 +67,31 @@ bool pick_allocator(const struct libdeflate_options *options,
 
 using namespace lda;
 
+/* device bytes behind d->tokens for a batch of n streams: the token rows of
+ * every wave of the grid, 16 bytes of counters */
+/* waves (= streams in flight) per CU: what the kernel's LDS leaves room for, at
+ * most LDA_INFLATE_WAVES_PER_CU (16: four per SIMD at 128 VGPRs) */
+static size_t inflate_wave_lds(void)
+{
+	return lda_inflate_lds_per_stream() + lda_inflate_lds_shared() + lda_inflate_window_bytes();
+}
+
+static size_t inflate_waves_per_cu(void)
+{
+	const size_t fit = 163840 / inflate_wave_lds(), want = (size_t)env_cfg().inflate_waves_per_cu;
+
+	return want < fit ? want : fit;
+}
+
+static size_t inflate_tokens_bytes(size_t n, int num_cus)
+{
+	size_t grid = (size_t)num_cus * inflate_waves_per_cu();
+
+	if (grid > n)
+		grid = n;
+	return grid * lda_inflate_tokcap() * 4 + 16;
+}
+
 /* lib/utils.c:61-67 */
 extern "C" LIBDEFLATEAPI void
 libdeflate_set_memory_allocator(void *(*malloc_func)(size_t),
@@ -204,29 +229,26 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		c->inflate_attr_set.store(true, std::memory_order_release);
 	}
 	if (par) {
-		const size_t per_cu = (size_t)env_cfg().inflate_waves_per_cu;	/* tuning */
-		size_t grid = (size_t)c->num_cus * per_cu;
-		if (grid > n)
-			grid = n;
+		const size_t grid_max = (size_t)c->num_cus * inflate_waves_per_cu();
+		size_t grid = grid_max < n ? grid_max : n;
 		/* token rows of every wave (lda_inflate_tokcap() words: one row
 		 * of 64 tokens per parse step of a round), then the counter the
 		 * waves take their second and later streams from */
 		const size_t tok_bytes = grid * lda_inflate_tokcap() * 4;
-		uint32_t *tok = (uint32_t *)d->tokens.reserve(tok_bytes + 16);
+		uint32_t *tok = (uint32_t *)d->tokens.reserve(inflate_tokens_bytes(n, c->num_cus));
 		if (!tok)
 			return LIBDEFLATE_AMD_OOM;
 		uint32_t *next = (uint32_t *)((uint8_t *)tok + tok_bytes);
 		LDA_HIP_TRY(hipMemsetAsync(next, 0, 16, st), LIBDEFLATE_AMD_NO_DEVICE);
-		/* a batch of several streams per wave slot is handed out longest
+		/* a batch of more streams than wave slots is handed out costliest
 		 * stream first (a batch that fits the grid starts all at once) */
 		uint32_t *order = NULL;
-		if (n >= 2 * grid && n < 0xFFFFFFFFull) {
+		if (n > grid && n < 0xFFFFFFFFull) {
 			order = (uint32_t *)(s + sums_bytes + 16 * n);
 			hipLaunchKernelGGL(lda_inflate_order_kernel, dim3(1), dim3(1024), 0, st,
-					   (uint64_t)n, d_in_nbytes, order);
+					   (uint64_t)n, d_in_nbytes, d_out_avail, order);
 		}
-		size_t lds = lda_inflate_lds_per_stream() + lda_inflate_lds_shared() +
-			     lda_inflate_window_bytes();
+		size_t lds = inflate_wave_lds();
 		hipLaunchKernelGGL(lda_inflate_wave_kernel, dim3((unsigned)grid),
 				   dim3(64), lds, st, (uint64_t)n, format, tok, next,
 				   (const uint32_t *)order,
@@ -376,10 +398,8 @@ static int decompress_batch_host_body(struct libdeflate_decompressor *d,
 	if (!d->scratch.reserve(align_up(n * 4, 16) + 16 * n + 4 * n + 16))
 		return LIBDEFLATE_AMD_OOM;
 	{
-		size_t grid = (size_t)device_ctx()->num_cus * (size_t)env_cfg().inflate_waves_per_cu;
-		if (grid > n)
-			grid = n;
-		if (env_cfg().inflate_par && !d->tokens.reserve(grid * lda_inflate_tokcap() * 4 + 16))
+		if (env_cfg().inflate_par &&
+		    !d->tokens.reserve(inflate_tokens_bytes(n, device_ctx()->num_cus)))
 			return LIBDEFLATE_AMD_OOM;
 	}
 	/* per-chunk read-backs land in pinned memory (asynchronous for real) and

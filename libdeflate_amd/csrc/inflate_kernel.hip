@@ -574,8 +574,10 @@ struct par_bits {
 /* 'inp' is the round's input span staged in LDS (8-byte aligned, PAR_SPAN
  * bytes); b->nb and all bit positions of a round are relative to it */
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
-#define PAR_STAGE_BYTES (256u * 4 + 2 * PAR_GBYTES)	/* >= PAR_SPAN */
-static_assert(PAR_SPAN <= 256u * 4 + 2 * 1088u, "the staged input span shares the copy phase's LDS");
+/* the staged span shares its LDS with the copy phase's scratch (a group's
+ * tokens and its byte -> token map): whichever is larger */
+#define PAR_COPY_BYTES (256u * 4 + 2 * PAR_GBYTES)
+#define PAR_STAGE_BYTES (PAR_SPAN > PAR_COPY_BYTES ? (PAR_SPAN + 15u) & ~15u : PAR_COPY_BYTES)
 
 static __device__ __forceinline__ u64 pb_load(const lu8 *inp, u32 nb)
 {
@@ -696,9 +698,7 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	/* what follows a literal is looked up now, beside the offset codeword of
 	 * a match and not behind it: a step is two dependent LDS round trips
 	 * for every kind of token (the callers pair two literals) */
-#ifndef E1_LATE
 	t.e1 = S->lit_tab[(u32)bb & ((1u << LIT_TB) - 1)];
-#endif
 	u32 lbase, xb;
 	len_sym(pay & 31, &lbase, &xb);
 	t.length = lbase + ((u32)bb & ((1u << xb) - 1));
@@ -719,9 +719,6 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	t.kind = kind;
 	t.lit = pay & 0xFF;
 	t.used = cl + (kind == K_LEN ? xb + ol + dxb : 0);
-#ifdef E1_LATE	/* (A/B knob of round 6: the lookup behind the offset codeword, as before) */
-	t.e1 = S->lit_tab[(u32)(buf >> t.used) & ((1u << LIT_TB) - 1)];
-#endif
 	return t;
 }
 
@@ -2083,16 +2080,30 @@ lda_inflate_batch_kernel(u64 n_chunks, int format, u32 lpw,
 #define PAR_WAVES_PER_SIMD 4	/* 16 streams in flight per CU: occupancy hides the LDS chains */
 #endif
 /*
- * Longest first: the streams of a batch larger than the grid are handed out
- * in the order of their compressed size, largest first (the cost of a stream
- * follows its size: the classic longest-processing-time rule keeps the last
- * waves from starting a long stream when the others are about to finish).
- * One workgroup: a 256-bucket counting sort by size / 512 (everything from
- * 128 KiB up shares the first bucket); the order inside a bucket is whatever
- * the atomics give - it only decides which wave decodes which stream.
+ * Costliest first: the streams of a batch in the order of what they cost to
+ * decode (the classic longest-processing-time rule: a batch larger than the
+ * grid is handed out in this order, so that the last waves do not start a long
+ * stream when the others are about to finish).  The cost of a stream
+ * follows its compressed size (measured on the benchmark kinds, 64 KiB out:
+ * 0.45 + 0.040 ms per KiB in) - except where that is all but the output's
+ * size: stored blocks, copied at memory speed.  One workgroup: a 256-bucket
+ * counting sort by cost / 512 (everything from 128 KiB up shares the first
+ * bucket); the order inside a bucket is whatever the atomics give - it only
+ * decides which wave decodes which stream.
  */
+static __device__ __forceinline__ u32
+order_bucket(const u64 *__restrict__ in_nbytes, const u64 *__restrict__ out_avail, u64 i)
+{
+	u64 b = in_nbytes[i];
+	if (out_avail && b + (b >> 5) >= out_avail[i])
+		b >>= 4;	/* (nearly) incompressible: stored */
+	b >>= 9;
+	return 255 - (b < 255 ? (u32)b : 255u);
+}
+
 extern "C" __global__ void __launch_bounds__(1024)
 lda_inflate_order_kernel(u64 n, const u64 *__restrict__ in_nbytes,
+			 const u64 *__restrict__ out_avail,
 			 u32 *__restrict__ order)
 {
 	__shared__ u32 cnt[256], at[256];
@@ -2101,10 +2112,8 @@ lda_inflate_order_kernel(u64 n, const u64 *__restrict__ in_nbytes,
 	if (tid < 256)
 		cnt[tid] = 0;
 	__syncthreads();
-	for (u64 i = tid; i < n; i += 1024) {
-		const u64 b = in_nbytes[i] >> 9;
-		atomicAdd(&cnt[255 - (b < 255 ? (u32)b : 255u)], 1u);
-	}
+	for (u64 i = tid; i < n; i += 1024)
+		atomicAdd(&cnt[order_bucket(in_nbytes, out_avail, i)], 1u);
 	__syncthreads();
 	if (tid < 64) {		/* exclusive prefix over the 256 buckets, one wave */
 		u32 v[4], s = 0;
@@ -2121,10 +2130,8 @@ lda_inflate_order_kernel(u64 n, const u64 *__restrict__ in_nbytes,
 		}
 	}
 	__syncthreads();
-	for (u64 i = tid; i < n; i += 1024) {
-		const u64 b = in_nbytes[i] >> 9;
-		order[atomicAdd(&at[255 - (b < 255 ? (u32)b : 255u)], 1u)] = (u32)i;
-	}
+	for (u64 i = tid; i < n; i += 1024)
+		order[atomicAdd(&at[order_bucket(in_nbytes, out_avail, i)], 1u)] = (u32)i;
 }
 
 extern "C" __global__ void __launch_bounds__(64, PAR_WAVES_PER_SIMD)

@@ -56,6 +56,11 @@
  * lib/decompress_template.h:85-245 through the functions of inflate_kernel.hip.
  */
 #define LDA_INFLATE_DEVICE_ONLY
+#ifndef STREAM_PAR_CB
+#define STREAM_PAR_CB 384u	/* this file's rounds keep their own piece length (LDS per chunk wave) */
+#endif
+#undef PAR_CB
+#define PAR_CB STREAM_PAR_CB
 #include "inflate_kernel.hip"
 #include "stream_kernels.h"
 

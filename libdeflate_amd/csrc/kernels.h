@@ -36,7 +36,8 @@ lda_inflate_wave_kernel(uint64_t n_chunks, int format, uint32_t *tokscratch,
 			const uint64_t *out_avail, int32_t *results,
 			uint64_t *actual_in, uint64_t *actual_out);
 extern "C" __global__ void
-lda_inflate_order_kernel(uint64_t n, const uint64_t *in_nbytes, uint32_t *order);
+lda_inflate_order_kernel(uint64_t n, const uint64_t *in_nbytes, const uint64_t *out_avail,
+			 uint32_t *order);
 extern "C" size_t lda_inflate_tokcap(void);
 extern "C" size_t lda_inflate_window_bytes(void);
 extern "C" __global__ void
