@@ -96,11 +96,14 @@ def test_compress_kernels_keep_their_register_budget():
     mk = open(os.path.join(csrc, "Makefile")).read()
     assert re.search(r"^NOLICM \?= .*\bdeflate_kernel\b.*\bdeflate_small\b", mk, re.M)
     assert re.search(r"\$\(NOLICM\).*: CXXFLAGS \+= -mllvm -disable-machine-licm", mk)
+    flags = ["-mllvm", "-disable-machine-licm"]
+    if "deflate_kernel" in re.search(r"^MAXILP \?= (.*)$", mk, re.M).group(1).split():
+        flags += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]    # (the Makefile's flags for this object)
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                        "-fvisibility=hidden", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
+                        "-fvisibility=hidden", "-ffp-contract=off", *flags,
                         "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c",
                         "deflate_kernel.hip", "-o", os.devnull],
                        cwd=csrc, capture_output=True, text=True, timeout=600)
@@ -110,7 +113,7 @@ def test_compress_kernels_keep_their_register_budget():
     assert set(kernels) >= {"lda_deflate_batch_kernel", "lda_deflate_opt_kernel"}
     vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", rep)]
     spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", rep)]
-    assert vgprs and max(vgprs) <= 96, vgprs      # round 5's final build: 85 / 83
+    assert vgprs and max(vgprs) <= 104, vgprs     # round 5: 85 / 83; round 6 (max-ilp scheduling): 99 / 97
     assert spills and max(spills) == 0, spills
 
 

@@ -2,8 +2,8 @@
 # scratch driver of one gpurun call (rewritten per call)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-INFL="main v_cb512 v_cb576 v_cb768" DEFL="main" LEVELS_OF="main" SMALL="main" tools/ab_r6.sh
-for v in v_cb576 v_cb768; do
-  LIBDEFLATE_AMD_LIB=$PWD/libdeflate_amd/libdeflate_amd_$v.so timeout 600 python -m pytest tests/test_inflate_gpu.py -x -q 2>&1 | tail -3
-done
-timeout 300 python -m pytest tests/test_deflate_gpu.py -x -q -k "recorded or ratio or roundtrip" 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r6_gputests_2.txt 2>&1; tail -3 gpurun_out/r6_gputests_2.txt
+DEFL="main v_ilpd" LEVELS_OF="v_ilpd" SMALL="v_ilpd" tools/ab_r6.sh
+{ for k in 5 0; do for n in 256 1024; do echo "== lone streams: kind $k x $n"; LIBDEFLATE_AMD_LIB=$PWD/libdeflate_amd/libdeflate_amd_prof.so timeout 120 python tools/microbench.py inflate --chunks $n --kind $k 2>&1 | grep -v amdgpu.ids; done; done; } > gpurun_out/r6_inflate_lone_profile.txt
+cat gpurun_out/r6_inflate_lone_profile.txt
+for k in 5 0 6; do for n in 256 1024; do timeout 120 python tools/microbench.py inflate --chunks $n --kind $k 2>&1 | grep "flate\["; done; done
