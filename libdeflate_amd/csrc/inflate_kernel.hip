@@ -119,31 +119,26 @@ enum { ST_HDR = 0, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
  * 286/287 and 30/31 alias their neighbours exactly as there) */
 static __device__ __forceinline__ void len_sym(u32 s, u32 *base, u32 *xb)
 {
-	if (s < 8) {
-		*base = 3 + s;
-		*xb = 0;
-	} else if (s >= 28) {
-		*base = 258;
-		*xb = 0;
-	} else {
-		u32 e = (s - 4) >> 2;
-		*xb = e;
-		*base = 3 + ((4 | (s & 3)) << e);
-	}
+	/* straight-line selects: as if / else the parse loop ran both sides
+	 * behind EXEC masks on every token */
+	const u32 e = (s - 4) >> 2;	/* (garbage below 8: not selected) */
+	const u32 mid = 3 + ((4 | (s & 3)) << (e & 7));
+	const bool lo = s < 8, hi = s >= 28;
+
+	*xb = lo || hi ? 0 : e;
+	*base = hi ? 258 : lo ? 3 + s : mid;
 }
 
 static __device__ __forceinline__ void off_sym(u32 d, u32 *base, u32 *xb)
 {
 	if (d > 29)
 		d = 29;
-	if (d < 4) {
-		*base = 1 + d;
-		*xb = 0;
-	} else {
-		u32 e = (d - 2) >> 1;
-		*xb = e;
-		*base = 1 + ((2 | (d & 1)) << e);
-	}
+	const u32 e = (d - 2) >> 1;	/* (garbage below 4: not selected) */
+	const u32 big = 1 + ((2 | (d & 1)) << (e & 15));
+	const bool lo = d < 4;
+
+	*xb = lo ? 0 : e;
+	*base = lo ? 1 + d : big;
 }
 
 /*
@@ -748,6 +743,12 @@ static __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
 
 typedef __attribute__((address_space(1))) u8 gu8;	/* output bytes in HBM */
 
+/* bit `lane` of a wave-uniform 64-bit mask: the mask IS a lane predicate */
+static __device__ __forceinline__ bool lane_bit(u64 uniform_mask)
+{
+	return __builtin_amdgcn_inverse_ballot_w64(uniform_mask);
+}
+
 /*
  * Output bytes one lane of the wave stored are read back by another lane
  * (match sources older than the LDS mirror; the sequential decoder's matches
@@ -910,13 +911,22 @@ tok_fetch(const u32 *__restrict__ rows, lu8 *mk, const lu16 *tb, u32 tbase,
 #undef DPP_MAX
 	c = __builtin_amdgcn_update_dpp(0, c, 0x138, 0xF, 0xF, true);	/* wave_shr:1, lane 0 gets 0 */
 	c = c > first ? c : first;
-	u32 w[4];
+	/* the four owners' bases first (one LDS round trip for all four), then
+	 * four unconditional loads: a token past `total` reads row 0 of its owner
+	 * and is masked (as `i < total ? rows[..] : 0` each load sat in an EXEC
+	 * section of its own behind its own LDS wait) */
+	u32 w[4], own[4], base[4];
 #pragma unroll
 	for (u32 j = 0; j < 4; j++) {
-		const u32 own = (o[j] > c ? o[j] : c) - 1;
+		own[j] = (o[j] > c ? o[j] : c) - 1;
+		base[j] = tb[own[j]];
+	}
+#pragma unroll
+	for (u32 j = 0; j < 4; j++) {
 		const u32 i = g + 4 * lane + j;
-		const u32 row = i - tb[own];
-		w[j] = i < total ? rows[row * 64 + own] : 0;
+		const u32 row = i < total ? i - base[j] : 0;
+		const u32 v = rows[row * 64 + own[j]];
+		w[j] = i < total ? v : 0;
 	}
 	return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -1011,8 +1021,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					eob = true;
 					run = false;
 				} else {
-					/* row ntok of the lane-interleaved list: the 64
-					 * lanes of an iteration write one 256-byte row */
 					if (keep && ntok < PAR_LANECAP)
 						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
@@ -1166,7 +1174,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			/* a distance that reaches back before the stream: possible only
 			 * in the first 32 KiB */
 			const u32 back_max = gbase < 32768 ? (u32)gbase : 32768u;
-			bool bad = false;
+			u64 badm = 0;	/* lanes whose distance reaches back before the stream */
 			/* The slots (64 bytes each) are resolved in order, so the
 			 * source of a byte is final in the mirror when its slot is
 			 * reached, unless it lies in the same slot.  The token lookup
@@ -1183,8 +1191,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				u32 own[SB], vfar[SB];
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
+					/* (an index past the group reads its last entry and is
+					 * masked: as `bi < gtot ? R[bi] : 0` each of the four
+					 * reads sat in an EXEC section of its own with its own
+					 * wait) */
 					const u32 bi = s0 + 64 * k + lane;
-					own[k] = bi < gtot ? R[bi] : 0;
+					const u32 r = R[bi < gtot ? bi : gtot - 1];
+					own[k] = bi < gtot ? r : 0;
 				}
 #define DPP_MAX(k, ctrl, rm, bc)                                               \
 	do {                                                                   \
@@ -1217,33 +1230,50 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
+					/* (own >= 1 everywhere: the group's first byte starts its
+					 * first token and the running maximum carries on) */
 					const u32 bi = s0 + 64 * k + lane;
-					own[k] = bi < gtot ? tk[own[k] - 1] : 0;	/* token word */
+					const u32 w = tk[own[k] - 1];	/* token word */
+					own[k] = bi < gtot ? w : 0;
 				}
-				/* bytes whose source is older than the mirror */
+				/* bytes whose source is older than the mirror.  The tests are
+				 * one ballot per compare, combined on the scalar unit (a
+				 * ballot of a compound predicate goes through a 0 / 1 detour
+				 * in a vector register), and the four slots share ONE
+				 * section: nothing of it runs when the batch has no such byte */
+				u64 mfar[SB], anyfar = 0, anyneed = 0;
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
 					const u32 bi = s0 + 64 * k + lane, tw = own[k];
 					const u32 dist = (tw >> 9) & 0xFFFF;
-					const bool before = (tw >> 31) && dist > bi;
-					const bool toofar = before && dist - bi > back_max;
-					const bool far = before && !toofar && dist - bi > ring_rel;
-					bad |= toofar;
+					const u32 back = dist - bi;	/* bytes in front of the group (when dist > bi) */
+					const u64 before = __ballot((s32)tw < 0) & __ballot(dist > bi);
+					const u64 toofar = before & __ballot(back > back_max);
+					mfar[k] = before & ~toofar & __ballot(back > ring_rel);
+					badm |= toofar;
+					anyfar |= mfar[k];
+					/* a source at or above safe_hi was stored by this wave
+					 * after its last wait: see below */
+					anyneed |= mfar[k] & __ballot(back <= (u32)(gbase - safe_hi));
 					vfar[k] = 0x100;	/* not a byte: no far source */
-					if (__ballot(far)) {
-						/* The source may be a byte another lane of this
-						 * wave stored earlier in THIS round (flush_ring);
-						 * everything below safe_hi was stored before a
-						 * wait.  Only a source at or above it - rare: it
-						 * must be older than the mirror and younger than
-						 * the last wait - makes the wave wait for its
-						 * stores (and for the token rows requested ahead)
-						 * before it loads. */
-						if (__ballot(far && dist - bi <= (u32)(gbase - safe_hi))) {
-							global_stores_visible();
-							safe_hi = flushed;
-						}
-						if (far)
+				}
+				if (anyfar) {
+					/* The source may be a byte another lane of this wave
+					 * stored earlier in THIS round (flush_ring); everything
+					 * below safe_hi was stored before a wait.  Only a source
+					 * at or above it - rare: it must be older than the mirror
+					 * and younger than the last wait - makes the wave wait for
+					 * its stores (and for the token rows requested ahead)
+					 * before it loads. */
+					if (anyneed) {
+						global_stores_visible();
+						safe_hi = flushed;
+					}
+#pragma unroll
+					for (u32 k = 0; k < SB; k++) {
+						const u32 bi = s0 + 64 * k + lane;
+						const u32 dist = (own[k] >> 9) & 0xFFFF;
+						if (lane_bit(mfar[k]))
 							vfar[k] = gfar[bi + 32768u - dist];
 					}
 				}
@@ -1289,7 +1319,10 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					const bool match = (tw >> 31) != 0;	/* false past gtot */
 					/* every lane reads the mirror (the index is always
 					 * inside it); matches from outside the slot use it */
-					const u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
+					u32 wv = win[(gb + bi - dist) & (PAR_RW - 1)];
+					/* (kept out of the branches below: as part of one the
+					 * read, and its wait, sat inside an EXEC section) */
+					asm volatile("" : "+v"(wv));
 					u32 v = match ? wv : tw & 0xFF;
 					v = vfar[k] < 0x100 ? vfar[k] : v;
 					if (__ballot(root[k] != lane))
@@ -1300,7 +1333,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			}
 			wave_sync();
 			PROF_SEC(3);
-			if (__ballot(bad)) {
+			if (badm) {
 				/* Invalid stream.  The sequential decoder takes the
 				 * round's bits again and reports it at the token where
 				 * it belongs; what the earlier groups wrote is what it
