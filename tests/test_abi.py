@@ -158,5 +158,5 @@ def test_visibility_probe_uses_the_products_access_pattern():
     far = [l.strip() for l in wave.splitlines() if re.match(r"\s*global_load_ubyte", l)]
     assert far, "no byte loads from the output in the wave kernel?"
     assert not [l for l in far if re.search(r"\b(sc0|sc1|nt)\b", l)], far
-    # the four slots of a batch each have their conditional wait + the round start + the block end
-    assert len(re.findall(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)", wave)) >= 6
+    # the round start, a batch of slots with a just-stored source, the block end, a stored block
+    assert len(re.findall(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)", wave)) >= 4
