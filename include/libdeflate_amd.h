@@ -233,11 +233,13 @@ LIBDEFLATEAPI size_t
 libdeflate_amd_last_fanout(void);
 
 /*
- * The kernels rely on two hardware behaviours beyond what the ISA manual
- * states (lane order of conflicting LDS atomics; a wave's global store being
- * visible to its own next load).  Both are checked on every device before its
- * first use (~1 ms, once per device and process; LDA_NO_SELFCHECK skips it):
- * a device that deviates is refused - the allocators return NULL and
+ * Two hardware behaviours are checked on every device before its first use
+ * (~1 ms, once per device and process; LDA_NO_SELFCHECK skips it): the lane
+ * order of conflicting LDS atomics (the compress kernel relies on it beyond
+ * what the ISA manual states) and - a belt: the kernels wait for their stores
+ * first, which is architected - that a wave's global store is visible to
+ * another lane's plain load behind s_waitcnt vmcnt(0).  A device that
+ * deviates is refused - the allocators return NULL and
  * libdeflate_amd_last_error() says why.  This runs the check again on the
  * current device: out[0..4] = LDS-atomic lanes checked, of them out of order,
  * same-instruction conflicts among them, loads checked, of them stale.

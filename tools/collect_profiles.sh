@@ -2,7 +2,7 @@
 # collect_profiles.sh TAG - copy what tools/prof_all.sh left in gpurun_out/ into
 # profiles/TAG_* (the committed evidence the documents cite)
 cd "$(dirname "$0")/.."
-tag=${1:-r05}
+tag=${1:-r06}
 for w in bench l1 l9 small opt inflate64k stream; do
   f=$(find gpurun_out/trace_${tag}_$w -name "*kernel_stats.csv" 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/${tag}_${w}_kernel_stats.csv

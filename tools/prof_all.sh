@@ -6,9 +6,9 @@
 # in gpurun_out/; tools/collect_profiles.sh TAG copies the summaries into
 # profiles/TAG_*.
 R=$GRAFT_REPO_ROOT
-tag=${1:-r05}
+tag=${1:-r06}
 cd $R
-for w in bench l1 small opt inflate64k stream; do
+for w in bench l1 l9 small opt inflate64k stream; do
   timeout 600 tools/prof_trace.sh $tag $w > gpurun_out/trace_${tag}_$w.log 2>&1
 done
 for w in bench l1 l9 opt small inflate64k stream; do
