@@ -85,7 +85,7 @@ struct stream_lds {
 	u16 lit_sorted[288];
 	u16 off_sorted[32];
 	u8 in_ring[128 + 8];	/* this stream's next input bytes (+8 mirror) */
-};
+} __attribute__((aligned(16)));	/* what follows it in LDS (mirror, copy scratch) takes 16-byte accesses */
 
 __constant__ u8 c_pre_perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 				   12, 3, 13, 2, 14, 1, 15 };
@@ -843,27 +843,28 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 
 /*
  * Output positions [flushed, end) are in the LDS mirror and not yet in
- * memory: store the whole 4-byte words among them (words of the POSITION, the
- * alignment the mirror can be read with) and return the new 'flushed'.  The
- * rest, less than a word, waits for the next group or the end of the round.
+ * memory: store the whole 16-byte units among them (units of the POSITION, the
+ * alignment the mirror can be read with: a group of 1 KiB leaves in one store
+ * per lane) and return the new 'flushed'.  The rest, less than a unit, waits
+ * for the next group or the end of the round.
  */
 static __device__ __forceinline__ u64
 flush_ring(gu8 *gout, const lu8 *win, u64 flushed, u64 end, u32 lane)
 {
-	u64 a = (flushed + 3) & ~(u64)3;
+	u64 a = (flushed + 15) & ~(u64)15;
 	if (a > end)
 		return flushed;
-	if (flushed + lane < a)		/* up to 3 bytes in front of the first word */
+	if (flushed + lane < a)		/* up to 15 bytes in front of the first unit */
 		gout[flushed + lane] = win[(u32)(flushed + lane) & (PAR_RW - 1)];
-	const u64 e = end & ~(u64)3;
+	const u64 e = end & ~(u64)15;
 	if (e <= a)
 		return a;
-	const u32 nw = (u32)(e - a) >> 2;
+	const u32 nq = (u32)(e - a) >> 4;
 	gu8 *dst = gout + a;
 	const u32 a32 = (u32)a;
-	for (u32 w = lane; w < nw; w += 64) {
-		const u32 v = *(const lu32 *)(win + ((a32 + 4 * w) & (PAR_RW - 1)));
-		__builtin_memcpy(dst + 4 * w, &v, 4);
+	for (u32 q = lane; q < nq; q += 64) {
+		const uint4 v = *(const AS3 uint4 *)(win + ((a32 + 16 * q) & (PAR_RW - 1)));
+		__builtin_memcpy(dst + 16 * q, &v, 16);
 	}
 	return e;
 }
@@ -1147,14 +1148,24 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 						    g + 4 * cnt, total_tok, lane);
 			/* byte -> token: every token drops its number at its first
 			 * byte, a running maximum over the bytes spreads it */
-			for (u32 b0 = lane; b0 < gtot; b0 += 64)
-				R[b0] = 0;
+			/* (the whole map is cleared with three 16-byte stores per lane
+			 * - 2 x 1024 + 128 bytes - instead of a loop of 2-byte stores
+			 * over the group's bytes: 12 rounds of 8 instructions) */
+			{
+				static_assert(2 * PAR_GBYTES == 2176, "two full wave stores and one of eight lanes");
+				const uint4 z = make_uint4(0, 0, 0, 0);
+				AS3 uint4 *R16 = (AS3 uint4 *)R;
+				R16[lane] = z;
+				R16[64 + lane] = z;
+				if (lane < 8)
+					R16[128 + lane] = z;
+			}
 			wave_sync();
 			if (lane < cnt) {
 				u32 o = incl0 - lsum;
+				*(AS3 uint4 *)&tk[4 * lane] = tq;	/* the lane's four token words */
 #pragma unroll
 				for (u32 j = 0; j < 4; j++) {
-					tk[4 * lane + j] = tw4[j];
 					if (len4[j])
 						R[o] = (u16)(4 * lane + j + 1);
 					o += len4[j];
