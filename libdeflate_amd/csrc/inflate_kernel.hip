@@ -805,10 +805,10 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 	const bool mine = lane >= f && lane < NL && cend == pe;
 	for (u32 ph = 0; ph < PAR_PHASES; ph++) {
 		struct par_bits b;
-		bool run = mine, stop = false;
+		bool stop = false;
 		pb_init(&b, span, ps + ph);
+		bool run = mine && PB_POS(b) < pe;	/* (tested at the end of the body: see par_round()) */
 		while (__ballot(run)) {
-			run = run && PB_POS(b) < pe;
 			pb_refill(&b, span);
 			const struct par_token t = par_decode(S, SH, pll, plo, b.buf);
 			const u32 e1 = t.e1;
@@ -823,6 +823,7 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 				b.buf >>= used;
 				b.cnt -= used;
 			}
+			run = run && PB_POS(b) < pe;
 		}
 		const u32 over = PB_POS(b) - pe;
 		const u64 code = mine && !stop && PB_POS(b) >= pe && over < PAR_PHASES ? over : 63;
@@ -993,7 +994,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	/* ---- sync passes ---- */
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
-		bool run = dirty;
 		/* the first pass is a guess for every lane but lane 0: its tokens
 		 * are not written (every other lane parses again in the second
 		 * pass, see below) */
@@ -1004,9 +1004,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			ntok = 0;
 			eob = false;
 		}
+		/* (a lane runs while its position is inside its piece: tested
+		 * where the position moves, at the end of the body, not at its
+		 * top - that form went round once more, a whole step, only to
+		 * find every lane at its end) */
+		bool run = dirty && PB_POS(b) < cend;
 		while (__ballot(run)) {
 			PROF_SEC_ADD(1, 1);
-			run = run && PB_POS(b) < cend;
 			pb_refill(&b, span);
 			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
 			/* A literal takes a second one with it when that one starts
@@ -1038,6 +1042,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				b.buf >>= used;
 				b.cnt -= used;
 			}
+			run = run && PB_POS(b) < cend;
 		}
 		if (dirty)
 			end = PB_POS(b);
@@ -1303,15 +1308,22 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				}
 				if (__ballot(any_intra)) {
 					for (;;) {
-						bool ch = false;
+						/* the four permutes go out together, one wait (as
+						 * `pp = permute; ch |= pp != root` per slot each
+						 * compare waited for its own permute) */
+						u32 pp[SB];
+#pragma unroll
+						for (u32 k = 0; k < SB; k++)
+							pp[k] = (u32)__builtin_amdgcn_ds_bpermute(
+									(int)(root[k] << 2), (int)root[k]);
+						asm volatile("" :: "v"(pp[0]), "v"(pp[1]), "v"(pp[2]), "v"(pp[3]));
+						u64 chm = 0;
 #pragma unroll
 						for (u32 k = 0; k < SB; k++) {
-							const u32 pp = (u32)__builtin_amdgcn_ds_bpermute(
-									(int)(root[k] << 2), (int)root[k]);
-							ch |= pp != root[k];
-							root[k] = pp;
+							chm |= __ballot(pp[k] != root[k]);
+							root[k] = pp[k];
 						}
-						if (!__ballot(ch))
+						if (!chm)
 							break;
 					}
 				}
