@@ -669,15 +669,18 @@ par_long_decode(const struct par_long *pl, const lu16 *sorted, u64 bits, u32 *le
 	return sorted[((acc >> 16) + (rev >> (16 - len))) & MASK];
 }
 
+/* (`act`: the lanes whose result is used.  The long-codeword paths run when ANY
+ * lane needs them; a lane that has finished its piece still decodes - garbage -
+ * and must not send the wave down them) */
 static __device__ __forceinline__ struct par_token
 par_decode(const slds_t *S, const shlds_t *SH,
-	   const struct par_long *pll, const struct par_long *plo, u64 buf)
+	   const struct par_long *pll, const struct par_long *plo, u64 buf, bool act = true)
 {
 	struct par_token t;
 	u32 e = S->lit_tab[(u32)buf & ((1u << LIT_TB) - 1)];
 	u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
 
-	if (__ballot(cl == 0)) {
+	if (__ballot(cl == 0) & __ballot(act)) {
 		u32 l2;
 		u32 sym = par_long_decode<LIT_TB + 1, 511>(pll, S->lit_sorted, buf, &l2);
 		if (cl == 0) {
@@ -700,7 +703,7 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	bb >>= xb;
 	u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
 	u32 ol = e2 & 15, osym = e2 >> 4;
-	if (__ballot(kind == K_LEN && ol == 0)) {
+	if (__ballot(kind == K_LEN) & __ballot(ol == 0) & __ballot(act)) {
 		u32 l2;
 		u32 sym = par_long_decode<OFF_TB + 1, 31>(plo, S->off_sorted, bb, &l2);
 		if (ol == 0) {
@@ -810,7 +813,7 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 		bool run = mine && PB_POS(b) < pe;	/* (tested at the end of the body: see par_round()) */
 		while (__ballot(run)) {
 			pb_refill(&b, span);
-			const struct par_token t = par_decode(S, SH, pll, plo, b.buf);
+			const struct par_token t = par_decode(S, SH, pll, plo, b.buf, run);
 			const u32 e1 = t.e1;
 			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < pe &&
 					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
@@ -994,10 +997,6 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	/* ---- sync passes ---- */
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
-		/* the first pass is a guess for every lane but lane 0: its tokens
-		 * are not written (every other lane parses again in the second
-		 * pass, see below) */
-		const bool keep = pass != 0 || lane == 0;
 		pb_init(&b, span, start);
 		if (dirty) {
 			nbytes = 0;
@@ -1009,10 +1008,30 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		 * top - that form went round once more, a whole step, only to
 		 * find every lane at its end) */
 		bool run = dirty && PB_POS(b) < cend;
+		if (pass == 0) {
+			/* The first pass is a guess for every lane but lane 0, and
+			 * every lane parses again in the second: all it has to find
+			 * is where each lane's parse ENDS.  Its loop keeps nothing
+			 * else - no token words, lengths, distances, counts (the
+			 * compiler drops what computes them) - and lane 0 records
+			 * its tokens in the second pass with everybody else. */
+			while (__ballot(run)) {
+				PROF_SEC_ADD(1, 1);
+				pb_refill(&b, span);
+				const struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
+				const u32 e1 = t.e1;
+				const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
+						 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+				const u32 used = run ? t.used + (two ? e1 & 15 : 0) : 0;
+				b.buf >>= used;
+				b.cnt -= used;
+				run = run && t.kind != K_EOB && PB_POS(b) < cend;
+			}
+		} else
 		while (__ballot(run)) {
 			PROF_SEC_ADD(1, 1);
 			pb_refill(&b, span);
-			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf);
+			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
 			/* A literal takes a second one with it when that one starts
 			 * inside the piece and its codeword is in the table: a pass
 			 * lasts as long as its lane with the most tokens, and those
@@ -1026,13 +1045,15 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					eob = true;
 					run = false;
 				} else {
-					if (keep && ntok < PAR_LANECAP)
+					/* row ntok of the lane-interleaved list: the 64
+					 * lanes of an iteration write one 256-byte row */
+					if (ntok < PAR_LANECAP)
 						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
 					if (two) {
-						if (keep && ntok < PAR_LANECAP)
+						if (ntok < PAR_LANECAP)
 							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
 						nbytes++;
 						ntok++;
@@ -1050,7 +1071,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		u32 ns = __builtin_amdgcn_update_dpp(end, end, 0x138, 0xF, 0xF, false);
 		if (lane == 0)
 			ns = bpos0;
-		dirty = (ns != start || (pass == 0 && lane != 0)) && lane < NL;
+		dirty = (ns != start || pass == 0) && lane < NL;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {	/* end of block on the exact prefix */
