@@ -1025,6 +1025,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				const u32 used = run ? t.used + (two ? e1 & 15 : 0) : 0;
 				b.buf >>= used;
 				b.cnt -= used;
+				eob = eob || (run && t.kind == K_EOB);
 				run = run && t.kind != K_EOB && PB_POS(b) < cend;
 			}
 		} else
@@ -1072,6 +1073,11 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		if (lane == 0)
 			ns = bpos0;
 		dirty = (ns != start || pass == 0) && lane < NL;
+		/* (the block ends in lane 0's piece - a stream of tiny blocks,
+		 * programs/test_slow_decompression.c: only lane 0 parses again, to
+		 * record its tokens; nothing behind it belongs to the round) */
+		if (pass == 0 && bcast_lane(eob ? 1u : 0u, 0))
+			dirty = lane == 0;
 		const u64 dm = __ballot(dirty), em = __ballot(eob);
 		const u64 exact = dm ? (1ull << __builtin_ctzll(dm)) - 1 : ~0ull;
 		if (em & exact) {	/* end of block on the exact prefix */
