@@ -112,7 +112,7 @@ typedef AS3 u16 lu16;
 typedef AS3 u32 lu32;
 typedef AS3 u64 lu64;
 
-enum { ST_HDR = 0, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
+enum { ST_HDR = 0, ST_PRETAB, ST_LENS, ST_TABLES, ST_TOK, ST_STORED, ST_DONE };
 
 /* length / offset symbol -> base and extra-bit count, computed instead of
  * looked up (values of lib/deflate_decompress.c:555-588, :615-628; symbols
@@ -226,6 +226,63 @@ static __device__ bool build_precode(lu16 *tab, const u8 *plens)
 		u32 rev = __brev(next[l]++) >> (32 - l);
 		for (u32 i = rev; i < 128; i += 1u << l)
 			tab[i] = ENTRY(0, s, l);
+	}
+	return true;
+}
+
+/*
+ * The same by all 64 lanes, from the 19 lengths in LDS (the wave-per-stream
+ * kernel: the serial build above indexes small private arrays with run-time
+ * values, which compile into select chains - ten thousand instructions on
+ * the one lane that holds the stream, 5 % of a 64 KiB stream's).  Lane s is
+ * symbol s: the counts per length are ballots, a symbol's codeword is the
+ * first codeword of its length plus its rank among the symbols of that
+ * length, and it fills its own 2^(7 - len) table entries.  Same validity
+ * rules, same tables.  Returns false (uniformly) if the code is invalid.
+ */
+static __device__ bool build_precode_coop(lu16 *tab, const lu8 *plens, u32 lane)
+{
+	const u32 l = lane < 19 ? plens[lane] : 0;
+	u64 m[8];
+	u32 c[8];
+#pragma unroll
+	for (u32 L = 1; L < 8; L++) {
+		m[L] = __ballot(l == L);
+		c[L] = (u32)__builtin_popcountll(m[L]);
+	}
+	u32 maxlen = 7;
+	while (maxlen > 1 && c[maxlen] == 0)
+		maxlen--;
+	u32 used = 0, next[8], code = 0;
+#pragma unroll
+	for (u32 L = 1; L < 8; L++) {
+		next[L] = code;
+		code = (code + c[L]) << 1;
+		if (L <= maxlen)
+			used = (used << 1) + c[L];
+	}
+	if (used > (1u << maxlen))
+		return false;
+	if (used < (1u << maxlen)) {
+		u32 sym = 0;
+		if (used != 0) {
+			if (used != (1u << (maxlen - 1)) || c[1] != 1)
+				return false;
+			sym = (u32)__builtin_ctzll(m[1]);	/* the one symbol of length 1 */
+		}
+		tab[lane] = ENTRY(0, sym, 1);
+		tab[64 + lane] = ENTRY(0, sym, 1);
+		return true;
+	}
+	u32 cw = 0;
+	const u64 lt = (1ull << lane) - 1;
+#pragma unroll
+	for (u32 L = 1; L < 8; L++)
+		cw = l == L ? next[L] + (u32)__builtin_popcountll(m[L] & lt) : cw;
+	if (l) {
+		const u32 rev = __brev(cw) >> (32 - l);
+		for (u32 i = rev; i < 128; i += 1u << l)
+			tab[i] = ENTRY(0, lane, l);
 	}
 	return true;
 }
@@ -555,6 +612,9 @@ ring_fill(lu8 *ring, const u8 *inp, u64 in_n, u64 at)
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
 #endif
 #define PAR_LANECAP (PAR_CB / 2)	/* tokens one lane may find in its piece (2 bits each) */
+#ifndef PAR_TAIL
+#define PAR_TAIL 8u		/* input bytes a round needs in front of it */
+#endif
 #define PAR_SCRATCH (64u * PAR_LANECAP)	/* u32 words per wave */
 #define PAR_MAP_BYTES (256u + 128u)	/* tok_fetch: marks + tbase table */
 enum { PAR_STOP = 0, PAR_OK = 1, PAR_EOB = 2 };
@@ -958,7 +1018,10 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * beyond the input is abandoned below and left to that decoder (it is
 	 * the one that knows the overread rules). */
 	const u64 byte0 = bpos_abs >> 3;
-	if (byte0 + 64 > in_n)
+	/* (rounds run up to the last bytes of the input: what is left behind them
+	 * goes token by token through lane 0 - with a margin of 64 bytes that was
+	 * some fifty tokens per stream, 2 % of a 64 KiB stream's instructions) */
+	if (byte0 + PAR_TAIL > in_n)
 		return PAR_STOP;
 	u32 *__restrict__ tokS = tok;	/* [PAR_LANECAP][64]: row k holds every lane's k-th token */
 	/* long pieces need fewer rounds and fewer passes per round (a parse
@@ -1602,13 +1665,16 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				} else {
 					/* dynamic header: decompress_template.h:85-245 (its
 					 * scratch shares the tables' LDS) */
-					u8 plens[19];
+					/* (the 19 precode lengths go to LDS scratch behind
+					 * lens[]: a private array indexed by c_pre_perm[i]
+					 * compiles into a 19-way select chain per store) */
+					lu8 *plens = (lu8 *)S->lit_tab + 480;
 					static_loaded = false;
 					nlit = 257 + (((u32)bitbuf >> 3) & 31);
 					noff = 1 + (((u32)bitbuf >> 8) & 31);
 					u32 npre = 4 + (((u32)bitbuf >> 13) & 15);
-					for (u32 i = 0; i < 19; i++)
-						plens[i] = 0;
+					for (u32 i = 0; i < 5; i++)
+						((lu32 *)plens)[i] = 0;
 					plens[c_pre_perm[0]] = ((u32)bitbuf >> 17) & 7;
 					CONSUME(20);
 					ENSURE_INPUT();
@@ -1621,60 +1687,78 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 							plens[c_pre_perm[i]] = (u32)bitbuf & 7;
 							CONSUME(3);
 						}
-						if (!build_precode(S->pre_tab, plens)) {
-							result = LDA_BAD_DATA;
-							state = ST_DONE;
-						}
-					}
-					if (state == ST_HDR) {
-						/* code length runs (:150-245); bitcnt tracks the
-						 * reference's bitsleft: both were topped up at
-						 * the same points */
-						u32 i = 0, total = nlit + noff, bad = 0;
-						do {
-							if (bitcnt < 14) {
-								ENSURE_INPUT();
-								REFILL();
-								if (CONSUMED() > limit_bits) {
-									bad = 1;
-									break;
-								}
-							}
-							u32 e = S->pre_tab[(u32)bitbuf & 127];
-							CONSUME(e & 15);
-							u32 presym = e >> 4;
-							if (presym < 16) {
-								S->lens[i++] = (u8)presym;
-								continue;
-							}
-							u32 rep, val = 0;
-							if (presym == 16) {
-								if (i == 0) {
-									bad = 1;
-									break;
-								}
-								val = S->lens[i - 1];
-								rep = 3 + ((u32)bitbuf & 3);
-								CONSUME(2);
-							} else if (presym == 17) {
-								rep = 3 + ((u32)bitbuf & 7);
-								CONSUME(3);
-							} else {
-								rep = 11 + ((u32)bitbuf & 127);
-								CONSUME(7);
-							}
-							for (u32 k = 0; k < rep; k++)
-								S->lens[i + k] = (u8)val;
-							i += rep;
-						} while (i < total);
-						if (bad || i != total) {
-							result = LDA_BAD_DATA;
-							state = ST_DONE;
-						} else {
-							state = ST_TABLES;
-						}
+						state = ST_PRETAB;
 					}
 				}
+			}
+		}
+		/* ------------ precode tables: one stream at a time, all lanes ------------ */
+		{
+			u64 need = __ballot(state == ST_PRETAB);
+			while (need) {
+				const u32 who = (u32)__builtin_ctzll(need);
+				need &= need - 1;
+				slds_t *T = &SL[who];
+				wave_sync();
+				const bool ok = build_precode_coop(T->pre_tab, (lu8 *)T->lit_tab + 480, lane);
+				wave_sync();
+				if (lane == who) {
+					if (ok) {
+						state = ST_LENS;
+					} else {
+						result = LDA_BAD_DATA;
+						state = ST_DONE;
+					}
+				}
+			}
+		}
+		/* ------------ code length runs (lanes whose precode is built) ------------ */
+		if (state == ST_LENS) {
+			/* code length runs (:150-245); bitcnt tracks the
+			 * reference's bitsleft: both were topped up at
+			 * the same points */
+			u32 i = 0, total = nlit + noff, bad = 0;
+			do {
+				if (bitcnt < 14) {
+					ENSURE_INPUT();
+					REFILL();
+					if (CONSUMED() > limit_bits) {
+						bad = 1;
+						break;
+					}
+				}
+				u32 e = S->pre_tab[(u32)bitbuf & 127];
+				CONSUME(e & 15);
+				u32 presym = e >> 4;
+				if (presym < 16) {
+					S->lens[i++] = (u8)presym;
+					continue;
+				}
+				u32 rep, val = 0;
+				if (presym == 16) {
+					if (i == 0) {
+						bad = 1;
+						break;
+					}
+					val = S->lens[i - 1];
+					rep = 3 + ((u32)bitbuf & 3);
+					CONSUME(2);
+				} else if (presym == 17) {
+					rep = 3 + ((u32)bitbuf & 7);
+					CONSUME(3);
+				} else {
+					rep = 11 + ((u32)bitbuf & 127);
+					CONSUME(7);
+				}
+				for (u32 k = 0; k < rep; k++)
+					S->lens[i + k] = (u8)val;
+				i += rep;
+			} while (i < total);
+			if (bad || i != total) {
+				result = LDA_BAD_DATA;
+				state = ST_DONE;
+			} else {
+				state = ST_TABLES;
 			}
 		}
 		PROF_MARK(0);
