@@ -209,11 +209,17 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 	 * the slowest lane, fewer divergent paths); lpw only grows once the
 	 * batch no longer fits in flight (measured best: 2 at 4096 streams, 8 at
 	 * 65536 on 256 CUs) */
+	/* (as many streams as a workgroup's LDS holds tables for) */
+	uint32_t lpw_max = 64;
+	while (lda_inflate_lds_per_stream() * lpw_max + lda_inflate_lds_shared() > 163840)
+		lpw_max >>= 1;
 	uint32_t lpw = 2;
-	while (lpw < 64 && (size_t)lpw * 32 * (size_t)c->num_cus < n)
+	while (lpw < lpw_max && (size_t)lpw * 32 * (size_t)c->num_cus < n)
 		lpw <<= 1;
 	if (env_cfg().inflate_lpw)	/* tuning aid */
 		lpw = (uint32_t)env_cfg().inflate_lpw;
+	if (lpw > lpw_max)
+		lpw = lpw_max;
 	/* wave per stream with sub-block parallel token decoding (the default):
 	 * one stream keeps all 64 lanes of its wave busy, so even a batch that
 	 * is small next to the machine (4096 streams on 1024 SIMDs) runs at the
@@ -223,7 +229,7 @@ libdeflate_amd_decompress_batch(struct libdeflate_decompressor *d, int format,
 		LDA_HIP_TRY(hipFuncSetAttribute(
 				(const void *)lda_inflate_batch_kernel,
 				hipFuncAttributeMaxDynamicSharedMemorySize,
-				(int)(lda_inflate_lds_per_stream() * 64 +
+				(int)(lda_inflate_lds_per_stream() * lpw_max +
 				      lda_inflate_lds_shared())),
 			    LIBDEFLATE_AMD_NO_DEVICE);
 		c->inflate_attr_set.store(true, std::memory_order_release);

@@ -55,8 +55,28 @@
 #ifndef PAR_PRIO
 #define PAR_PRIO 1	/* wave-per-stream: issue priority by the share of the input still ahead */
 #endif
-#define LIT_TB 9
-#define OFF_TB 7
+/*
+ * Primary table bits.  The tables' LDS holds LIT_TB / OFF_TB bits; a block
+ * uses that many or the _MIN ones (inflate_block() decides per block: a table
+ * of 10 bits sends a wave down the long-codeword path in one step of five
+ * instead of one of two on text, but costs twice the entries to fill - a
+ * small block keeps 9 / 7).  The parse (par_decode()) takes the masks as
+ * wave-uniform values; the long-codeword walk starts at the _MIN length and a
+ * block with the larger table has that length's limit out of reach.
+ */
+#ifndef LIT_TB
+#define LIT_TB 10
+#endif
+#ifndef LIT_TB_MIN
+#define LIT_TB_MIN 9
+#endif
+#ifndef OFF_TB
+#define OFF_TB 8
+#endif
+#ifndef OFF_TB_MIN
+#define OFF_TB_MIN 7
+#endif
+#define TB_BIG_BLOCK 8192u	/* bytes of input: see inflate_block() */
 
 /* 16-bit table entry: [3:0] codeword length (0 = longer than the table),
  * [15:14] kind, [13:4] payload (literal byte / length index / offset index /
@@ -693,13 +713,16 @@ struct par_long {
 	u32 acc0;	/* from | adj[from] << 16; adj[l] = index[l] - first[l] */
 };
 
-static __device__ __forceinline__ void
+/* `from` (wave-uniform) is FROM or FROM + 1: the first length beyond the
+ * block's table; par_long_decode<FROM> walks from FROM either way */
+template <u32 FROM> static __device__ __forceinline__ void
 par_long_init(struct par_long *pl, const lcanon_t *cn, u32 from)
 {
 	u32 adj[16];
+	const bool up = from > FROM;
 #pragma unroll
 	for (u32 l = 1; l < 16; l++) {
-		if (l >= from) {
+		if (l >= FROM) {
 			const u32 first = bcast_first(cn->first[l]);
 			const u32 count = bcast_first(cn->count[l]);
 			const u32 index = bcast_first(cn->index[l]);
@@ -707,10 +730,12 @@ par_long_init(struct par_long *pl, const lcanon_t *cn, u32 from)
 			adj[l] = (index - first) & 0xFFFF;
 		}
 	}
-	pl->acc0 = from | (adj[from] << 16);
+	/* (a left-justified codeword is below 1 << 16: that limit is never reached) */
+	pl->limit[FROM] = up ? 0xFFFFFFFFu : pl->limit[FROM];
+	pl->acc0 = up ? (FROM + 1) | (adj[FROM + 1] << 16) : FROM | (adj[FROM] << 16);
 #pragma unroll
 	for (u32 l = 1; l < 15; l++)
-		if (l >= from)
+		if (l >= FROM)
 			pl->inc[l] = 1 + (((adj[l + 1] - adj[l]) & 0xFFFF) << 16);
 }
 
@@ -734,15 +759,16 @@ par_long_decode(const struct par_long *pl, const lu16 *sorted, u64 bits, u32 *le
  * and must not send the wave down them) */
 static __device__ __forceinline__ struct par_token
 par_decode(const slds_t *S, const shlds_t *SH,
-	   const struct par_long *pll, const struct par_long *plo, u64 buf, bool act = true)
+	   const struct par_long *pll, const struct par_long *plo, u64 buf, bool act = true,
+	   u32 lmask = (1u << LIT_TB) - 1, u32 omask = (1u << OFF_TB) - 1)
 {
 	struct par_token t;
-	u32 e = S->lit_tab[(u32)buf & ((1u << LIT_TB) - 1)];
+	u32 e = S->lit_tab[(u32)buf & lmask];
 	u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
 
 	if (__ballot(cl == 0) & __ballot(act)) {
 		u32 l2;
-		u32 sym = par_long_decode<LIT_TB + 1, 511>(pll, S->lit_sorted, buf, &l2);
+		u32 sym = par_long_decode<LIT_TB_MIN + 1, 511>(pll, S->lit_sorted, buf, &l2);
 		if (cl == 0) {
 			cl = l2;
 			kind = sym < 256 ? K_LIT : sym == 256 ? K_EOB : K_LEN;
@@ -756,16 +782,16 @@ par_decode(const slds_t *S, const shlds_t *SH,
 	/* what follows a literal is looked up now, beside the offset codeword of
 	 * a match and not behind it: a step is two dependent LDS round trips
 	 * for every kind of token (the callers pair two literals) */
-	t.e1 = S->lit_tab[(u32)bb & ((1u << LIT_TB) - 1)];
+	t.e1 = S->lit_tab[(u32)bb & lmask];
 	u32 lbase, xb;
 	len_sym(pay & 31, &lbase, &xb);
 	t.length = lbase + ((u32)bb & ((1u << xb) - 1));
 	bb >>= xb;
-	u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
+	u32 e2 = S->off_tab[(u32)bb & omask];
 	u32 ol = e2 & 15, osym = e2 >> 4;
 	if (__ballot(kind == K_LEN) & __ballot(ol == 0) & __ballot(act)) {
 		u32 l2;
-		u32 sym = par_long_decode<OFF_TB + 1, 31>(plo, S->off_sorted, bb, &l2);
+		u32 sym = par_long_decode<OFF_TB_MIN + 1, 31>(plo, S->off_sorted, bb, &l2);
 		if (ol == 0) {
 			ol = l2;
 			osym = sym;
@@ -787,7 +813,7 @@ par_decode(const slds_t *S, const shlds_t *SH,
  * path of the copy phase.
  */
 #ifndef PAR_RW
-#define PAR_RW 4096u
+#define PAR_RW 2048u
 #endif
 #define PAR_GBYTES 1088u	/* output bytes resolved per group (>= 4 x 258) */
 
@@ -858,7 +884,8 @@ static __device__ __forceinline__ void global_stores_visible(void)
 static __device__ u32
 par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 		 const struct par_long *plo, const lu8 *span, u32 bpos0, u32 cb, u32 cend,
-		 u32 lane, u32 NL, u32 f, u32 start_f, u32 cur)
+		 u32 lane, u32 NL, u32 f, u32 start_f, u32 cur,
+		 u32 lmask = (1u << LIT_TB) - 1, u32 omask = (1u << OFF_TB) - 1)
 {
 	const u32 ps = bpos0 + lane * cb, pe = ps + cb;
 	u32 o = start_f - (bpos0 + f * cb);	/* wave-uniform */
@@ -873,7 +900,7 @@ par_phase_starts(const slds_t *S, const shlds_t *SH, const struct par_long *pll,
 		bool run = mine && PB_POS(b) < pe;	/* (tested at the end of the body: see par_round()) */
 		while (__ballot(run)) {
 			pb_refill(&b, span);
-			const struct par_token t = par_decode(S, SH, pll, plo, b.buf, run);
+			const struct par_token t = par_decode(S, SH, pll, plo, b.buf, run, lmask, omask);
 			const u32 e1 = t.e1;
 			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < pe &&
 					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
@@ -1010,8 +1037,9 @@ static __device__ u32
 par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	  const slds_t *S, const shlds_t *SH,
 	  u32 *__restrict__ tok, lu8 *win, lu8 *stage, u64 ring_lo, u32 lane,
-	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret)
+	  u64 bpos_abs, u64 out0, u64 *bpos_ret, u64 *out_ret, u32 ltb, u32 otb)
 {
+	const u32 lmask = (1u << ltb) - 1, omask = (1u << otb) - 1;	/* wave-uniform */
 	/* lanes in this round: one PAR_CB-bit chunk each, up to the end of the
 	 * input.  Bytes past the end are staged as zeros, exactly the implicit
 	 * padding of the sequential decoder; a round whose exact parse ends
@@ -1047,8 +1075,8 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	const lu8 *span = stage;	/* the parse reads the staged copy */
 	const u32 bpos0 = (u32)bpos_abs & 7;	/* positions relative to the span */
 	struct par_long pll, plo;
-	par_long_init(&pll, &S->lit, LIT_TB + 1);
-	par_long_init(&plo, &S->off, OFF_TB + 1);
+	par_long_init<LIT_TB_MIN + 1>(&pll, &S->lit, ltb + 1);
+	par_long_init<OFF_TB_MIN + 1>(&plo, &S->off, otb + 1);
 	const u32 cend = bpos0 + (lane + 1) * cb;
 	u32 start = bpos0 + lane * cb, end = 0;
 	u32 nbytes = 0, ntok = 0;
@@ -1081,7 +1109,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			while (__ballot(run)) {
 				PROF_SEC_ADD(1, 1);
 				pb_refill(&b, span);
-				const struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
+				const struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run, lmask, omask);
 				const u32 e1 = t.e1;
 				const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
 						 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
@@ -1095,7 +1123,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 		while (__ballot(run)) {
 			PROF_SEC_ADD(1, 1);
 			pb_refill(&b, span);
-			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
+			struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run, lmask, omask);
 			/* A literal takes a second one with it when that one starts
 			 * inside the piece and its codeword is in the table: a pass
 			 * lasts as long as its lane with the most tokens, and those
@@ -1154,7 +1182,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			/* the passes are not converging: see par_phase_starts() */
 			const u32 f = (u32)__builtin_ctzll(dm);
 			const u32 g = par_phase_starts(S, SH, &pll, &plo, span, bpos0, cb, cend, lane,
-						       NL, f, bcast_lane(ns, f), ns);
+						       NL, f, bcast_lane(ns, f), ns, lmask, omask);
 			if (lane > f && lane < NL) {
 				ns = g;
 				dirty = ns != start;
@@ -1593,6 +1621,12 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 	u32 bitcnt = 0, final_block = 0, nlit = 0, noff = 0;
 	u64 stored_left = 0;
 	bool static_loaded = false;	/* the stream's tables are the static codes' */
+	/* the current block has the larger tables (see LIT_TB); where its header
+	 * began (bits, modulo 2^32: only differences below TB_BIG_BLOCK matter) */
+	bool tb_big = false;
+	u32 blk_at = 0;
+#define ltb (tb_big ? LIT_TB : LIT_TB_MIN)
+#define otb (tb_big ? OFF_TB : OFF_TB_MIN)
 	u64 pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;	/* loaded, not yet stored */
 	u8 *pend_dst = outp;
 	u32 pend_n = 0, pend_len = 0;
@@ -1615,6 +1649,15 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 			} else {
 				final_block = (u32)bitbuf & 1;
 				u32 btype = ((u32)bitbuf >> 1) & 3;
+				/* the larger tables where they will be used enough to pay
+				 * for their entries: a dynamic block with input ahead of
+				 * it, behind a block that was not a small one */
+				{
+					const u64 at = CONSUMED();
+					const bool was_small = at != 0 && (u32)at - blk_at < 8 * TB_BIG_BLOCK;
+					tb_big = btype == 2 && !was_small && in_n - (at >> 3) >= TB_BIG_BLOCK;
+					blk_at = (u32)at;
+				}
 				if (btype == 0) {
 					/* stored: decompress_template.h:247-285 */
 					CONSUME(3);
@@ -1659,6 +1702,8 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 								     i < 280 ? 7 : i < 288 ? 8 : 5;
 						nlit = 288;
 						noff = 32;
+						/* (no static codeword is longer than 9 / 5 bits:
+						 * tb_big is false) */
 						state = ST_TABLES;
 						static_loaded = true;	/* taken back if the build fails (ST_TABLES) */
 					}
@@ -1670,6 +1715,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					 * compiles into a 19-way select chain per store) */
 					lu8 *plens = (lu8 *)S->lit_tab + 480;
 					static_loaded = false;
+
 					nlit = 257 + (((u32)bitbuf >> 3) & 31);
 					noff = 1 + (((u32)bitbuf >> 8) & 31);
 					u32 npre = 4 + (((u32)bitbuf >> 13) & 15);
@@ -1772,20 +1818,22 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				slds_t *T = &SL[who];
 				u32 t_nlit = bcast_lane(nlit, who);
 				u32 t_noff = bcast_lane(noff, who);
+				const bool t_big = bcast_lane(tb_big ? 1u : 0u, who) != 0;
+				const u32 t_ltb = t_big ? LIT_TB : LIT_TB_MIN, t_otb = t_big ? OFF_TB : OFF_TB_MIN;
 				u32 s_lit, s_off;
 				wave_sync();
 				/* both sorts read lens[] before any table overwrites it;
 				 * offset first as in the reference (:331-332) */
-				bool ok = build_table_coop(T->lens + t_nlit, t_noff, OFF_TB,
+				bool ok = build_table_coop(T->lens + t_nlit, t_noff, t_otb,
 							   false, &T->off, T->off_sorted,
 							   lane, &s_off);
-				ok = build_table_coop(T->lens, t_nlit, LIT_TB, true, &T->lit,
+				ok = build_table_coop(T->lens, t_nlit, t_ltb, true, &T->lit,
 						      T->lit_sorted, lane, &s_lit) && ok;
 				wave_sync();
 				if (ok) {
-					fill_table(T->off_tab, OFF_TB, false, &T->off,
+					fill_table(T->off_tab, t_otb, false, &T->off,
 						   T->off_sorted, s_off, lane);
-					fill_table(T->lit_tab, LIT_TB, true, &T->lit,
+					fill_table(T->lit_tab, t_ltb, true, &T->lit,
 						   T->lit_sorted, s_lit, lane);
 				}
 				wave_sync();
@@ -1899,7 +1947,8 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 						   bcast64(out_avail), &SL[0], SH, tok,
 						   (lu8 *)(SH + 1), (lu8 *)(SH + 1) + PAR_RW,
 						   ring_lo, lane, bpos0, o0,
-						   &nb, &no);
+						   &nb, &no, bcast_first(ltb), bcast_first(otb));
+
 				PROF_COUNT(12 + pr, 1);
 				if (pr == PAR_STOP)
 					break;
@@ -1946,7 +1995,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				if (filled < rpos + 64)
 					ENSURE_INPUT();
 				REFILL();
-				u32 e = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+				u32 e = S->lit_tab[(u32)bitbuf & ((1u << ltb) - 1)];
 				FLUSH_PENDING();
 				u32 cl = e & 15;
 				if (cl == 0) {
@@ -1954,7 +2003,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				} else if ((e & 0xC000) == K_LIT) {
 					u32 pay = (e >> 4) & 0xFF;
 					CONSUME(cl);
-					u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+					u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << ltb) - 1)];
 					if ((e1 & 15) && (e1 & 0xC000) == K_LIT) {
 						u16 two = (u16)(pay | (((e1 >> 4) & 0xFF) << 8));
 						__builtin_memcpy(outp + out_pos, &two, 2);
@@ -1979,7 +2028,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 					u32 length = (lt & 0xFFFF) + ((u32)bb & ((1u << xb) - 1));
 					bb >>= xb;
 					u32 used = cl + xb;
-					u32 e2 = S->off_tab[(u32)bb & ((1u << OFF_TB) - 1)];
+					u32 e2 = S->off_tab[(u32)bb & ((1u << otb) - 1)];
 					u32 ol = e2 & 15;
 					u32 dt = SH->dist_tab[(e2 >> 4) & 31];
 					bb >>= ol;
@@ -2066,7 +2115,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				state = ST_DONE;
 				continue;
 			}
-			u32 e = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+			u32 e = S->lit_tab[(u32)bitbuf & ((1u << ltb) - 1)];
 			FLUSH_PENDING();
 			u32 cl = e & 15, kind = e & 0xC000, pay = (e >> 4) & 0x3FF;
 			if (cl == 0) {
@@ -2088,7 +2137,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				/* a second literal in the same round when no end-of-input
 				 * rule can interfere (>= 16 input bytes left) and the
 				 * 41+ bits still buffered hold its whole codeword */
-				u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << LIT_TB) - 1)];
+				u32 e1 = S->lit_tab[(u32)bitbuf & ((1u << ltb) - 1)];
 				if ((e1 & 0xC00F) > K_LIT && (e1 & 0xC000) == K_LIT &&
 				    rpos + 16 < in_n && out_pos + 1 < out_avail) {
 					u16 two = (u16)(pay | (((e1 >> 4) & 0xFF) << 8));
@@ -2117,7 +2166,7 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 				state = ST_DONE;
 				continue;
 			}
-			u32 e2 = S->off_tab[(u32)bitbuf & ((1u << OFF_TB) - 1)];
+			u32 e2 = S->off_tab[(u32)bitbuf & ((1u << otb) - 1)];
 			u32 ol = e2 & 15, osym = e2 >> 4;
 			if (ol == 0)
 				osym = decode_long(&S->off, S->off_sorted, bitbuf, &ol);
@@ -2216,6 +2265,8 @@ inflate_block(u64 blk, lu8 *lds_raw, u32 par, u32 *__restrict__ tok,
 			actual_in[c] = 0;
 	}
 }
+#undef ltb
+#undef otb
 
 /* inflate_stream.hip includes this file for its device functions only */
 #ifndef LDA_INFLATE_DEVICE_ONLY

@@ -61,6 +61,13 @@
 #endif
 #undef PAR_CB
 #define PAR_CB STREAM_PAR_CB
+/* (this file's kernels build a block's tables once per CHUNK of a few KiB: they
+ * keep the 9 / 7-bit tables for every block, and the 4 Ki-entry mirror) */
+#define LIT_TB 9
+#define LIT_TB_MIN 9
+#define OFF_TB 7
+#define OFF_TB_MIN 7
+#define PAR_RW 4096u
 #include "inflate_kernel.hip"
 #include "stream_kernels.h"
 
@@ -142,8 +149,8 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 	}
 	const lu8 *span = stage;
 	struct par_long pll, plo;
-	par_long_init(&pll, &S->lit, LIT_TB + 1);
-	par_long_init(&plo, &S->off, OFF_TB + 1);
+	par_long_init<LIT_TB + 1>(&pll, &S->lit, LIT_TB + 1);
+	par_long_init<OFF_TB + 1>(&plo, &S->off, OFF_TB + 1);
 	u32 cend = bpos0 + (lane + 1) * cb;
 	cend = cend < lim ? cend : lim;
 	u32 start = bpos0 + lane * cb, end = 0;

@@ -427,6 +427,56 @@ def test_codes_of_one_codeword_length(dec, oracle, monkeypatch):
     assert r == (0, len(zb), len(big), big), binding.stream_stats()
 
 
+def test_table_bits_follow_the_block_size(dec, oracle, monkeypatch):
+    """A block's primary tables have 10 / 8 bits when it has 8 KiB of input
+    ahead of it and the block before was not a small one, else 9 / 7
+    (LIT_TB / TB_BIG_BLOCK in csrc/inflate_kernel.hip).  Streams whose blocks
+    alternate between the two - cut by flushes - over bytes and distances with
+    a long-tailed distribution, so that codewords of 10, 11 and more bits (and
+    offset codewords of 8 and 9) occur under both table sizes; both mappings,
+    valid / truncated / short output, against the oracle."""
+    rng = np.random.default_rng(0x7AB1E)
+
+    def skewed(n):
+        # geometric byte values: code lengths from 1 to 15 bits
+        v = np.minimum(rng.geometric(0.08, n) - 1, 255).astype(np.uint8)
+        b = bytearray(v.tobytes())
+        # matches at geometric distances (long offset codewords are the rare ones)
+        for _ in range(n // 40):
+            d = int(min(rng.geometric(0.0008), 30000, n - 40)) + 1
+            at = int(rng.integers(d, n - 20))
+            ln = int(rng.integers(3, 18))
+            b[at:at + ln] = b[at - d:at - d + ln]
+        return bytes(b)
+
+    cases, wants = [], []
+    for k, sizes in enumerate(((60000, 3000, 50000, 40000), (2000, 2000, 70000, 1000, 30000),
+                               (30000,), (9000, 9000, 9000), (100000, 500, 500, 100000))):
+        co = zlib.compressobj(6 if k % 2 else 9, zlib.DEFLATED, -15)
+        z, data = b"", b""
+        for j, n in enumerate(sizes):
+            part = skewed(n)
+            data += part
+            z += co.compress(part) + co.flush(zlib.Z_FULL_FLUSH if j % 2 else zlib.Z_SYNC_FLUSH)
+        z += co.flush()
+        assert zlib.decompress(z, -15) == data
+        wants.append((z, data))
+        cases.append(("deflate", z, len(data), True, f"tb{k}"))
+        cases.append(("deflate", z, len(data), False, f"tb{k}/exact"))
+        cases.append(("deflate", z, len(data) - 3, True, f"tb{k}/short"))
+        cases.append(("deflate", z[:len(z) * 2 // 3], len(data), True, f"tb{k}/cut"))
+        for _ in range(4):
+            bad = bytearray(z)
+            bad[int(rng.integers(10, len(z) - 10))] ^= 1 << int(rng.integers(0, 8))
+            cases.append(("deflate", bytes(bad), len(data), True, f"tb{k}/flip"))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDA_INFLATE_PAR", mode)
+        binding.reload_env()
+        _run_cases(dec, oracle, cases)
+        for z, data in wants:
+            assert dec.decompress_ex("deflate", z, len(data))[3] == data, mode
+
+
 def test_parallel_round_corner_streams(dec, oracle, monkeypatch):
     """Streams aimed at the wave-per-stream rounds (more tokens in a piece
     than a lane records, copies inside a 64-byte slot, sources older than the
