@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "host_objects.h"
@@ -120,6 +121,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		S[slot] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(now - t_last).count();
 		t_last = now;
 	};
+	/* LDA_STREAM_DEBUG: where the host's time goes inside a phase (stderr) */
+	const bool debug = getenv("LDA_STREAM_DEBUG") != nullptr;
+	auto dbg = [&](const char *what) {
+		if (debug)
+			fprintf(stderr, "  %-28s +%lld us\n", what,
+				(long long)std::chrono::duration_cast<std::chrono::microseconds>(
+					std::chrono::steady_clock::now() - t_last).count());
+	};
 	DeviceCtx *ctx = device_ctx();
 	const EnvCfg &env = env_cfg();
 	if (!ctx || env.no_stream_par || in_nbytes < env.stream_par_min) {
@@ -181,9 +190,12 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	auto peek = [&](uint64_t bit, unsigned n) -> uint32_t {	/* n <= 24; zeros past the end */
 		uint32_t v = 0;
 		const uint64_t b0 = bit >> 3;
-		for (unsigned k = 0; k < 4; k++)
-			if (b0 + k < raw_n)
-				v |= (uint32_t)raw[b0 + k] << (8 * k);
+		if (b0 + 4 <= raw_n)
+			memcpy(&v, raw + b0, 4);	/* (little-endian host, as the HIP runtime's) */
+		else
+			for (unsigned k = 0; k < 4; k++)
+				if (b0 + k < raw_n)
+					v |= (uint32_t)raw[b0 + k] << (8 * k);
 		return (v >> (bit & 7)) & ((1u << n) - 1);
 	};
 	/*
@@ -241,6 +253,92 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				return p;
 			}
 		}
+	};
+
+	/*
+	 * Is the dynamic block whose header starts at bit `hb` one whose parses
+	 * do not fall in step - literal codewords of (nearly) ONE length, the
+	 * block a compressor writes over incompressible bytes inside a stream of
+	 * other data?  The host reads the header itself (the precode and the
+	 * literal lengths, lib/deflate_decompress.c:1227-1359 restated for the
+	 * first 256 symbols; a few hundred bits): returns the longest literal
+	 * codeword when the literals of one length fill 98 % of the code
+	 * space, 0 otherwise (or when the header is not a
+	 * valid dynamic one: the kernels say what is wrong with it).  Only the
+	 * plan depends on the answer, never the result.
+	 */
+	auto one_length_code = [&](uint64_t hb) -> uint32_t {
+		static const uint8_t perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+		uint64_t p = hb;
+		if (p + 17 + 19 * 3 > raw_bits || ((peek(p, 3) >> 1) & 3) != 2)
+			return 0;
+		const uint32_t nl = 257 + peek(p + 3, 5), nc = 4 + peek(p + 13, 4);
+		p += 17;
+		uint8_t pl[19] = { 0 };
+		for (uint32_t i = 0; i < nc; i++, p += 3)
+			pl[perm[i]] = (uint8_t)peek(p, 3);
+		uint32_t cnt[8] = { 0 }, first[8] = { 0 }, base[8] = { 0 };
+		uint8_t sorted[19];
+		uint32_t ns = 0;
+		for (uint32_t len = 1; len < 8; len++)
+			for (uint32_t sy = 0; sy < 19; sy++)
+				if (pl[sy] == len) {
+					sorted[ns++] = (uint8_t)sy;
+					cnt[len]++;
+				}
+		for (uint32_t len = 1, code = 0; len < 8; len++) {
+			code = (code + cnt[len - 1]) << 1;
+			first[len] = code;
+			base[len] = len > 1 ? base[len - 1] + cnt[len - 1] : 0;
+		}
+		uint8_t lens[256 + 138];
+		uint32_t n = 0;
+		const uint32_t want = nl < 256 ? nl : 256;
+		while (n < want) {
+			if (p + 32 > raw_bits)
+				return 0;
+			uint32_t c = 0, sy = 99;
+			for (uint32_t len = 1; len < 8; len++) {
+				c = (c << 1) | peek(p++, 1);
+				if (c - first[len] < cnt[len]) {
+					sy = sorted[base[len] + c - first[len]];
+					break;
+				}
+			}
+			if (sy < 16) {
+				lens[n++] = (uint8_t)sy;
+			} else if (sy == 16) {
+				if (!n)
+					return 0;
+				const uint32_t r = 3 + peek(p, 2);
+				p += 2;
+				for (uint32_t k = 0; k < r; k++, n++)
+					lens[n] = lens[n - 1];
+			} else if (sy == 17 || sy == 18) {
+				const uint32_t r = sy == 17 ? 3 + peek(p, 3) : 11 + peek(p, 7);
+				p += sy == 17 ? 3 : 7;
+				for (uint32_t k = 0; k < r; k++)
+					lens[n++] = 0;
+			} else {
+				return 0;
+			}
+		}
+		uint32_t hist[16] = { 0 }, hi = 0, top = 1;
+		for (uint32_t sy = 0; sy < want; sy++)
+			hist[lens[sy]]++;
+		for (uint32_t len = 1; len < 16; len++) {
+			if (hist[len])
+				hi = len;
+			if (hist[len] > hist[top])
+				top = len;
+		}
+		/* 98 % of the code space at one length.  (Two parses that are d bits
+		 * apart drift by a bit where one of them meets a codeword of another
+		 * length: with a share p of those they meet after ~10 / 2p tokens -
+		 * at 5 % well inside the 1 KiB warm-up, which then costs a ninth of
+		 * what the exact starts cost; at 0.5 % - 256 literals of 8 bits and
+		 * what a compressor squeezes in beside them - in a thousand.) */
+		return hist[top] >= 32 && hi <= 11 && 50 * hist[top] >= 49 * (1u << top) ? hi : 0;
 	};
 
 	/*
@@ -392,6 +490,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 2048), 65536);
 		const uint64_t OV = 8192, HDRSAFE = 4608;
 		std::vector<planned> plan;
+		uint32_t nexact = 0;	/* chunks planned at exact starts (blocks of one codeword length) */
 		/* a block (or, for the carried-in state, what is left of one): its
 		 * first chunk, then inner chunks up to `next` */
 		/* (`inner`: the block's tables are known without looking - from its
@@ -406,6 +505,34 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			if (!inner)
 				return;
 			const uint64_t start = first.start_bit;
+			/* a block of one codeword length (one_length_code()): no warm-up
+			 * falls in step there, and a count pass that walks on such a
+			 * block is slow (ten parses per piece, par_phase_starts()).  Its
+			 * inner chunks are small - 2 KiB of input - and start EXACTLY,
+			 * at every bit a literal that overhangs the planned start can
+			 * end at: P, P + 1, .. P + longest literal codeword.  One of them
+			 * is the true parse; the chain finds it by its key, in the first
+			 * count pass.  (A match across P is not covered: a repair.) */
+			const uint32_t hi = first.kind == LDA_CHUNK_HEADER && !env.stream_chunk ?
+						    one_length_code(first.hdr_bit) : 0;
+			/* (the starts of one position are counted together by ONE wave,
+			 * phase_count() of inflate_stream.hip, when the chunk is one
+			 * round of input: 1.5 x TN <= 64 pieces of 384 bits) */
+			const uint64_t TN = 15360;
+			if (hi && nexact + (next - start) / TN * (hi + 1) <= 65536) {
+				for (uint64_t P = start + TN; P + TN / 2 <= next; P += TN)
+					for (uint32_t j = 0; j <= hi; j++) {
+						planned q = {};
+						q.c.kind = LDA_CHUNK_EXACT;
+						q.c.hdr_bit = under;
+						q.c.start_bit = q.c.target_bit = P + j;
+						q.c.phases = j ? ~0u : hi + 1;
+						q.at = P;
+						plan.push_back(q);
+						nexact++;
+					}
+				return;
+			}
 			const uint64_t safe = first.kind == LDA_CHUNK_HEADER ? start + HDRSAFE : start;
 			for (uint64_t P = start + T; P + T / 2 <= next; P += T) {
 				uint64_t ws = P > OV ? P - OV : 0;
@@ -458,10 +585,16 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				last_at = cs[i];
 			}
 		}
-		for (size_t i = 0; i < plan.size(); i++)
-			plan[i].c.limit_bit = i + 1 < plan.size() ? plan[i + 1].at : R1;
+		/* (a chunk ends at the next planned start: the starts of one planned
+		 * position - see add_block() - share theirs) */
+		for (size_t i = plan.size(), nxt_at = R1; i-- > 0;) {
+			if (i + 1 < plan.size() && plan[i + 1].at != plan[i].at)
+				nxt_at = plan[i + 1].at;
+			plan[i].c.limit_bit = nxt_at;
+		}
 		const uint32_t np = (uint32_t)plan.size();
 		S[4] += np;
+		dbg("planned");
 
 		/* ---- count ---- */
 		const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
@@ -481,7 +614,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n))
 			return false;
 		ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
+		dbg("count queued");
 		ST_TRY(pin_sync());
+		dbg("counted");
 
 		/* ---- chain ----
 		 * Every counted chunk is a pool entry keyed by its exact start state.
@@ -494,7 +629,17 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		 * the longest run of consecutive breaks, not the number of breaks. */
 		{
 			typedef std::pair<uint64_t, uint64_t> key_t;	/* (start_bit * 2 + boundary, header) */
-			std::map<key_t, uint32_t> by_start;
+			/* (hashed: a window of blocks of one codeword length has ten
+			 * thousand entries, and an ordered map's inserts were a third of
+			 * its count phase) */
+			struct key_hash {
+				size_t operator()(const key_t &k) const {
+					uint64_t h = k.first * 0x9E3779B97F4A7C15ull ^ (k.second + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+					return (size_t)(h ^ (h >> 29));
+				}
+			};
+			std::unordered_map<key_t, uint32_t, key_hash> by_start;
+			by_start.reserve(2 * (size_t)np + 1024);
 			std::vector<lda_stream_chunk> pc(hc);
 			std::vector<lda_stream_res> pr(hr);
 			auto start_key = [&](uint32_t i) -> key_t {
@@ -512,6 +657,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			std::vector<uint64_t> ats(np);
 			for (uint32_t i = 0; i < np; i++)
 				ats[i] = plan[i].at;
+			dbg("pool built");
 			std::vector<uint32_t> path;
 			/* how many repairs in a row led to an entry (0: planned): a
 			 * repair behind a repair reaches twice as far as the one before
@@ -519,6 +665,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			 * length) is walked in a few long strides, not chunk by chunk */
 			std::vector<uint8_t> depth(np, 0);
 			uint32_t repairs = 0, first_open = 0;
+			/* phase candidates (see the repairs): planned starts that have theirs,
+			 * and how many there are (they do not count as repairs for the limit) */
+			const uint32_t PHASES = 10;
+			std::vector<uint8_t> phased(np + 1, 0);
+			uint32_t ncand = 0;
 			const uint32_t max_repairs = 64 + 2 * np;
 			const uint64_t sgroup = 8 * (uint64_t)(env.stream_chunk ? env.stream_chunk : 16384);
 			bool closed = false;	/* the walk ended: final block, or the window's end */
@@ -593,8 +744,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				}
 				if (closed)
 					break;
-				if (getenv("LDA_STREAM_DEBUG")) {
+				if (debug) {
 					const uint32_t e = path.back();
+					dbg("walked");
 					fprintf(stderr, "round %d: walk of %zu stops after chunk %u (kind %u hdr %llu start %llu) "
 						"end %llu bnd %u endhdr %llu status %u nout %llu\n", round, path.size(), e,
 						pc[e].kind, (unsigned long long)pc[e].hdr_bit,
@@ -607,7 +759,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				std::vector<lda_stream_chunk> rc;
 				std::vector<uint8_t> rdepth;
 				const uint32_t npool = (uint32_t)pc.size();
-				std::map<key_t, int> asked;
+				std::unordered_map<key_t, int, key_hash> asked;
 				for (uint32_t i = first_open; i < npool; i++) {
 					if (pr[i].status != LDA_STREAM_OK || pr[i].end_bit >= R1)
 						continue;
@@ -625,10 +777,55 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					const uint32_t dp = std::min<uint32_t>((uint32_t)depth[i] + 1, 12);
 					size_t nx = (size_t)(std::upper_bound(ats.begin(), ats.end(), pr[i].end_bit) -
 							     ats.begin());
+					const size_t nx0 = nx;	/* the next planned start behind this end */
 					nx += ((size_t)1 << (dp - 1)) - 1;
 					c.limit_bit = nx >= ats.size() ? R1 : ats[nx];
 					rc.push_back(c);
 					rdepth.push_back((uint8_t)dp);
+					/* PHASE CANDIDATES.  The planned chunk q that should have
+					 * gone on from this end did not (its warm-up ended on
+					 * another token boundary) - and its own end is open too
+					 * or it failed (a parse out of step meets an end-of-block
+					 * codeword sooner or later and reads a header that is
+					 * none): a code whose parses do not fall in step
+					 * (codewords of nearly one length: a dynamic block over
+					 * incompressible bytes).  Repairs alone would walk
+					 * such a block one stride per round trip.  But the end of
+					 * whatever comes to the next planned start P from the
+					 * true parse is the first token boundary at or behind P:
+					 * a literal's codeword is at most a dozen bits, so one of
+					 * the chunks that start EXACTLY at P, P + 1, .. P + K - 1
+					 * is the true parse, and the chain finds it by its key.
+					 * Every open end of the block asks for the K starts at
+					 * its own next planned start, in this same round. */
+					const size_t nq = nx0 ? nx0 - 1 : 0;
+					if (!bnd && i < np && nx0 >= 1 && nx0 < np && nq != i && nq < np &&
+					    plan[nq].c.kind == LDA_CHUNK_WARM &&
+					    plan[nq].c.hdr_bit == pr[i].end_hdr_bit &&
+					    (pr[nq].status != LDA_STREAM_OK ||
+					     !by_start.count(end_key((uint32_t)nq))) &&
+					    plan[nx0].c.kind == LDA_CHUNK_WARM &&
+					    plan[nx0].c.hdr_bit == pr[i].end_hdr_bit && !phased[nx0] &&
+					    ncand + PHASES <= 4096) {
+						phased[nx0] = 1;
+						const uint64_t lim2 = nx0 + 1 < np ? ats[nx0 + 1] : R1;
+						/* (one wave for all of them when they are one round
+						 * of input: phase_count() of inflate_stream.hip) */
+						const bool together = pr[i].end_hdr_bit != LDA_HDR_STATIC &&
+								      lim2 > ats[nx0] + PHASES &&
+								      lim2 - ats[nx0] <= 24000;
+						for (uint32_t j = 0; j < PHASES && ats[nx0] + j < lim2; j++) {
+							lda_stream_chunk k2 = {};
+							k2.kind = LDA_CHUNK_EXACT;
+							k2.hdr_bit = pr[i].end_hdr_bit;
+							k2.start_bit = k2.target_bit = ats[nx0] + j;
+							k2.limit_bit = lim2;
+							k2.phases = !together ? 0 : j ? ~0u : PHASES;
+							rc.push_back(k2);
+							rdepth.push_back(0);
+							ncand++;
+						}
+					}
 				}
 				/* the open end of the walk is always among them (round 0 looks at
 				 * all entries; later rounds at the new ones, and the walk can only
@@ -636,7 +833,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				first_open = npool;
 				repairs += (uint32_t)rc.size();
 				S[5] += (uint32_t)rc.size();
-				if (rc.empty() || repairs > max_repairs) {
+				if (rc.empty() || repairs > max_repairs + ncand) {
 					S[1] = rc.empty() ? WHY_CHAIN : WHY_REPAIRS;
 					return false;
 				}
@@ -654,7 +851,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n))
 					return false;
 				ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
+				dbg("repairs queued");
 				ST_TRY(pin_sync());
+				dbg("repairs counted");
 				for (uint32_t i = 0; i < nr; i++) {
 					pc.push_back(rc[i]);
 					pr.push_back(rr[i]);
@@ -668,6 +867,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			}
 			for (uint32_t i : path) {
 				lda_stream_chunk c = pc[i];
+				c.phases = 0;
 				if (c.kind == LDA_CHUNK_WARM) {
 					c.kind = LDA_CHUNK_EXACT;
 					c.start_bit = pr[i].start_bit;
@@ -754,7 +954,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		}
 		/* [2]: the error flag of the window / resolve kernels */
 		ST_TRY(hipMemsetAsync(d_cnt, 0, 16, s_comp));
-		const size_t BATCH = 2048;	/* decode waves per launch (their token scratch) */
+		const size_t BATCH = 4096;	/* decode waves per launch (their token scratch: 48 KiB each) */
 		uint16_t *d_sym = (uint16_t *)d->ssym.reserve((size_t)total * 2 + 64);
 		uint8_t *d_out = (uint8_t *)d->sout.reserve((size_t)total + 64);
 		uint32_t *d_tok = (uint32_t *)d->tokens.reserve(
@@ -855,6 +1055,10 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		if (npc)
 			ST_TRY(back(sums.data(), d_sums, npc * 4));
 		lap(11);
+		if (debug) {
+			ST_TRY(hipEventSynchronize(d->streams.mark));
+			dbg("decode .. resolve kernels");
+		}
 		/* the output, beside the checksum kernels and the read-backs */
 		ST_TRY(hipStreamWaitEvent(s_copy, d->streams.mark, 0));
 		if (span_out(&d->pinned, d_out, 0, out, (size_t)total, s_copy) != LIBDEFLATE_AMD_OK)

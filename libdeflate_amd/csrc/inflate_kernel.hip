@@ -651,7 +651,8 @@ struct par_bits {
 #define PAR_SPAN (64u * PAR_CB / 8 + 80)
 /* the staged span shares its LDS with the copy phase's scratch (a group's
  * tokens and its byte -> token map): whichever is larger */
-#define PAR_COPY_BYTES (256u * 4 + 2 * PAR_GBYTES)
+#define PAR_MAP_CLEAR 2176u	/* bytes of the byte -> token map: what three 16-byte stores per lane clear */
+#define PAR_COPY_BYTES (256u * 4 + PAR_MAP_CLEAR)
 #define PAR_STAGE_BYTES (PAR_SPAN > PAR_COPY_BYTES ? (PAR_SPAN + 15u) & ~15u : PAR_COPY_BYTES)
 
 static __device__ __forceinline__ u64 pb_load(const lu8 *inp, u32 nb)
@@ -815,7 +816,9 @@ par_decode(const slds_t *S, const shlds_t *SH,
 #ifndef PAR_RW
 #define PAR_RW 2048u
 #endif
-#define PAR_GBYTES 1088u	/* output bytes resolved per group (>= 4 x 258) */
+#ifndef PAR_GBYTES
+#define PAR_GBYTES 1088u	/* output bytes resolved per group (>= 4 x 258; the mirror holds the group and 256 more) */
+#endif
 
 static __device__ __forceinline__ u64 shfl_up64(u64 v)
 {
@@ -1240,7 +1243,9 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 	 * per group (flush_ring). */
 	{
 		lu32 *tk = (lu32 *)stage;			/* [256] the group's tokens */
-		lu16 *R = (lu16 *)((lu32 *)stage + 256);	/* [PAR_GBYTES] byte -> source byte */
+		/* (a group's tokens are numbered 0 .. 255 and its first byte starts
+		 * token 0, so a cleared entry and "token 0" say the same) */
+		lu8 *R = (lu8 *)((lu32 *)stage + 256);		/* [PAR_GBYTES] byte -> token of the group */
 		gu8 *gout = (gu8 *)outp;
 		u64 gbase = out0;
 		u64 flushed = out0;	/* output below this is in memory */
@@ -1275,7 +1280,9 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 			 * - 2 x 1024 + 128 bytes - instead of a loop of 2-byte stores
 			 * over the group's bytes: 12 rounds of 8 instructions) */
 			{
-				static_assert(2 * PAR_GBYTES == 2176, "two full wave stores and one of eight lanes");
+				static_assert(PAR_GBYTES <= PAR_MAP_CLEAR && PAR_MAP_CLEAR == 2176 &&
+					      PAR_GBYTES + 256 <= PAR_RW && PAR_GBYTES >= 4 * 258,
+					      "two full wave stores and one of eight lanes");
 				const uint4 z = make_uint4(0, 0, 0, 0);
 				AS3 uint4 *R16 = (AS3 uint4 *)R;
 				R16[lane] = z;
@@ -1290,7 +1297,7 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 #pragma unroll
 				for (u32 j = 0; j < 4; j++) {
 					if (len4[j])
-						R[o] = (u16)(4 * lane + j + 1);
+						R[o] = (u8)(4 * lane + j);
 					o += len4[j];
 				}
 			}
@@ -1364,10 +1371,10 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 				}
 #pragma unroll
 				for (u32 k = 0; k < SB; k++) {
-					/* (own >= 1 everywhere: the group's first byte starts its
-					 * first token and the running maximum carries on) */
+					/* (the group's first byte starts token 0 and the running
+					 * maximum carries on) */
 					const u32 bi = s0 + 64 * k + lane;
-					const u32 w = tk[own[k] - 1];	/* token word */
+					const u32 w = tk[own[k]];	/* token word */
 					own[k] = bi < gtot ? w : 0;
 				}
 				/* bytes whose source is older than the mirror.  The tests are

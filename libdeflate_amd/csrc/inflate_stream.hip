@@ -158,6 +158,7 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 	bool eob = false, dirty = lane < NL;
 	u32 K = NL - 1;
 	bool has_eob = false;
+	u32 nphase = 0;
 
 	for (u32 pass = 0; pass < 64; pass++) {
 		struct par_bits b;
@@ -216,15 +217,26 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 		}
 		if (!dm)
 			break;
-		if (pass == 1 && (u32)__builtin_popcountll(dm) >= PAR_PHASE_MIN) {
+		if (pass >= 1 && nphase < 6 && (u32)__builtin_popcountll(dm) >= PAR_PHASE_MIN) {
 			/* the passes are not converging (a code of nearly one codeword
-			 * length): par_phase_starts() of inflate_kernel.hip */
+			 * length): par_phase_starts() of inflate_kernel.hip.  Here it
+			 * runs again where its chain broke (a match across a piece's
+			 * start: the lane behind it starts beyond the phases) once
+			 * that lane's start lies within them - a chunk is as slow as
+			 * its slowest round, and a block over incompressible bytes
+			 * has a match every few hundred literals: one pass per lane
+			 * behind the first of them made such a chunk three times as
+			 * slow as its neighbours. */
 			const u32 f = (u32)__builtin_ctzll(dm);
-			const u32 g = par_phase_starts(S, SH, &pll, &plo, span, bpos0, cb, cend, lane,
-						       NL, f, bcast_lane(ns, f), ns);
-			if (lane > f && lane < NL) {
-				ns = g;
-				dirty = ns != start;
+			const u32 sf = bcast_lane(ns, f);
+			if (sf - (bpos0 + f * cb) < PAR_PHASES) {
+				const u32 g = par_phase_starts(S, SH, &pll, &plo, span, bpos0, cb, cend,
+							       lane, NL, f, sf, ns);
+				nphase++;
+				if (lane > f && lane < NL) {
+					ns = g;
+					dirty = ns != start;
+				}
 			}
 		}
 		start = ns;
@@ -831,14 +843,228 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	}
 }
 
+/*
+ * K EXACT chunks that start at consecutive bits P, P + 1, .. P + K - 1 of one
+ * block and end at the same limit, counted TOGETHER by one wave (the host
+ * plans them where no parse falls in step: a block of one codeword length,
+ * host_stream.hip).  The true parse crosses P at one of those bits; as K
+ * separate chunks every one would parse the same input, ten times over.  Here
+ * every lane parses its piece of the input once from each of its first K bits
+ * (as par_phase_starts() does for a round that does not converge) and keeps
+ * where the parse leaves the piece and how many bytes it makes; then lane j
+ * follows the chain "my end is the next piece's start" from bit j of piece 0
+ * through the pieces, which is chunk j's answer: K answers for K parses per
+ * piece instead of K x (K + 3).  A chain that enters a piece behind its first
+ * K bits (a match across the piece's start) has the rest of that piece parsed
+ * for it.  A chain that meets an end of block in front of the limit reports
+ * LDA_STREAM_ERR: the host's chain treats that start as not counted and
+ * asks for it on its own if it ever arrives there.  What is
+ * reported as counted is exactly what chunk_run() would report - the decode
+ * pass runs chunk_run() on every accepted chunk and the host compares.
+ * false: not taken (a static block, more than one round of input, the last
+ * bytes of the stream): the caller counts the K chunks one after the other.
+ */
+#define PHASE_MAX 12u
+static __device__ bool
+phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_res *__restrict__ rs,
+	    u32 K, const u8 *__restrict__ inp, u64 in_n)
+{
+	const u32 lane = threadIdx.x;
+	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
+	shlds_t *SH = (shlds_t *)(S + 1);
+	lu8 *scr = (lu8 *)(SH + 1);		/* the mirror's LDS: nothing is executed here */
+	lu8 *stage = scr + 2 * PAR_RW;
+	lu32 *nb = (lu32 *)scr;			/* [PHASE_MAX][64] bytes a piece makes from a start */
+	lu32 *endpos = nb + PHASE_MAX * 64;	/* [PHASE_MAX][64] where a chain ends (bit 31: at an end of block) */
+	lu8 *code = (lu8 *)(endpos + PHASE_MAX * 64);	/* [PHASE_MAX][64] 0 goes on at endpos, 62 ends there, 63 fails */
+	static_assert(PHASE_MAX * 64 * 9 <= 2 * PAR_RW, "the tables fit the mirror");
+	const u64 hdr = cd->hdr_bit, P = cd->start_bit, limit = cd->limit_bit;
+	const u64 byte0 = P >> 3;
+	const u32 bpos0 = (u32)P & 7, cb = PAR_CB;
+	if (K < 1 || K > PHASE_MAX || hdr == LDA_HDR_STATIC || limit <= P + K ||
+	    limit - 8 * byte0 > 64 * cb - 64 || in_n < byte0 + 64 * (PAR_CB / 8))
+		return false;
+	u32 final_blk = 0;
+	u64 p2;
+	bool gov_static = false;
+	if (chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static) != 0 || P < p2)
+		return false;
+	const u32 lim = (u32)(limit - 8 * byte0);
+	const u32 NL = (lim - bpos0 + cb - 1) / cb;	/* 1 .. 64 */
+	stage_input(stage, inp, in_n, byte0, PAR_SPAN & ~7u, lane);
+	struct par_long pll, plo;
+	par_long_init<LIT_TB + 1>(&pll, &S->lit, LIT_TB + 1);
+	par_long_init<OFF_TB + 1>(&plo, &S->off, OFF_TB + 1);
+	const u32 ps = bpos0 + lane * cb, pe = ps + cb;
+	const u32 cend = pe < lim ? pe : lim;	/* the last piece ends at the limit */
+	const bool mine = lane < NL;
+	for (u32 ph = 0; ph < K; ph++) {
+		struct par_bits b;
+		u32 nbytes = 0;
+		bool eob = false;
+		pb_init(&b, stage, ps + ph);
+		bool run = mine && PB_POS(b) < cend;
+		while (__ballot(run)) {
+			pb_refill(&b, stage);
+			const struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
+			const u32 e1 = t.e1;
+			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < cend &&
+					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+			if (run) {
+				u32 used = t.used;
+				if (t.kind == K_EOB) {
+					eob = true;
+					run = false;
+				} else {
+					nbytes += t.kind == K_LEN ? t.length : 1;
+					if (two) {
+						nbytes++;
+						used += e1 & 15;
+					}
+				}
+				b.buf >>= used;
+				b.cnt -= used;
+			}
+			run = run && PB_POS(b) < cend;
+		}
+		const u32 pos = PB_POS(b);
+		u32 c = 0;	/* the chain goes on at `pos` */
+		if (eob) {
+			/* the chunk ends with its block when that is the stream's last or
+			 * ends at or behind the limit; else it would go on into the next */
+			c = final_blk || pos >= lim ? 62 : 63;
+		} else if (lane == NL - 1) {
+			c = 62;
+		}
+		if (mine) {
+			nb[ph * 64 + lane] = nbytes;
+			endpos[ph * 64 + lane] = pos | (eob ? 0x80000000u : 0);
+			code[ph * 64 + lane] = (u8)c;
+		}
+	}
+	wave_sync();
+	/* lane j follows chunk j's parse through the table; where it enters a
+	 * piece behind its first K bits (a match across the piece's start) the
+	 * rest of that piece is parsed for it - all lanes that are in that
+	 * position at once, so the passes are as many as the longest run of such
+	 * entries on one chain */
+	bool active = lane < K;
+	u32 pos = bpos0 + lane, st = LDA_STREAM_ERR, endv = 0;
+	u64 total = 0;
+	for (u32 guard = 0; guard < 64 && __ballot(active); guard++) {
+		bool need = false, last = false;
+		u32 pcend = 0;
+		if (active) {
+			for (;;) {
+				const u32 i = (pos - bpos0) / cb, o = pos - bpos0 - i * cb;
+				if (i >= NL) {
+					active = false;
+					break;
+				}
+				if (o >= K) {
+					need = true;
+					last = i == NL - 1;
+					pcend = bpos0 + (i + 1) * cb;
+					pcend = pcend < lim ? pcend : lim;
+					break;
+				}
+				const u32 c = code[o * 64 + i], e = endpos[o * 64 + i];
+				total += nb[o * 64 + i];
+				if (c == 62) {
+					endv = e;
+					st = LDA_STREAM_OK;
+				}
+				if (c >= 62) {
+					active = false;
+					break;
+				}
+				pos = e;
+			}
+		}
+		if (!__ballot(need))
+			break;
+		struct par_bits b;
+		u32 nbytes = 0;
+		bool eob = false;
+		pb_init(&b, stage, need ? pos : 0);
+		bool run = need && PB_POS(b) < pcend;
+		while (__ballot(run)) {
+			pb_refill(&b, stage);
+			const struct par_token t = par_decode(S, SH, &pll, &plo, b.buf, run);
+			const u32 e1 = t.e1;
+			const bool two = t.kind == K_LIT && PB_POS(b) + t.used < pcend &&
+					 (e1 & 0xC000) == K_LIT && (e1 & 15) != 0;
+			if (run) {
+				u32 used = t.used;
+				if (t.kind == K_EOB) {
+					eob = true;
+					run = false;
+				} else {
+					nbytes += t.kind == K_LEN ? t.length : 1;
+					if (two) {
+						nbytes++;
+						used += e1 & 15;
+					}
+				}
+				b.buf >>= used;
+				b.cnt -= used;
+			}
+			run = run && PB_POS(b) < pcend;
+		}
+		if (need) {
+			const u32 np = PB_POS(b);
+			total += nbytes;
+			if (eob ? final_blk || np >= lim : last) {
+				endv = np | (eob ? 0x80000000u : 0);
+				st = LDA_STREAM_OK;
+				active = false;
+			} else if (eob) {
+				active = false;
+			} else {
+				pos = np;
+			}
+		}
+	}
+	if (lane < K) {
+		const bool eobt = endv >> 31;
+		const u64 end_bit = 8 * byte0 + (endv & 0x7FFFFFFFu);
+		if (st == LDA_STREAM_OK && end_bit > 8 * in_n)
+			st = LDA_STREAM_ERR;
+		struct lda_stream_res *r = rs + lane;
+		r->start_bit = P + lane;
+		r->end_bit = st == LDA_STREAM_OK ? end_bit : P + lane;
+		r->end_hdr_bit = st != LDA_STREAM_OK ? hdr : eobt ? end_bit : hdr;
+		r->nout = st == LDA_STREAM_OK ? total : 0;
+		r->status = st != LDA_STREAM_OK ? LDA_STREAM_ERR :
+			    eobt && final_blk ? LDA_STREAM_FINAL : LDA_STREAM_OK;
+		r->flags = st != LDA_STREAM_OK ? 0 :
+			   (eobt ? LDA_RES_BOUNDARY : 0) | (!eobt && final_blk ? LDA_RES_GOV_FINAL : 0);
+	}
+	return true;
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 			struct lda_stream_res *res, const u8 *inp, u64 in_n,
 			u32 *tokscratch)
 {
-	if (blockIdx.x < nchunks)
-		chunk_run<SM_COUNT>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, NULL,
-				    tokscratch);	/* (keeps no tokens) */
+	if (blockIdx.x >= nchunks)
+		return;
+	/* `phases`: 0 a chunk of its own; K the first of K exact starts counted
+	 * together (phase_count()); ~0 one of the K - 1 behind it */
+	const u32 K = chunks[blockIdx.x].phases;
+	if (K == ~0u)
+		return;
+	if (K != 0 && K <= nchunks - blockIdx.x) {
+		if (phase_count(chunks + blockIdx.x, res + blockIdx.x, K, inp, in_n))
+			return;
+		for (u32 j = 0; j < K; j++)
+			chunk_run<SM_COUNT>(chunks + blockIdx.x + j, res + blockIdx.x + j, inp, in_n,
+					    NULL, tokscratch);
+		return;
+	}
+	chunk_run<SM_COUNT>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, NULL,
+			    tokscratch);	/* (keeps no tokens) */
 }
 
 extern "C" __global__ void __launch_bounds__(64)

@@ -33,7 +33,8 @@ struct lda_stream_chunk {
 	uint64_t limit_bit;
 	uint64_t out_off;	/* decode pass: absolute output position of the chunk's first byte */
 	uint32_t kind;
-	uint32_t pad;
+	uint32_t phases;	/* count pass: 0, or K on the first of K EXACT chunks at consecutive
+				 * bits with one limit that are counted together, ~0 on the others */
 };
 
 #define LDA_STREAM_OK 0u	/* stopped at the limit */

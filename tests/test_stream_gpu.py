@@ -190,6 +190,61 @@ def test_streams_the_finder_cannot_enter(dec, oracle):
     assert r == (0, len(z), len(zeros), zeros)
 
 
+def test_blocks_of_one_codeword_length(dec, comp, oracle):
+    """Dynamic blocks over incompressible bytes - literal codewords of (nearly)
+    one length - inside a large stream: a parse started at a wrong bit never
+    falls in step there, so warm-ups fail.  The host reads such a block's
+    header itself and plans its inner chunks at EXACT starts, one per bit a
+    literal across the planned position can end at (host_stream.hip,
+    one_length_code()); the chain picks the true one.  Round 6: the blocks of
+    one length between text, alone, with matches across the planned starts, and
+    damaged - bytes and codes are the oracle's, and the chain closes in few
+    rounds (repairs stay far below one per chunk)."""
+    rng = np.random.default_rng(0x1E6)
+    txt = datagen.text_chunk(3 << 20, 41)
+    parts = []
+    for i in range(12):
+        parts.append(txt[i * 200000:(i + 1) * 200000])
+        parts.append(rng.integers(0, 256, 70000, dtype=np.uint8).tobytes())
+    mixed = b"".join(parts)
+    z = comp("gzip", 6, mixed)
+    r = dec.decompress_ex("gzip", z, len(mixed))
+    st = binding.stream_stats()
+    print("text and incompressible bytes:", st)
+    assert r == (0, len(z), len(mixed), mixed), (r[:3], st)
+    assert st["parallel"] == 1, st
+    # Huffman-only blocks over bytes of 256 / 250 / 64 values (8 bits; 7 and 8; 6)
+    for nv in (256, 250, 64):
+        raw = rng.integers(0, nv, 3 << 20, dtype=np.uint8).tobytes()
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        h = co.compress(raw) + co.flush()
+        r = dec.decompress_ex("deflate", h, len(raw))
+        st = binding.stream_stats()
+        print(f"Huffman-only, {nv} values:", st)
+        assert r == (0, len(h), len(raw), raw), (nv, r[:3], st)
+        assert st["parallel"] == 1, st
+        assert st["repairs"] <= st["chunks_decoded"], st
+        # a damaged byte in the middle: whatever the oracle says
+        bad = h[:len(h) // 2] + bytes([h[len(h) // 2] ^ 0x10]) + h[len(h) // 2 + 1:]
+        got = dec.decompress_ex("deflate", bad, len(raw))
+        exp = oracle.decompress_ex("deflate", bad, len(raw))
+        assert got[0] == exp[0], (nv, got[:3], exp[:3], binding.stream_stats())
+        if exp[0] == 0:
+            assert got[1:] == exp[1:]
+    # incompressible bytes with a repeated stretch now and then: matches (long
+    # tokens) across planned starts, which no exact start covers - repairs
+    blocks = []
+    for i in range(40):
+        b = rng.integers(0, 256, 60000, dtype=np.uint8).tobytes()
+        blocks.append(b + b[1000:1000 + 300] * 3)
+    rep = b"".join(blocks)
+    z = comp("zlib", 6, rep)
+    r = dec.decompress_ex("zlib", z, len(rep))
+    st = binding.stream_stats()
+    print("incompressible with repeats:", st)
+    assert r == (0, len(z), len(rep), rep), (r[:3], st)
+
+
 def test_small_chunks_everything_through_the_stream_path(dec, oracle, comp, monkeypatch):
     """Every stream, however small, through the many-wave path with 4 KiB
     chunks: the chunk kernels' edge cases (a stream shorter than a round, the

@@ -24,7 +24,10 @@ def main():
         if a.startswith("--kind="):
             kind = "kind" + a.split("=")[1]
     # --stored: level 0 (stored blocks only); --fixed: zlib Z_FIXED (static blocks only)
-    shape = "stored" if "--stored" in sys.argv else "fixed" if "--fixed" in sys.argv else "dynamic"
+    # --huff: zlib Z_HUFFMAN_ONLY over bytes drawn evenly from 250 values (dynamic blocks of
+    # literals under a code of nearly one codeword length: parses never fall in step)
+    shape = ("stored" if "--stored" in sys.argv else "fixed" if "--fixed" in sys.argv else
+             "huff" if "--huff" in sys.argv else "dynamic")
     level = 6
     ref = oracle_util.load_ref()
     d = api.Decompressor()
@@ -38,7 +41,13 @@ def main():
             data = b"".join(datagen.chunk(k + 8 * i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
         else:
             data = b"".join(datagen.chunk(i, 65536, 0x0E110200) for i in range((n + 65535) >> 16))[:n]
-        if shape == "stored":
+        if shape == "huff":
+            import zlib
+            nv = int(os.environ.get("HUFF_VALUES", "250"))
+            data = np.random.default_rng(0x0E11).integers(0, nv, n, dtype=np.uint8).tobytes()
+            co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_HUFFMAN_ONLY)
+            z = co.compress(data) + co.flush()
+        elif shape == "stored":
             z = streams._zcompress("gzip", 0, data)
         elif shape == "fixed":
             import zlib

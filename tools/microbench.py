@@ -113,12 +113,17 @@ def bench_inflate(a, fmt="gzip", level=6):
         # in step, the case of par_phase_starts()
         import zlib
         wb = {"deflate": -15, "zlib": 15, "gzip": 31}[fmt]
-        chunks = [np.random.default_rng(7000 + i).integers(0, a.kind - 100, a.size, dtype=np.uint8).tobytes()
+        # kind >= 1000: the same bytes from (kind - 1000) values through zlib's default strategy
+        # (a match now and then among the literals: what a compressor writes over
+        # incompressible bytes when it does not store them)
+        nv = a.kind - 1000 if a.kind >= 1000 else a.kind - 100
+        chunks = [np.random.default_rng(7000 + i).integers(0, nv, a.size, dtype=np.uint8).tobytes()
                   for i in range(distinct)]
         chunks = [chunks[i % distinct] for i in range(a.chunks)]
         comp = []
         for c in chunks[:distinct]:
-            co = zlib.compressobj(6, zlib.DEFLATED, wb, 9, zlib.Z_HUFFMAN_ONLY)
+            co = zlib.compressobj(6, zlib.DEFLATED, wb, 9,
+                                  zlib.Z_DEFAULT_STRATEGY if a.kind >= 1000 else zlib.Z_HUFFMAN_ONLY)
             comp.append(co.compress(c) + co.flush())
     offs, blob, sizes = [], bytearray(), []
     for i in range(a.chunks):
