@@ -632,6 +632,12 @@ ring_fill(lu8 *ring, const u8 *inp, u64 in_n, u64 at)
 #define PAR_CB 384u		/* input bits per lane and round: the span of 64 lanes must fit PAR_STAGE_BYTES */
 #endif
 #define PAR_LANECAP (PAR_CB / 2)	/* tokens one lane may find in its piece (2 bits each) */
+/* where token k of lane l of a round lives in the wave's token scratch */
+#ifdef TOK_LANE_MAJOR
+#define TOK_AT(k, l) ((l) * PAR_LANECAP + (k))
+#else
+#define TOK_AT(k, l) ((k) * 64 + (l))
+#endif
 #ifndef PAR_TAIL
 #define PAR_TAIL 8u		/* input bytes a round needs in front of it */
 #endif
@@ -1020,7 +1026,7 @@ tok_fetch(const u32 *__restrict__ rows, lu8 *mk, const lu16 *tb, u32 tbase,
 	for (u32 j = 0; j < 4; j++) {
 		const u32 i = g + 4 * lane + j;
 		const u32 row = i < total ? i - base[j] : 0;
-		const u32 v = rows[row * 64 + own[j]];
+		const u32 v = rows[TOK_AT(row, own[j])];
 		w[j] = i < total ? v : 0;
 	}
 	return make_uint4(w[0], w[1], w[2], w[3]);
@@ -1143,13 +1149,13 @@ par_round(const u8 *inp, u64 in_n, u8 *outp, u64 out_avail,
 					/* row ntok of the lane-interleaved list: the 64
 					 * lanes of an iteration write one 256-byte row */
 					if (ntok < PAR_LANECAP)
-						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
+						tokS[TOK_AT(ntok, lane)] = t.kind == K_LEN ?
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
 					if (two) {
 						if (ntok < PAR_LANECAP)
-							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
+							tokS[TOK_AT(ntok, lane)] = (e1 >> 4) & 0xFF;
 						nbytes++;
 						ntok++;
 						used += e1 & 15;

@@ -186,13 +186,13 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 					}
 				} else {
 					if (keep && ntok < PAR_LANECAP)
-						tokS[ntok * 64 + lane] = t.kind == K_LEN ?
+						tokS[TOK_AT(ntok, lane)] = t.kind == K_LEN ?
 							0x80000000u | t.length | (t.dist << 9) : t.lit;
 					nbytes += t.kind == K_LEN ? t.length : 1;
 					ntok++;
 					if (two) {
 						if (keep && ntok < PAR_LANECAP)
-							tokS[ntok * 64 + lane] = (e1 >> 4) & 0xFF;
+							tokS[TOK_AT(ntok, lane)] = (e1 >> 4) & 0xFF;
 						nbytes++;
 						ntok++;
 						used += e1 & 15;
