@@ -298,10 +298,12 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			if (p + 32 > raw_bits)
 				return 0;
 			uint32_t c = 0, sy = 99;
+			const uint32_t v7 = peek(p, 7);
 			for (uint32_t len = 1; len < 8; len++) {
-				c = (c << 1) | peek(p++, 1);
+				c = (c << 1) | ((v7 >> (len - 1)) & 1);
 				if (c - first[len] < cnt[len]) {
 					sy = sorted[base[len] + c - first[len]];
+					p += len;
 					break;
 				}
 			}
@@ -490,6 +492,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		T = 8 * std::min<uint64_t>(std::max<uint64_t>(T, 2048), 65536);
 		const uint64_t OV = 8192, HDRSAFE = 4608;
 		std::vector<planned> plan;
+		plan.reserve(4096 + cands.size() * 8);
 		uint32_t nexact = 0;	/* chunks planned at exact starts (blocks of one codeword length) */
 		/* a block (or, for the carried-in state, what is left of one): its
 		 * first chunk, then inner chunks up to `next` */
@@ -639,7 +642,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				}
 			};
 			std::unordered_map<key_t, uint32_t, key_hash> by_start;
-			by_start.reserve(2 * (size_t)np + 1024);
+			by_start.reserve((size_t)np / 2 + 4096);
 			std::vector<lda_stream_chunk> pc(hc);
 			std::vector<lda_stream_res> pr(hr);
 			auto start_key = [&](uint32_t i) -> key_t {
@@ -651,9 +654,44 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
 				return key_t(pr[i].end_bit * 2 + (bnd ? 1 : 0), bnd ? pr[i].end_bit : pr[i].end_hdr_bit);
 			};
-			for (uint32_t i = 0; i < np; i++)
+			/* The K exact starts of one planned position (phases != 0) are
+			 * consecutive entries at consecutive bits: they are found by
+			 * position, not through the map (four fifths of a window's
+			 * entries where it has such blocks: their inserts were 0.2 ms of
+			 * the 16 MiB mix's count phase). */
+			struct pgroup { uint64_t P, hdr; uint32_t first, K; };
+			std::vector<pgroup> groups;	/* sorted by P */
+			auto pool_add = [&](uint32_t i) {
+				if (pc[i].phases == ~0u)
+					return;
+				if (pc[i].phases) {
+					const pgroup g = { pc[i].start_bit, pc[i].hdr_bit, i, pc[i].phases };
+					groups.insert(std::upper_bound(groups.begin(), groups.end(), g.P,
+								       [](uint64_t v, const pgroup &a) { return v < a.P; }), g);
+					return;
+				}
 				if (pc[i].kind == LDA_CHUNK_HEADER || pr[i].status != LDA_STREAM_ERR)
 					by_start.emplace(start_key(i), i);
+			};
+			auto pool_find = [&](const key_t &k) -> int64_t {
+				const auto it = by_start.find(k);
+				if (it != by_start.end())
+					return it->second;
+				if ((k.first & 1) || groups.empty())
+					return -1;	/* (a start at a block boundary is a header chunk's) */
+				const uint64_t e = k.first >> 1;
+				auto g = std::upper_bound(groups.begin(), groups.end(), e,
+							  [](uint64_t v, const pgroup &a) { return v < a.P; });
+				if (g == groups.begin())
+					return -1;
+				--g;
+				if (e - g->P >= g->K || g->hdr != k.second)
+					return -1;
+				const uint32_t idx = g->first + (uint32_t)(e - g->P);
+				return pr[idx].status != LDA_STREAM_ERR ? (int64_t)idx : -1;
+			};
+			for (uint32_t i = 0; i < np; i++)
+				pool_add(i);
 			std::vector<uint64_t> ats(np);
 			for (uint32_t i = 0; i < np; i++)
 				ats[i] = plan[i].at;
@@ -720,8 +758,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 						closed = true;
 						break;
 					}
-					auto it = by_start.find(end_key(cur));
-					if (it == by_start.end() && bnd_end) {
+					int64_t nxt = pool_find(end_key(cur));
+					if (nxt < 0 && bnd_end) {
 						/* a run of stored blocks behind this boundary: the
 						 * host's (no count pass, no round trip) */
 						std::vector<lda_stream_chunk> oc;
@@ -733,14 +771,13 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 							pc.push_back(oc[k]);
 							pr.push_back(orr[k]);
 							depth.push_back(0);
-							by_start.emplace(start_key((uint32_t)pc.size() - 1),
-									 (uint32_t)pc.size() - 1);
+							pool_add((uint32_t)pc.size() - 1);
 						}
-						it = by_start.find(end_key(cur));
+						nxt = pool_find(end_key(cur));
 					}
-					if (it == by_start.end())
+					if (nxt < 0)
 						break;
-					cur = it->second;
+					cur = (uint32_t)nxt;
 				}
 				if (closed)
 					break;
@@ -764,7 +801,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					if (pr[i].status != LDA_STREAM_OK || pr[i].end_bit >= R1)
 						continue;
 					const key_t k = end_key(i);
-					if (by_start.count(k) || asked.count(k))
+					if (pool_find(k) >= 0 || asked.count(k))
 						continue;
 					asked[k] = 1;
 					const bool bnd = pr[i].flags & LDA_RES_BOUNDARY;
@@ -803,7 +840,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					    plan[nq].c.kind == LDA_CHUNK_WARM &&
 					    plan[nq].c.hdr_bit == pr[i].end_hdr_bit &&
 					    (pr[nq].status != LDA_STREAM_OK ||
-					     !by_start.count(end_key((uint32_t)nq))) &&
+					     pool_find(end_key((uint32_t)nq)) < 0) &&
 					    plan[nx0].c.kind == LDA_CHUNK_WARM &&
 					    plan[nx0].c.hdr_bit == pr[i].end_hdr_bit && !phased[nx0] &&
 					    ncand + PHASES <= 4096) {
@@ -858,8 +895,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					pc.push_back(rc[i]);
 					pr.push_back(rr[i]);
 					depth.push_back(rdepth[i]);
-					by_start.emplace(start_key(npool + i), npool + i);
 				}
+				for (uint32_t i = 0; i < nr; i++)
+					pool_add(npool + i);
 			}
 			if (!closed) {
 				S[1] = WHY_CHAIN;
