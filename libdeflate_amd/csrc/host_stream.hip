@@ -1035,19 +1035,26 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					   d_res + lo, d_raw, dev_n, d_sym, d_tok);
 		}
 		{
-			/* the window chain as a two-level scan over groups of chunks:
-			 * 2 x per_group + groups steps instead of one per chunk */
+			/* the window chain: groups of chunks side by side with a symbolic
+			 * window, the groups' windows composed by a prefix scan (log2
+			 * launches), the groups again from their real windows.  Up to 512
+			 * groups - two workgroups of 64 KiB LDS per CU - of at least four
+			 * chunks (round 5: sqrt(chunks) / 2 groups, because a serial link
+			 * step per group had to be paid) */
 			uint32_t per_group = 4;
-			while ((uint64_t)per_group * per_group * 4 < na)
+			while ((uint64_t)per_group * 512 < na)
 				per_group++;
 			const uint32_t groups = (na + per_group - 1) / per_group;
-			uint8_t *gw = (uint8_t *)d->swin.reserve((size_t)groups * 32768 * 3 + 64);
+			uint8_t *gw = (uint8_t *)d->swin.reserve((size_t)groups * 65536 * 2 + 64);
 			if (!gw)
 				return false;
 			uint16_t *d_gwin = (uint16_t *)gw;
-			uint8_t *d_fwin = gw + (size_t)groups * 65536;
+			uint16_t *d_gwin2 = d_gwin + (size_t)groups * 32768;
+			const uint16_t *d_fwin = d_gwin;
 			if (!ctx->stream_attr_set.load(std::memory_order_acquire)) {
 				ST_TRY(hipFuncSetAttribute((const void *)lda_stream_window_kernel,
+							   hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+				ST_TRY(hipFuncSetAttribute((const void *)lda_stream_window_scan_kernel,
 							   hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
 				ctx->stream_attr_set.store(true, std::memory_order_release);
 			}
@@ -1055,8 +1062,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				hipLaunchKernelGGL(lda_stream_window_kernel, dim3(groups), dim3(1024), 65536,
 						   s_comp, na, per_group, 0u, d_off, d_sym, d_out, d_gwin,
 						   d_fwin, d_cnt + 2);
-				hipLaunchKernelGGL(lda_stream_window_link_kernel, dim3(1), dim3(1024), 0,
-						   s_comp, groups, d_gwin, d_fwin);
+				/* (the window behind the last group is nobody's) */
+				uint16_t *src = d_gwin, *dst = d_gwin2;
+				for (uint32_t h = 1; h < groups - 1; h *= 2) {
+					hipLaunchKernelGGL(lda_stream_window_scan_kernel, dim3(groups - 1), dim3(1024),
+							   65536, s_comp, groups - 1, h, src, dst);
+					std::swap(src, dst);
+				}
+				d_fwin = src;
 			}
 			hipLaunchKernelGGL(lda_stream_window_kernel, dim3(groups), dim3(1024), 65536, s_comp,
 					   na, per_group, 2u, d_off, d_sym, d_out, d_gwin, d_fwin, d_cnt + 2);

@@ -44,7 +44,7 @@
  *            symbols, a byte or - for a match source in front of the chunk's
  *            first byte - a MARKER 0x8000 | index into the 32 KiB in front of
  *            the chunk.
- *   window   lda_stream_window_kernel (+ lda_stream_window_link_kernel): the
+ *   window   lda_stream_window_kernel (+ lda_stream_window_scan_kernel): the
  *            last 32 KiB of every chunk settled against the 32 KiB in front
  *            of it - a chain through all chunks, run as a two-level scan over
  *            groups of chunks with the window as a ring in LDS (see "markers
@@ -1370,8 +1370,8 @@ find_b_one(const u8 *__restrict__ inp, u64 in_n, u64 p, lu16 *tab,
  *            group's chunks with a SYMBOLIC window - entry i of the window in
  *            front of the group is the marker 0x8000 | i - leaves the window
  *            behind the group in terms of the window in front of it;
- *   phase 1  lda_stream_window_link_kernel, one workgroup, one step per
- *            group: those symbolic windows turned into bytes, in order;
+ *   phase 1  lda_stream_window_scan_kernel: those symbolic windows composed by
+ *            a prefix scan over the groups (log2(groups) launches);
  *   phase 2  every group side by side again, now from the real window in
  *            front of it: the tails' bytes go to the output.
  *
@@ -1384,7 +1384,7 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 			 const u64 *__restrict__ out_off /*[nchunks + 1]*/,
 			 const u16 *__restrict__ sym, u8 *__restrict__ out,
 			 u16 *__restrict__ gwin /*[groups][32768]: phase 0 out */,
-			 const u8 *__restrict__ fwin /*[groups][32768]: phase 2 in */,
+			 const u16 *__restrict__ fwin /*[groups][32768]: phase 2 in (the scan's result) */,
 			 u32 *__restrict__ err)
 {
 	lu16 *W = (lu16 *)(uintptr_t)0;		/* [32768], the launch's dynamic LDS */
@@ -1399,6 +1399,10 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 		u32 v = 0x8000u | i;
 		if (phase != 0)
 			v = g ? fwin[(size_t)(g - 1) * 32768 + i] : 0;
+		/* (what is still a marker behind the scan points in front of the
+		 * stream's first byte: caught, with its position, where it is used) */
+		if (phase != 0 && (v & 0x8000u))
+			v = 0;
 		W[((u32)s0 + i) & 32767] = (u16)v;
 	}
 	__syncthreads();
@@ -1487,50 +1491,56 @@ lda_stream_window_kernel(u32 nchunks, u32 per_group, u32 phase,
 		*err = 1;
 }
 
-/* phase 1: the symbolic window behind group g, settled against the bytes
- * behind group g - 1 (nothing in front of group 0: a marker there points
- * before the stream and is caught, with its position, in phase 2) */
+/*
+ * phase 1: the symbolic windows behind the groups, composed.  The window
+ * behind group g in terms of the window in front of group g (what phase 0
+ * leaves) and the window behind group g - h in terms of the one in front of
+ * group g - 2h + 1 give the window behind g in terms of the one in front of
+ * g - 2h + 1: an entry that is a byte stays, a marker w becomes entry w of the
+ * other window.  Composition is associative, so the chain through all groups
+ * is a prefix scan: ceil(log2(groups)) launches with h = 1, 2, 4 .., every
+ * group a workgroup that holds the window it looks things up in in LDS
+ * (Hillis / Steele; the arrays alternate).  Round 5 walked the groups one
+ * after the other in one workgroup: 2.3 us per group, 173 us of a 16 MiB
+ * call - and the price of a group there kept the groups few and the group
+ * passes long (20 chunks each).  What is still a marker at the end points in
+ * front of the stream.
+ */
 extern "C" __global__ void __launch_bounds__(1024)
-lda_stream_window_link_kernel(u32 groups, const u16 *__restrict__ gwin,
-			      u8 *__restrict__ fwin)
+lda_stream_window_scan_kernel(u32 n, u32 h, const u16 *__restrict__ src, u16 *__restrict__ dst)
 {
-	__shared__ u8 F[2][32768];
-	const u32 tid = threadIdx.x;
-	u32 cur = 0;
-	/* two symbols per load; the next group's are requested before this
-	 * one's are settled */
-	u32 nx[16];
-	if (groups > 1) {
-#pragma unroll
-		for (u32 k = 0; k < 16; k++)
-			nx[k] = ((const u32 *)gwin)[tid + 1024 * k];
+	lu16 *A = (lu16 *)(uintptr_t)0;		/* [32768], the launch's dynamic LDS */
+	const u32 tid = threadIdx.x, g = blockIdx.x;
+	if (g >= n)
+		return;
+	const uint4 *sb = (const uint4 *)(src + (size_t)g * 32768);
+	uint4 *db = (uint4 *)(dst + (size_t)g * 32768);
+	if (g < h) {	/* already in terms of the window in front of the stream */
+		for (u32 q = tid; q < 4096; q += 1024)
+			db[q] = sb[q];
+		return;
 	}
-	for (u32 g = 0; g + 1 < groups; g++) {
-		u8 *dst = fwin + (size_t)g * 32768;
-		u32 v[16];
+	const uint4 *sa = (const uint4 *)(src + (size_t)(g - h) * 32768);
+	uint4 vb[4];
 #pragma unroll
-		for (u32 k = 0; k < 16; k++)
-			v[k] = nx[k];
-		if (g + 2 < groups) {
-			const u32 *src = (const u32 *)(gwin + (size_t)(g + 1) * 32768);
+	for (u32 k = 0; k < 4; k++) {
+		vb[k] = sb[tid + 1024 * k];
+		((AS3 uint4 *)A)[tid + 1024 * k] = sa[tid + 1024 * k];
+	}
+	__syncthreads();
 #pragma unroll
-			for (u32 k = 0; k < 16; k++)
-				nx[k] = src[tid + 1024 * k];
+	for (u32 k = 0; k < 4; k++) {
+		u32 w[4] = { vb[k].x, vb[k].y, vb[k].z, vb[k].w };
+#pragma unroll
+		for (u32 j = 0; j < 4; j++) {
+			u32 lo = w[j] & 0xFFFF, hi = w[j] >> 16;
+			if (lo & 0x8000)
+				lo = A[lo & 0x7FFF];
+			if (hi & 0x8000)
+				hi = A[hi & 0x7FFF];
+			w[j] = lo | (hi << 16);
 		}
-#pragma unroll
-		for (u32 k = 0; k < 16; k++) {
-			const u32 i = 2 * (tid + 1024 * k);
-			u32 b0 = v[k] & 0xFFFF, b1 = v[k] >> 16;
-			if (b0 & 0x8000)
-				b0 = g ? F[cur][b0 & 0x7FFF] : 0;
-			if (b1 & 0x8000)
-				b1 = g ? F[cur][b1 & 0x7FFF] : 0;
-			const u16 two = (u16)((b0 & 0xFF) | (b1 << 8));
-			*(u16 *)&F[cur ^ 1][i] = two;
-			*(u16 *)(dst + i) = two;
-		}
-		__syncthreads();
-		cur ^= 1;
+		db[tid + 1024 * k] = make_uint4(w[0], w[1], w[2], w[3]);
 	}
 }
 

@@ -73,9 +73,9 @@ lda_stream_find_b_kernel(const uint8_t *inp, uint64_t in_n, const uint64_t *queu
 extern "C" __global__ void
 lda_stream_window_kernel(uint32_t nchunks, uint32_t per_group, uint32_t phase,
 			 const uint64_t *out_off, const uint16_t *sym, uint8_t *out,
-			 uint16_t *gwin, const uint8_t *fwin, uint32_t *err);
+			 uint16_t *gwin, const uint16_t *fwin, uint32_t *err);
 extern "C" __global__ void
-lda_stream_window_link_kernel(uint32_t groups, const uint16_t *gwin, uint8_t *fwin);
+lda_stream_window_scan_kernel(uint32_t n, uint32_t h, const uint16_t *src, uint16_t *dst);
 extern "C" __global__ void
 lda_stream_resolve_kernel(uint32_t nchunks, uint32_t chunk0, const uint64_t *out_off,
 			  const uint16_t *sym, uint8_t *out, uint32_t *err);
