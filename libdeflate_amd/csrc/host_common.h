@@ -158,11 +158,12 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 		    void *const *out, const uint64_t *nbytes,
 		    const uint64_t *off, hipStream_t st);
 
-/* one contiguous host range <-> device range, in 1 MiB pieces (see above) */
+/* one contiguous host range <-> device range, in pieces the copy threads share
+ * (`piece` bytes each; 0: sixteen to a slice, see host_context.hip) */
 int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src, size_t n,
-	    hipStream_t st);
+	    hipStream_t st, size_t piece = 0);
 int span_out(PinnedPair *pp, const uint8_t *d_base, uint64_t d_off, uint8_t *dst, size_t n,
-	     hipStream_t st);
+	     hipStream_t st, size_t piece = 0);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -617,6 +617,14 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 	    hipMemcpyAsync(d_seg, d32.data(), 4 * nseg, hipMemcpyHostToDevice, s_copy) != hipSuccess)
 		return large_fail("copy in");
 	std::vector<hipEvent_t> ev_done(ns, nullptr);
+	/* A call of one slice (up to 32 MiB) takes the copy helpers' own pieces:
+	 * all copy threads on its input AND on its output (16 MiB: 10.9 -> 12.2
+	 * GB/s, round 6).  A call of several slices keeps pieces of 1 MiB, with
+	 * which a slice's output - a third of its input - is copied by the calling
+	 * thread alone: with the threads on it too, four processes of six ran
+	 * 256 MiB calls in 12.3 ms instead of 10.9 (`profiles/r06_ab.md` run 35;
+	 * the calling thread is what queues the next slice's kernels). */
+	const size_t piece = ns > 1 ? (size_t)1 << 20 : 0;
 	size_t total = hdr;	/* bytes of the output so far */
 	bool fits = true, failed = false;
 	auto cleanup = [&]() {
@@ -638,7 +646,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 			fits = false;
 			return true;
 		}
-		if (tk && span_out(&c->pinned, st, pk_at + lo * slot, out + total, tk, s_copy) != LIBDEFLATE_AMD_OK)
+		if (tk && span_out(&c->pinned, st, pk_at + lo * slot, out + total, tk, s_copy, piece) != LIBDEFLATE_AMD_OK)
 			return false;
 		total += tk;
 		return true;
@@ -648,7 +656,7 @@ static size_t compress_large(struct libdeflate_compressor *c, int format,
 		const size_t a = lo * S, b = std::min(n, (lo + nk) * S);
 		/* (returns when the slice - and, the first time, the descriptors -
 		 * are on the device) */
-		if (span_in(&c->pinned, st, in_at + a, in + a, b - a, s_copy) != LIBDEFLATE_AMD_OK) {
+		if (span_in(&c->pinned, st, in_at + a, in + a, b - a, s_copy, piece) != LIBDEFLATE_AMD_OK) {
 			failed = true;
 			break;
 		}

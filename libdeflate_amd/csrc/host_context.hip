@@ -524,15 +524,25 @@ int copy_out_packed(PinnedPair *pp, const uint8_t *d_base, size_t n,
 }
 
 /* one contiguous host range <-> a device range through a pinned pair, cut into
- * pieces of 256 KiB so that the packing threads share the memcpy and the DMA of
- * one pinned buffer runs beside the memcpy of the other.  (Pieces of 1 MiB until
- * round 6: a slice of 4 MiB - a quarter of a 16 MiB stream - then had four
- * pieces, fewer than for_chunks_parallel() asks for before it wakes the
- * threads, and ONE thread copied every slice: 0.7 ms of a 2.4 ms call.) */
-int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src, size_t n,
-	    hipStream_t st)
+ * pieces so that the packing threads share the memcpy and the DMA of one pinned
+ * buffer runs beside the memcpy of the other: a slice is a quarter of the range
+ * (at least 2 MiB) and has sixteen pieces of 64 KiB .. 1 MiB.  (Pieces of 1 MiB
+ * whatever the range until round 6: a slice of 4 MiB - a quarter of a 16 MiB
+ * stream - then had four pieces, fewer than for_chunks_parallel() asks for
+ * before it wakes the threads, and ONE thread copied every slice: 0.7 ms of a
+ * 2.4 ms call.) */
+static size_t span_piece(size_t n)
 {
-	const size_t P = (size_t)256 << 10, np = (n + P - 1) / P;
+	size_t slice = std::max<size_t>((size_t)2 << 20, n / 4), p = (size_t)64 << 10;
+	while (p < ((size_t)1 << 20) && 16 * p < slice)
+		p *= 2;
+	return p;
+}
+
+int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src, size_t n,
+	    hipStream_t st, size_t piece)
+{
+	const size_t P = piece ? piece : span_piece(n), np = (n + P - 1) / P;
 	std::vector<const void *> ins(np);
 	std::vector<size_t> nb(np);
 	std::vector<uint64_t> off(np);
@@ -545,9 +555,9 @@ int span_in(PinnedPair *pp, uint8_t *d_base, uint64_t d_off, const uint8_t *src,
 }
 
 int span_out(PinnedPair *pp, const uint8_t *d_base, uint64_t d_off, uint8_t *dst, size_t n,
-	     hipStream_t st)
+	     hipStream_t st, size_t piece)
 {
-	const size_t P = (size_t)256 << 10, np = (n + P - 1) / P;
+	const size_t P = piece ? piece : span_piece(n), np = (n + P - 1) / P;
 	std::vector<void *> outs(np);
 	std::vector<uint64_t> nb(np), off(np);
 	for (size_t i = 0; i < np; i++) {
