@@ -137,6 +137,7 @@ struct PinnedBuf {
 struct StreamPair {
 	hipStream_t copy = nullptr, comp = nullptr;
 	hipEvent_t mark = nullptr;	/* a point on `comp` that `copy` may wait for */
+	hipEvent_t mark2 = nullptr;	/* and one on `copy` that `comp` may wait for */
 	bool ensure();
 	void release();
 };

@@ -165,11 +165,12 @@ void PinnedBuf::release()
 
 bool StreamPair::ensure()
 {
-	if (copy && comp && mark)
+	if (copy && comp && mark && mark2)
 		return true;
 	if ((!copy && hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) ||
 	    (!comp && hipStreamCreateWithFlags(&comp, hipStreamNonBlocking) != hipSuccess) ||
-	    (!mark && hipEventCreateWithFlags(&mark, hipEventDisableTiming) != hipSuccess)) {
+	    (!mark && hipEventCreateWithFlags(&mark, hipEventDisableTiming) != hipSuccess) ||
+	    (!mark2 && hipEventCreateWithFlags(&mark2, hipEventDisableTiming) != hipSuccess)) {
 		set_error("hipStreamCreate: %s", hipGetErrorString(hipGetLastError()));
 		return false;
 	}
@@ -184,8 +185,10 @@ void StreamPair::release()
 		(void)hipStreamDestroy(comp);
 	if (mark)
 		(void)hipEventDestroy(mark);
+	if (mark2)
+		(void)hipEventDestroy(mark2);
 	copy = comp = nullptr;
-	mark = nullptr;
+	mark = mark2 = nullptr;
 }
 
 size_t slice_by_bytes(size_t n, const size_t *nbytes, size_t max_slices,

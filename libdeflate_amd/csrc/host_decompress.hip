@@ -151,6 +151,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->schunks.release();
 	d->srepair.release();
 	d->swin.release();
+	d->shdr.release();
 	d->ssym.release();
 	d->sout.release();
 	d->pinned.release();

@@ -93,10 +93,11 @@ static bool container(int format, const uint8_t *in, size_t n, size_t *hdr, size
 }
 
 static bool launch_count(hipStream_t st, uint32_t n, const lda_stream_chunk *d_chunks,
-			 lda_stream_res *d_res, const uint8_t *d_raw, uint64_t raw_n)
+			 lda_stream_res *d_res, const uint8_t *d_raw, uint64_t raw_n,
+			 const uint8_t *d_hlens, const uint32_t *d_hinfo)
 {
 	hipLaunchKernelGGL(lda_stream_count_kernel, dim3(n), dim3(64), lda_stream_chunk_lds(),
-			   st, n, d_chunks, d_res, d_raw, raw_n, (uint32_t *)NULL);
+			   st, n, d_chunks, d_res, d_raw, raw_n, (uint32_t *)NULL, d_hlens, d_hinfo);
 	ST_TRY(hipGetLastError());
 	return true;
 }
@@ -382,6 +383,22 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	 * the window searched */
 	uint8_t *sin = nullptr, *d_raw = nullptr;
 	uint64_t *d_queue = nullptr, *d_cand = nullptr;
+	/* The headers the finder accepts are parsed ONCE each, by a wave of their
+	 * own, beside the host's planning (lda_stream_hdr_cache_kernel on the copy
+	 * stream, which has nothing to do then): slot i holds the code lengths of
+	 * candidate i of the current window, and every chunk at or inside that
+	 * block takes them from there instead of parsing the header again (one
+	 * lane's loop: 40 us of every chunk of the count pass and of the decode
+	 * pass).  hdr_bit -> slot + 1: */
+	uint8_t *d_hlens = (uint8_t *)d->shdr.reserve((size_t)LDA_STREAM_HDR_SLOTS * (320 + 16) + 64);
+	if (!d_hlens)
+		return false;
+	uint32_t *d_hinfo = (uint32_t *)(d_hlens + (size_t)LDA_STREAM_HDR_SLOTS * 320);
+	std::unordered_map<uint64_t, uint32_t> hdr_slot;
+	auto cache_of = [&](uint64_t hdr_bit) -> uint32_t {
+		const auto it = hdr_slot.find(hdr_bit);
+		return it == hdr_slot.end() ? 0 : it->second;
+	};
 	uint32_t *d_cnt = nullptr;	/* [0] queue, [1] candidates, [2] error flag */
 	uint32_t qcap = 0, ccap = 0;
 
@@ -398,6 +415,11 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	uint64_t dev_n = 0;	/* raw bytes the kernels may read (the last window's) */
 	bool final_seen = false;
 	for (size_t W = W0; !final_seen; W = W < ((size_t)1 << 40) ? W * 4 : W) {
+		/* (the parsed headers are the current window's) */
+		hdr_slot.clear();
+		for (lda_stream_chunk &c : acc)
+			c.hdr_cache = 0;
+		bool cache_queued = false;
 		/* ---- this window's input ---- */
 		const size_t upto = std::min<size_t>(in_nbytes, std::max(copied, hdr) + W);
 		if (!sin || in_at + upto + 64 > d->sin.cap) {
@@ -474,6 +496,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					   dim3(64), lda_stream_find_b_lds(),
 					   s_comp, d_raw, win_n, d_queue, d_cnt, qcap, d_cand, d_cnt + 1, ccap);
 			ST_TRY(hipGetLastError());
+			ST_TRY(hipEventRecord(d->streams.mark, s_comp));
+			ST_TRY(hipStreamWaitEvent(s_copy, d->streams.mark, 0));
+			hipLaunchKernelGGL(lda_stream_hdr_cache_kernel, dim3(8u * (unsigned)ctx->num_cus), dim3(64),
+					   lda_stream_hdr_cache_lds(), s_copy, d_raw, win_n, d_cand, d_cnt + 1,
+					   std::min<uint32_t>(ccap, LDA_STREAM_HDR_SLOTS), d_hlens, d_hinfo);
+			ST_TRY(hipGetLastError());
+			ST_TRY(hipEventRecord(d->streams.mark2, s_copy));
+			cache_queued = true;
 			/* the counts and the first candidates in one round trip (a stream
 			 * of a few MiB has a few hundred) */
 			const uint32_t first = std::min<uint32_t>(ccap, 2048);
@@ -492,6 +522,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				ST_TRY(back(cands.data() + first, d_cand + first, (size_t)(nc - first) * 8));
 				ST_TRY(pin_sync());
 			}
+			for (uint32_t i = 0; i < nc && i < LDA_STREAM_HDR_SLOTS; i++)
+				hdr_slot.emplace(cands[i], i + 1);
 			std::sort(cands.begin(), cands.end());
 			S[2] += cnt[0];
 			S[3] += nc;
@@ -611,9 +643,14 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				nxt_at = plan[i + 1].at;
 			plan[i].c.limit_bit = nxt_at;
 		}
+		if (!hdr_slot.empty())
+			for (planned &q : plan)
+				q.c.hdr_cache = cache_of(q.c.hdr_bit);
 		const uint32_t np = (uint32_t)plan.size();
 		S[4] += np;
 		dbg("planned");
+		if (cache_queued)
+			ST_TRY(hipStreamWaitEvent(s_comp, d->streams.mark2, 0));
 
 		/* ---- count ---- */
 		const size_t res_at = align_up((size_t)np * sizeof(lda_stream_chunk) + 64, 64);
@@ -630,7 +667,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		if (!pin_phase((size_t)np * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
 			return false;
 		ST_TRY(up(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk)));
-		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n))
+		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n, d_hlens, d_hinfo))
 			return false;
 		ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
 		dbg("count queued");
@@ -891,6 +928,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 					return false;
 				}
 				const uint32_t nr = (uint32_t)rc.size();
+				if (!hdr_slot.empty())
+					for (lda_stream_chunk &c : rc)
+						c.hdr_cache = cache_of(c.hdr_bit);
 				uint8_t *rp = (uint8_t *)d->srepair.reserve(
 					(size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 128);
 				if (!rp)
@@ -901,7 +941,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				if (!pin_phase((size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
 					return false;
 				ST_TRY(up(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk)));
-				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n))
+				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n, d_hlens, d_hinfo))
 					return false;
 				ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
 				dbg("repairs queued");
@@ -1048,7 +1088,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
 			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
 					   lda_stream_chunk_lds(), s_comp, nk, d_chunks + lo,
-					   d_res + lo, d_raw, dev_n, d_sym, d_tok);
+					   d_res + lo, d_raw, dev_n, d_sym, d_tok, d_hlens, d_hinfo);
 		}
 		{
 			/* the window chain: groups of chunks side by side with a symbolic

@@ -456,6 +456,83 @@ stage_input(lu8 *stage, const u8 *inp, u64 in_n, u64 byte0, u32 nbytes, u32 lane
 }
 
 /*
+ * The code lengths of a dynamic block header (lib/decompress_template.h:
+ * 150-245): ONE lane's loop, from the staged copy; b stands at the header's
+ * three first bits (b->buf holds BFINAL / BTYPE / HLIT .. at its low end).
+ * Leaves the lengths in S->lens[0 .. nlit + noff) and b behind the header.
+ * false: a repeat without a previous length, or one that overruns the counts.
+ */
+static __device__ __forceinline__ bool
+dynamic_lens(slds_t *S, const lu8 *stage, struct par_bits *bp, u32 *nlit_ret, u32 *noff_ret)
+{
+	struct par_bits b = *bp;
+	u8 plens[19];
+	const u32 nlit = 257 + (((u32)b.buf >> 3) & 31);
+	const u32 noff = 1 + (((u32)b.buf >> 8) & 31);
+	const u32 npre = 4 + (((u32)b.buf >> 13) & 15);
+	for (u32 i = 0; i < 19; i++)
+		plens[i] = 0;
+	plens[c_pre_perm[0]] = ((u32)b.buf >> 17) & 7;
+	b.buf >>= 20;
+	b.cnt -= 20;
+	pb_refill(&b, stage);
+	for (u32 i = 1; i < npre; i++) {
+		plens[c_pre_perm[i]] = (u32)b.buf & 7;
+		b.buf >>= 3;
+		b.cnt -= 3;
+	}
+	bool ok = build_precode(S->pre_tab, plens);
+	u32 i = 0;
+	const u32 total = nlit + noff;
+	while (ok && i < total) {
+		if (b.cnt < 14)
+			pb_refill(&b, stage);
+		const u32 e = S->pre_tab[(u32)b.buf & 127];
+		b.buf >>= e & 15;
+		b.cnt -= e & 15;
+		const u32 presym = e >> 4;
+		if (presym < 16) {
+			S->lens[i++] = (u8)presym;
+			continue;
+		}
+		u32 rep, val = 0;
+		if (presym == 16) {
+			if (i == 0) {
+				ok = false;
+				break;
+			}
+			val = S->lens[i - 1];
+			rep = 3 + ((u32)b.buf & 3);
+			b.buf >>= 2;
+			b.cnt -= 2;
+		} else if (presym == 17) {
+			rep = 3 + ((u32)b.buf & 7);
+			b.buf >>= 3;
+			b.cnt -= 3;
+		} else {
+			rep = 11 + ((u32)b.buf & 127);
+			b.buf >>= 7;
+			b.cnt -= 7;
+		}
+		for (u32 k = 0; k < rep; k++)
+			S->lens[i + k] = (u8)val;
+		i += rep;
+	}
+	*bp = b;
+	*nlit_ret = nlit;
+	*noff_ret = noff;
+	return ok && i == total;
+}
+
+/* a header the host had parsed ahead of the chunk kernels (lda_stream_hdr_cache_kernel):
+ * its code lengths and {HLIT + 257, HDIST + 1, bits up to the first token, BFINAL} */
+#define HDRC_LENS 320u
+struct hdr_cached {
+	const u8 *lens;		/* NULL: none, the chunk parses the header itself */
+	const u32 *info;
+};
+
+/*
  * A block header at bit `pos` (lib/decompress_template.h:72-245, :313-326):
  * lane 0 parses it from a staged copy, all lanes build the tables.
  * Returns 0: Huffman block, tables ready, *pos_ret = first token;
@@ -465,15 +542,30 @@ stage_input(lu8 *stage, const u8 *inp, u64 in_n, u64 byte0, u32 nbytes, u32 lane
 #define HDR_STAGE 704u	/* 17 + 57 + 316 x 14 bits at most, + slack */
 static __device__ u32
 chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
-	     u32 *final_ret, u64 *pos_ret, bool *static_ret)
+	     u32 *final_ret, u64 *pos_ret, bool *static_ret,
+	     struct hdr_cached hc = { NULL, NULL })
 {
 	/* pos == LDA_HDR_STATIC: no header to read, the static codes' tables */
 	const bool forced = pos == LDA_HDR_STATIC;
+	/* a dynamic header parsed ahead: its lengths come from memory (the parse
+	 * is one lane's loop of ~300 dependent LDS round trips: 40 us of every
+	 * chunk of the count pass and of the decode pass, and a block's chunks -
+	 * two dozen - all did it) */
+	const bool cached = !forced && hc.lens != NULL && hc.info[0] != 0;
 	if (forced)
 		pos = 0;
-	else
+	else if (!cached)
 		stage_input(stage, inp, in_n, pos >> 3, HDR_STAGE, lane);
 	u32 r = 2, fin = 0, nlit = 0, noff = 0, used = 0, stat = 0;
+	if (cached) {
+		nlit = hc.info[0];
+		noff = hc.info[1];
+		used = hc.info[2];
+		fin = hc.info[3];
+		r = 0;
+		for (u32 w = lane; w < HDRC_LENS / 4; w += 64)
+			((lu32 *)S->lens)[w] = ((const u32 *)hc.lens)[w];
+	} else {
 	if (lane == 0) {
 		struct par_bits b;
 		const u32 p0 = (u32)pos & 7;
@@ -496,63 +588,12 @@ chunk_header(const u8 *inp, u64 in_n, slds_t *S, lu8 *stage, u32 lane, u64 pos,
 			r = 0;
 			used = forced ? 0 : 3;
 		} else if (btype == 2) {
-			u8 plens[19];
-			nlit = 257 + (((u32)b.buf >> 3) & 31);
-			noff = 1 + (((u32)b.buf >> 8) & 31);
-			const u32 npre = 4 + (((u32)b.buf >> 13) & 15);
-			for (u32 i = 0; i < 19; i++)
-				plens[i] = 0;
-			plens[c_pre_perm[0]] = ((u32)b.buf >> 17) & 7;
-			b.buf >>= 20;
-			b.cnt -= 20;
-			pb_refill(&b, stage);
-			for (u32 i = 1; i < npre; i++) {
-				plens[c_pre_perm[i]] = (u32)b.buf & 7;
-				b.buf >>= 3;
-				b.cnt -= 3;
-			}
-			bool ok = build_precode(S->pre_tab, plens);
-			u32 i = 0;
-			const u32 total = nlit + noff;
-			while (ok && i < total) {
-				if (b.cnt < 14)
-					pb_refill(&b, stage);
-				const u32 e = S->pre_tab[(u32)b.buf & 127];
-				b.buf >>= e & 15;
-				b.cnt -= e & 15;
-				const u32 presym = e >> 4;
-				if (presym < 16) {
-					S->lens[i++] = (u8)presym;
-					continue;
-				}
-				u32 rep, val = 0;
-				if (presym == 16) {
-					if (i == 0) {
-						ok = false;
-						break;
-					}
-					val = S->lens[i - 1];
-					rep = 3 + ((u32)b.buf & 3);
-					b.buf >>= 2;
-					b.cnt -= 2;
-				} else if (presym == 17) {
-					rep = 3 + ((u32)b.buf & 7);
-					b.buf >>= 3;
-					b.cnt -= 3;
-				} else {
-					rep = 11 + ((u32)b.buf & 127);
-					b.buf >>= 7;
-					b.cnt -= 7;
-				}
-				for (u32 k = 0; k < rep; k++)
-					S->lens[i + k] = (u8)val;
-				i += rep;
-			}
-			if (ok && i == total) {
+			if (dynamic_lens(S, stage, &b, &nlit, &noff)) {
 				r = 0;
 				used = PB_POS(b) - p0;
 			}
 		}
+	}
 	}
 	r = bcast_first(r);
 	fin = bcast_first(fin);
@@ -691,11 +732,24 @@ chunk_seq(const u8 *inp, u64 in_n, const slds_t *S, lu8 *stage, u32 lane,
 	return ret;
 }
 
+static __device__ __forceinline__ struct hdr_cached
+hdr_of(const struct lda_stream_chunk *cd, const u8 *hdr_lens, const u32 *hdr_info)
+{
+	const u32 c = cd->hdr_cache;	/* slot + 1 of the header at cd->hdr_bit; 0: none */
+	struct hdr_cached h = { NULL, NULL };
+	if (c && hdr_lens) {
+		h.lens = hdr_lens + (size_t)(c - 1) * HDRC_LENS;
+		h.info = hdr_info + 4 * (size_t)(c - 1);
+	}
+	return h;
+}
+
 /* one chunk on one wave */
 template <int MODE> static __device__ void
 chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	  struct lda_stream_res *__restrict__ rs, const u8 *__restrict__ inp,
-	  u64 in_n, u16 *__restrict__ sym, u32 *__restrict__ tok)
+	  u64 in_n, u16 *__restrict__ sym, u32 *__restrict__ tok,
+	  const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info)
 {
 	const u32 lane = threadIdx.x;
 	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
@@ -718,7 +772,8 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	if (kind != LDA_CHUNK_HEADER) {
 		/* inside a block: its tables, then the start */
 		u64 p2;
-		const u32 r = chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static);
+		const u32 r = chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static,
+					   hdr_of(cd, hdr_lens, hdr_info));
 		if (r != 0 || (!stop_at_eob && cd->start_bit < p2)) {
 			status = LDA_STREAM_ERR;
 		} else {
@@ -749,11 +804,15 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 				at_boundary = 1;
 				break;
 			}
+			const bool own = first && pos == cd->hdr_bit;
 			first = false;
 			u64 p2;
 			hdr = pos;
+			/* (the chunk's own header may have been parsed ahead; what it
+			 * walks into behind it was not) */
 			const u32 r = chunk_header(inp, in_n, S, stage, lane, pos, &final_blk, &p2,
-						   &gov_static);
+						   &gov_static,
+						   own ? hdr_of(cd, hdr_lens, hdr_info) : hdr_cached{ NULL, NULL });
 			if (r == 2) {
 				status = LDA_STREAM_ERR;
 				break;
@@ -867,7 +926,8 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 #define PHASE_MAX 12u
 static __device__ bool
 phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_res *__restrict__ rs,
-	    u32 K, const u8 *__restrict__ inp, u64 in_n)
+	    u32 K, const u8 *__restrict__ inp, u64 in_n,
+	    const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info)
 {
 	const u32 lane = threadIdx.x;
 	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
@@ -887,7 +947,8 @@ phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_re
 	u32 final_blk = 0;
 	u64 p2;
 	bool gov_static = false;
-	if (chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static) != 0 || P < p2)
+	if (chunk_header(inp, in_n, S, stage, lane, hdr, &final_blk, &p2, &gov_static,
+			 hdr_of(cd, hdr_lens, hdr_info)) != 0 || P < p2)
 		return false;
 	const u32 lim = (u32)(limit - 8 * byte0);
 	const u32 NL = (lim - bpos0 + cb - 1) / cb;	/* 1 .. 64 */
@@ -1046,7 +1107,7 @@ phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_re
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 			struct lda_stream_res *res, const u8 *inp, u64 in_n,
-			u32 *tokscratch)
+			u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info)
 {
 	if (blockIdx.x >= nchunks)
 		return;
@@ -1056,25 +1117,82 @@ lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 	if (K == ~0u)
 		return;
 	if (K != 0 && K <= nchunks - blockIdx.x) {
-		if (phase_count(chunks + blockIdx.x, res + blockIdx.x, K, inp, in_n))
+		if (phase_count(chunks + blockIdx.x, res + blockIdx.x, K, inp, in_n, hdr_lens, hdr_info))
 			return;
 		for (u32 j = 0; j < K; j++)
 			chunk_run<SM_COUNT>(chunks + blockIdx.x + j, res + blockIdx.x + j, inp, in_n,
-					    NULL, tokscratch);
+					    NULL, tokscratch, hdr_lens, hdr_info);
 		return;
 	}
 	chunk_run<SM_COUNT>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, NULL,
-			    tokscratch);	/* (keeps no tokens) */
+			    tokscratch, hdr_lens, hdr_info);	/* (keeps no tokens) */
 }
 
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_decode_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 			 struct lda_stream_res *res, const u8 *inp, u64 in_n,
-			 u16 *sym, u32 *tokscratch)
+			 u16 *sym, u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info)
 {
 	if (blockIdx.x < nchunks)
 		chunk_run<SM_MARK>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, sym,
-				   tokscratch + (size_t)blockIdx.x * PAR_SCRATCH);
+				   tokscratch + (size_t)blockIdx.x * PAR_SCRATCH, hdr_lens, hdr_info);
+}
+
+/*
+ * The headers the finder accepted, parsed ONCE each (a wave per header: lane 0
+ * decodes the code lengths, all lanes store them) beside the host's planning,
+ * for every chunk that starts at or inside the block: slot i belongs to
+ * cand[i].  A header this kernel cannot parse leaves HLIT + 257 = 0 in its
+ * slot: the chunks parse it themselves and say what is wrong with it.
+ */
+extern "C" __global__ void __launch_bounds__(64)
+lda_stream_hdr_cache_kernel(const u8 *__restrict__ inp, u64 in_n,
+			    const u64 *__restrict__ cand, const u32 *__restrict__ ncand,
+			    u32 nslots, u8 *__restrict__ hdr_lens, u32 *__restrict__ hdr_info)
+{
+	const u32 lane = threadIdx.x;
+	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
+	lu8 *stage = (lu8 *)(S + 1);
+	u32 nc = *ncand;
+	nc = nc < nslots ? nc : nslots;
+	for (u32 idx = blockIdx.x; idx < nc; idx += gridDim.x) {
+		const u64 p = cand[idx];
+		wave_sync();	/* (the LDS of the header before) */
+		stage_input(stage, inp, in_n, p >> 3, HDR_STAGE, lane);
+		u32 ok = 0, nlit = 0, noff = 0, used = 0, fin = 0;
+		if (lane == 0) {
+			struct par_bits b;
+			const u32 p0 = (u32)p & 7;
+			pb_init(&b, stage, p0);
+			fin = (u32)b.buf & 1;
+			if ((((u32)b.buf >> 1) & 3) == 2 && dynamic_lens(S, stage, &b, &nlit, &noff)) {
+				ok = 1;
+				used = PB_POS(b) - p0;
+			}
+		}
+		ok = bcast_first(ok);
+		nlit = bcast_first(nlit);
+		noff = bcast_first(noff);
+		used = bcast_first(used);
+		fin = bcast_first(fin);
+		wave_sync();
+		if (!ok || p + used > 8 * in_n)
+			nlit = 0;
+		for (u32 w = lane; w < HDRC_LENS / 4; w += 64)
+			((u32 *)(hdr_lens + (size_t)idx * HDRC_LENS))[w] = ((const lu32 *)S->lens)[w];
+		if (lane == 0) {
+			u32 *inf = hdr_info + 4 * (size_t)idx;
+			inf[0] = nlit;
+			inf[1] = noff;
+			inf[2] = used;
+			inf[3] = fin;
+		}
+	}
+}
+
+extern "C" size_t lda_stream_hdr_cache_lds(void)
+{
+	return sizeof(struct stream_lds) + HDR_STAGE;
 }
 
 extern "C" size_t lda_stream_chunk_lds(void)

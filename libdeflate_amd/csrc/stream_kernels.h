@@ -35,6 +35,9 @@ struct lda_stream_chunk {
 	uint32_t kind;
 	uint32_t phases;	/* count pass: 0, or K on the first of K EXACT chunks at consecutive
 				 * bits with one limit that are counted together, ~0 on the others */
+	uint32_t hdr_cache;	/* 0, or 1 + the slot of lda_stream_hdr_cache_kernel that holds the
+				 * code lengths of the header at hdr_bit */
+	uint32_t pad;
 };
 
 #define LDA_STREAM_OK 0u	/* stopped at the limit */
@@ -58,11 +61,18 @@ struct lda_stream_res {
 extern "C" __global__ void
 lda_stream_count_kernel(uint32_t nchunks, const struct lda_stream_chunk *chunks,
 			struct lda_stream_res *res, const uint8_t *inp, uint64_t in_n,
-			uint32_t *tokscratch);
+			uint32_t *tokscratch, const uint8_t *hdr_lens, const uint32_t *hdr_info);
 extern "C" __global__ void
 lda_stream_decode_kernel(uint32_t nchunks, const struct lda_stream_chunk *chunks,
 			 struct lda_stream_res *res, const uint8_t *inp, uint64_t in_n,
-			 uint16_t *sym, uint32_t *tokscratch);
+			 uint16_t *sym, uint32_t *tokscratch, const uint8_t *hdr_lens,
+			 const uint32_t *hdr_info);
+extern "C" __global__ void
+lda_stream_hdr_cache_kernel(const uint8_t *inp, uint64_t in_n, const uint64_t *cand,
+			    const uint32_t *ncand, uint32_t nslots, uint8_t *hdr_lens,
+			    uint32_t *hdr_info);
+extern "C" size_t lda_stream_hdr_cache_lds(void);
+#define LDA_STREAM_HDR_SLOTS 8192u	/* headers of a window parsed ahead (320 + 16 bytes each) */
 extern "C" __global__ void
 lda_stream_find_a_kernel(const uint8_t *inp, uint64_t in_n, uint64_t bit0, uint64_t nbits,
 			 uint64_t *queue, uint32_t *qcount, uint32_t qcap);
