@@ -152,6 +152,7 @@ libdeflate_free_decompressor(struct libdeflate_decompressor *d)
 	d->srepair.release();
 	d->swin.release();
 	d->shdr.release();
+	d->shint.release();
 	d->ssym.release();
 	d->sout.release();
 	d->pinned.release();

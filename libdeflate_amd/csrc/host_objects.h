@@ -44,7 +44,7 @@ struct libdeflate_decompressor {
 	lda::DevBuf tokens;	/* per-wave token scratch of the wave-per-stream kernel */
 	/* one large stream on many waves (host_stream.hip): input + finder
 	 * queues, chunk descriptors / results, 16-bit symbols, output bytes */
-	lda::DevBuf sin, squeue, schunks, srepair, ssym, sout, swin, shdr;
+	lda::DevBuf sin, squeue, schunks, srepair, ssym, sout, swin, shdr, shint;
 	lda::PinnedPair pinned;	/* host-pointer entry points */
 	lda::PinnedBuf meta;	/* host-pointer entry points: per-chunk read-backs */
 	lda::StreamPair streams;	/* host-pointer entry points: transfers / kernels */

@@ -94,10 +94,11 @@ static bool container(int format, const uint8_t *in, size_t n, size_t *hdr, size
 
 static bool launch_count(hipStream_t st, uint32_t n, const lda_stream_chunk *d_chunks,
 			 lda_stream_res *d_res, const uint8_t *d_raw, uint64_t raw_n,
-			 const uint8_t *d_hlens, const uint32_t *d_hinfo)
+			 const uint8_t *d_hlens, const uint32_t *d_hinfo, uint16_t *d_hints)
 {
 	hipLaunchKernelGGL(lda_stream_count_kernel, dim3(n), dim3(64), lda_stream_chunk_lds(),
-			   st, n, d_chunks, d_res, d_raw, raw_n, (uint32_t *)NULL, d_hlens, d_hinfo);
+			   st, n, d_chunks, d_res, d_raw, raw_n, (uint32_t *)NULL, d_hlens, d_hinfo,
+			   d_hints);
 	ST_TRY(hipGetLastError());
 	return true;
 }
@@ -394,6 +395,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	if (!d_hlens)
 		return false;
 	uint32_t *d_hinfo = (uint32_t *)(d_hlens + (size_t)LDA_STREAM_HDR_SLOTS * 320);
+	uint16_t *d_hints = nullptr;	/* the last window's rows of lane starts (chunk.hint) */
 	std::unordered_map<uint64_t, uint32_t> hdr_slot;
 	auto cache_of = [&](uint64_t hdr_bit) -> uint32_t {
 		const auto it = hdr_slot.find(hdr_bit);
@@ -418,7 +420,8 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		/* (the parsed headers are the current window's) */
 		hdr_slot.clear();
 		for (lda_stream_chunk &c : acc)
-			c.hdr_cache = 0;
+			c.hdr_cache = c.hint = 0;
+		d_hints = nullptr;
 		bool cache_queued = false;
 		/* ---- this window's input ---- */
 		const size_t upto = std::min<size_t>(in_nbytes, std::max(copied, hdr) + W);
@@ -667,7 +670,15 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		if (!pin_phase((size_t)np * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
 			return false;
 		ST_TRY(up(d_chunks, hc.data(), (size_t)np * sizeof(lda_stream_chunk)));
-		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n, d_hlens, d_hinfo))
+		/* (the chunks counted together leave the decode pass their lanes' starts:
+		 * a row of 64 per chunk of this launch, see phase_count()) */
+		if (nexact) {
+			d_hints = (uint16_t *)d->shint.reserve((size_t)np * 128 + 64);
+			if (!d_hints)
+				return false;
+		}
+		if (!launch_count(s_comp, np, d_chunks, d_res, d_raw, win_n, d_hlens, d_hinfo,
+				  nexact ? d_hints : nullptr))
 			return false;
 		ST_TRY(back(hr.data(), d_res, (size_t)np * sizeof(lda_stream_res)));
 		dbg("count queued");
@@ -941,7 +952,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				if (!pin_phase((size_t)nr * (sizeof(lda_stream_chunk) + sizeof(lda_stream_res)) + 256))
 					return false;
 				ST_TRY(up(d_rc, rc.data(), (size_t)nr * sizeof(lda_stream_chunk)));
-				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n, d_hlens, d_hinfo))
+				if (!launch_count(s_comp, nr, d_rc, d_rr, d_raw, win_n, d_hlens, d_hinfo, nullptr))
 					return false;
 				ST_TRY(back(rr.data(), d_rr, (size_t)nr * sizeof(lda_stream_res)));
 				dbg("repairs queued");
@@ -961,6 +972,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			}
 			for (uint32_t i : path) {
 				lda_stream_chunk c = pc[i];
+				/* (one of the starts counted together in the window's first
+				 * launch: row i holds where its parse entered the pieces) */
+				c.hint = pc[i].phases && i < np && d_hints ? i + 1 : 0;
 				c.phases = 0;
 				if (c.kind == LDA_CHUNK_WARM) {
 					c.kind = LDA_CHUNK_EXACT;
@@ -1088,7 +1102,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			const uint32_t nk = (uint32_t)std::min<size_t>(BATCH, na - lo);
 			hipLaunchKernelGGL(lda_stream_decode_kernel, dim3(nk), dim3(64),
 					   lda_stream_chunk_lds(), s_comp, nk, d_chunks + lo,
-					   d_res + lo, d_raw, dev_n, d_sym, d_tok, d_hlens, d_hinfo);
+					   d_res + lo, d_raw, dev_n, d_sym, d_tok, d_hlens, d_hinfo, d_hints);
 		}
 		{
 			/* the window chain: groups of chunks side by side with a symbolic

@@ -120,7 +120,8 @@ template <int MODE> static __device__ u32
 chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 	    u32 *__restrict__ tok, lsym *win, lu8 *stage, u64 ring_lo, u32 lane,
 	    u64 bpos_abs, u64 limit_abs, bool warm, u16 *__restrict__ sym,
-	    u64 out0, u64 chunk_abs, u64 *bpos_ret, u64 *out_ret, u32 *bad_ret)
+	    u64 out0, u64 chunk_abs, u64 *bpos_ret, u64 *out_ret, u32 *bad_ret,
+	    const u16 *__restrict__ hint = NULL)
 {
 	const u64 byte0 = bpos_abs >> 3;
 	if (byte0 + 64 > in_n)
@@ -154,6 +155,16 @@ chunk_round(const u8 *inp, u64 in_n, const slds_t *S, const shlds_t *SH,
 	u32 cend = bpos0 + (lane + 1) * cb;
 	cend = cend < lim ? cend : lim;
 	u32 start = bpos0 + lane * cb, end = 0;
+	/* `hint`: token boundaries the count pass met near the lanes' pieces, in
+	 * bits from the round's first (phase_count(): a chunk of a block of one
+	 * codeword length).  A lane that starts at one need not guess - and where
+	 * guesses do not fall in step that is ten parses of the round's twelve.
+	 * Only where the passes start: what they accept is decided as ever. */
+	if (hint != NULL && lane != 0) {
+		const u32 h = hint[lane];
+		if (h != 0xFFFFu && bpos0 + h < lim)
+			start = bpos0 + h;
+	}
 	u32 nbytes = 0, ntok = 0;
 	bool eob = false, dirty = lane < NL;
 	u32 K = NL - 1;
@@ -749,7 +760,8 @@ template <int MODE> static __device__ void
 chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 	  struct lda_stream_res *__restrict__ rs, const u8 *__restrict__ inp,
 	  u64 in_n, u16 *__restrict__ sym, u32 *__restrict__ tok,
-	  const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info)
+	  const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info,
+	  const u16 *__restrict__ hints = NULL)
 {
 	const u32 lane = threadIdx.x;
 	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
@@ -865,7 +877,9 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 			break;
 		u64 np = pos, no = out;
 		u32 pr = chunk_round<MODE>(inp, in_n, S, SH, tok, win, stage, ring_lo, lane,
-					   pos, limit, false, sym, out, chunk_abs, &np, &no, &bad);
+					   pos, limit, false, sym, out, chunk_abs, &np, &no, &bad,
+					   MODE == SM_MARK && hints != NULL && cd->hint &&
+					   pos == cd->start_bit ? hints + (size_t)(cd->hint - 1) * 64 : NULL);
 		if (pr == PAR_STOP) {
 			pr = chunk_seq<MODE>(inp, in_n, S, stage, lane, pos, limit, sym, out,
 					     chunk_abs, &np, &no, &bad);
@@ -927,7 +941,8 @@ chunk_run(const struct lda_stream_chunk *__restrict__ cd,
 static __device__ bool
 phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_res *__restrict__ rs,
 	    u32 K, const u8 *__restrict__ inp, u64 in_n,
-	    const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info)
+	    const u8 *__restrict__ hdr_lens, const u32 *__restrict__ hdr_info,
+	    u16 *__restrict__ hints /* [K][64] or NULL */)
 {
 	const u32 lane = threadIdx.x;
 	slds_t *S = (slds_t *)(lu8 *)(uintptr_t)0;
@@ -1022,6 +1037,10 @@ phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_re
 					active = false;
 					break;
 				}
+				/* (for the decode pass: where this chunk's parse enters
+				 * piece i, in bits from the chunk's start) */
+				if (hints != NULL)
+					hints[lane * 64 + i] = (u16)(pos - bpos0 - lane);
 				if (o >= K) {
 					need = true;
 					last = i == NL - 1;
@@ -1107,7 +1126,7 @@ phase_count(const struct lda_stream_chunk *__restrict__ cd, struct lda_stream_re
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 			struct lda_stream_res *res, const u8 *inp, u64 in_n,
-			u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info)
+			u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info, u16 *hints)
 {
 	if (blockIdx.x >= nchunks)
 		return;
@@ -1117,7 +1136,15 @@ lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 	if (K == ~0u)
 		return;
 	if (K != 0 && K <= nchunks - blockIdx.x) {
-		if (phase_count(chunks + blockIdx.x, res + blockIdx.x, K, inp, in_n, hdr_lens, hdr_info))
+		u16 *hrow = hints ? hints + (size_t)blockIdx.x * 64 : NULL;
+		if (hrow != NULL) {
+			for (u32 r = 0; r < K; r++)
+				hrow[r * 64 + threadIdx.x] = 0xFFFFu;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (phase_count(chunks + blockIdx.x, res + blockIdx.x, K, inp, in_n, hdr_lens, hdr_info,
+				hrow))
 			return;
 		for (u32 j = 0; j < K; j++)
 			chunk_run<SM_COUNT>(chunks + blockIdx.x + j, res + blockIdx.x + j, inp, in_n,
@@ -1131,11 +1158,13 @@ lda_stream_count_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 extern "C" __global__ void __launch_bounds__(64)
 lda_stream_decode_kernel(u32 nchunks, const struct lda_stream_chunk *chunks,
 			 struct lda_stream_res *res, const u8 *inp, u64 in_n,
-			 u16 *sym, u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info)
+			 u16 *sym, u32 *tokscratch, const u8 *hdr_lens, const u32 *hdr_info,
+			 const u16 *hints)
 {
 	if (blockIdx.x < nchunks)
 		chunk_run<SM_MARK>(chunks + blockIdx.x, res + blockIdx.x, inp, in_n, sym,
-				   tokscratch + (size_t)blockIdx.x * PAR_SCRATCH, hdr_lens, hdr_info);
+				   tokscratch + (size_t)blockIdx.x * PAR_SCRATCH, hdr_lens, hdr_info,
+				   hints);
 }
 
 /*

@@ -37,7 +37,8 @@ struct lda_stream_chunk {
 				 * bits with one limit that are counted together, ~0 on the others */
 	uint32_t hdr_cache;	/* 0, or 1 + the slot of lda_stream_hdr_cache_kernel that holds the
 				 * code lengths of the header at hdr_bit */
-	uint32_t pad;
+	uint32_t hint;		/* decode pass: 0, or 1 + the row of token boundaries the count pass
+				 * left for this chunk (phase_count(): starts for the lanes' parses) */
 };
 
 #define LDA_STREAM_OK 0u	/* stopped at the limit */
@@ -61,12 +62,13 @@ struct lda_stream_res {
 extern "C" __global__ void
 lda_stream_count_kernel(uint32_t nchunks, const struct lda_stream_chunk *chunks,
 			struct lda_stream_res *res, const uint8_t *inp, uint64_t in_n,
-			uint32_t *tokscratch, const uint8_t *hdr_lens, const uint32_t *hdr_info);
+			uint32_t *tokscratch, const uint8_t *hdr_lens, const uint32_t *hdr_info,
+			uint16_t *hints);
 extern "C" __global__ void
 lda_stream_decode_kernel(uint32_t nchunks, const struct lda_stream_chunk *chunks,
 			 struct lda_stream_res *res, const uint8_t *inp, uint64_t in_n,
 			 uint16_t *sym, uint32_t *tokscratch, const uint8_t *hdr_lens,
-			 const uint32_t *hdr_info);
+			 const uint32_t *hdr_info, const uint16_t *hints);
 extern "C" __global__ void
 lda_stream_hdr_cache_kernel(const uint8_t *inp, uint64_t in_n, const uint64_t *cand,
 			    const uint32_t *ncand, uint32_t nslots, uint8_t *hdr_lens,
