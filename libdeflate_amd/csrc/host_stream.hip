@@ -269,12 +269,12 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 	 * valid dynamic one: the kernels say what is wrong with it).  Only the
 	 * plan depends on the answer, never the result.
 	 */
-	auto one_length_code = [&](uint64_t hb) -> uint32_t {
+	auto one_length_code = [&](uint64_t hb, uint64_t *first_token) -> uint32_t {
 		static const uint8_t perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 		uint64_t p = hb;
 		if (p + 17 + 19 * 3 > raw_bits || ((peek(p, 3) >> 1) & 3) != 2)
 			return 0;
-		const uint32_t nl = 257 + peek(p + 3, 5), nc = 4 + peek(p + 13, 4);
+		const uint32_t nl = 257 + peek(p + 3, 5), nd = 1 + peek(p + 8, 5), nc = 4 + peek(p + 13, 4);
 		p += 17;
 		uint8_t pl[19] = { 0 };
 		for (uint32_t i = 0; i < nc; i++, p += 3)
@@ -293,16 +293,18 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			first[len] = code;
 			base[len] = len > 1 ? base[len - 1] + cnt[len - 1] : 0;
 		}
-		uint8_t lens[256 + 138];
+		/* (all lengths are read, the offsets' too: behind them is the block's
+		 * first token, where the first of the exact starts lies) */
+		uint8_t lens[320 + 138];
 		uint32_t n = 0;
-		const uint32_t want = nl < 256 ? nl : 256;
+		const uint32_t want = nl < 256 ? nl : 256, total = nl + nd;
 		/* (an ordinary block is told apart after two dozen lengths: under
 		 * three quarters of the literals seen so far on one length - a stream
 		 * of 1 GiB has 3600 blocks, and parsing every header in full was 2 ms
 		 * of its call) */
 		uint32_t seen[16] = { 0 }, nz = 0, most = 0;
-		while (n < want) {
-			if (nz >= 24 && 4 * most < 3 * nz)
+		while (n < total) {
+			if (n < want && nz >= 24 && 4 * most < 3 * nz)
 				return 0;
 			if (p + 32 > raw_bits)
 				return 0;
@@ -318,7 +320,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			}
 			if (sy < 16) {
 				lens[n++] = (uint8_t)sy;
-				if (sy) {
+				if (sy && n <= want) {
 					nz++;
 					most = std::max(most, ++seen[sy]);
 				}
@@ -329,7 +331,7 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				p += 2;
 				for (uint32_t k = 0; k < r; k++, n++)
 					lens[n] = lens[n - 1];
-				if (lens[n - 1]) {
+				if (lens[n - 1] && n <= want) {
 					nz += r;
 					seen[lens[n - 1]] += r;
 					most = std::max(most, seen[lens[n - 1]]);
@@ -358,6 +360,9 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 		 * at 5 % well inside the 1 KiB warm-up, which then costs a ninth of
 		 * what the exact starts cost; at 0.5 % - 256 literals of 8 bits and
 		 * what a compressor squeezes in beside them - in a thousand.) */
+		if (n != total || p >= raw_bits)
+			return 0;
+		*first_token = p;
 		return hist[top] >= 32 && hi <= 11 && 50 * hist[top] >= 49 * (1u << top) ? hi : 0;
 	};
 
@@ -567,13 +572,34 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 			 * end at: P, P + 1, .. P + longest literal codeword.  One of them
 			 * is the true parse; the chain finds it by its key, in the first
 			 * count pass.  (A match across P is not covered: a repair.) */
+			uint64_t tok0 = 0;
 			const uint32_t hi = first.kind == LDA_CHUNK_HEADER && !env.stream_chunk ?
-						    one_length_code(first.hdr_bit) : 0;
+						    one_length_code(first.hdr_bit, &tok0) : 0;
 			/* (the starts of one position are counted together by ONE wave,
 			 * phase_count() of inflate_stream.hip, when the chunk is one
 			 * round of input: 1.5 x TN <= 64 pieces of 384 bits) */
 			const uint64_t TN = 15360;
-			if (hi && nexact + (next - start) / TN * (hi + 1) <= 65536) {
+			if (hi && nexact + ((next - start) / TN + 1) * (hi + 1) <= 65536) {
+				/* (the first of them at the block's first token - the host has
+				 * read the header to its end -, so that the chunk that reads
+				 * the header holds no tokens: as the only chunk of the block
+				 * counted alone it was the only one the decode pass had no
+				 * starts for, 1.1 M cycles against 0.4.  The other positions
+				 * stay where they were.) */
+				const uint64_t P1 = start + TN;
+				const bool more = P1 + TN / 2 <= next;
+				const uint64_t lim0 = more ? P1 : next;
+				if (tok0 > start && tok0 + hi + 2 < lim0 && lim0 - tok0 <= 24000)
+					for (uint32_t j = 0; j <= hi; j++) {
+						planned q = {};
+						q.c.kind = LDA_CHUNK_EXACT;
+						q.c.hdr_bit = under;
+						q.c.start_bit = q.c.target_bit = tok0 + j;
+						q.c.phases = j ? ~0u : hi + 1;
+						q.at = tok0;
+						plan.push_back(q);
+						nexact++;
+					}
 				for (uint64_t P = start + TN; P + TN / 2 <= next; P += TN)
 					for (uint32_t j = 0; j <= hi; j++) {
 						planned q = {};
