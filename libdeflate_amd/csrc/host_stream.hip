@@ -614,7 +614,18 @@ bool decompress_stream_parallel(struct libdeflate_decompressor *d, int format,
 				return;
 			}
 			const uint64_t safe = first.kind == LDA_CHUNK_HEADER ? start + HDRSAFE : start;
-			for (uint64_t P = start + T; P + T / 2 <= next; P += T) {
+			/* (the block in equal parts of at most T: with steps of T and what
+			 * is left added to the last, a block's last chunk was up to 1.5 T -
+			 * and the count and decode launches last as long as their longest
+			 * chunk) */
+			/* (not the window's last block: a chunk that starts within T of
+			 * the end of the input runs its last rounds through the
+			 * sequential tail code, and one that close to the end was the
+			 * slowest chunk of the count launch by a factor of two) */
+			const uint64_t blen = next > start ? next - start : 0;
+			const uint64_t nparts = std::max<uint64_t>(1, (blen + T - 1) / T);
+			const uint64_t step = next == R1 ? T : std::max<uint64_t>(T / 2, blen / nparts);
+			for (uint64_t P = start + step; P + step / 2 <= next; P += step) {
 				uint64_t ws = P > OV ? P - OV : 0;
 				if (ws < safe)
 					ws = safe;
